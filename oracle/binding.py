@@ -1,0 +1,244 @@
+"""ctypes doorway to the checkers: oracle/libsvc_oracle.so (C restatement) and,
+when it has been built, oracle/_ref/libsvc_ref.so (the unmodified reference
+libs/motion.cpp compiled in place).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from scalable_video_codec_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libsvc_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libsvc_ref.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_u8pp = C.POINTER(_u8p)
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_f64p = C.POINTER(C.c_double)
+
+
+class RansacParams(C.Structure):
+    _fields_ = [("subset_sz", C.c_uint32), ("inlier_thresh", C.c_float),
+                ("success_prob", C.c_float), ("inlier_ratio", C.c_float)]
+
+
+DEFAULT_RANSAC = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def _pyr_ptrs(pyr: Sequence[np.ndarray]):
+    arr = (_u8p * len(pyr))()
+    for i, p in enumerate(pyr):
+        assert p.dtype == np.uint8 and p.flags["C_CONTIGUOUS"]
+        arr[i] = _ptr(p, _u8p)
+    return arr
+
+
+class Oracle:
+    """The C restatement (svc_oracle.h)."""
+
+    def __init__(self, path: str = ORACLE_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle oracle`")
+        L = self.lib = C.CDLL(path)
+        L.svc_oracle_mad.restype = C.c_float
+        L.svc_oracle_mad.argtypes = [_u8p, _u8p] + [C.c_uint32] * 7
+        L.svc_oracle_ebma.restype = None
+        L.svc_oracle_ebma.argtypes = [_u8p, _u8p] + [C.c_uint32] * 5 + [_f32p, _f32p]
+        L.svc_oracle_refine.restype = None
+        L.svc_oracle_refine.argtypes = [_u8p, _u8p] + [C.c_uint32] * 5 + [_f32p, _f32p]
+        L.svc_oracle_hbma.restype = C.c_int
+        L.svc_oracle_hbma.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 6 + [_f32p, _f32p]
+        L.svc_oracle_hbma16_sse2.restype = C.c_int
+        L.svc_oracle_hbma16_sse2.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 3 + [_f32p, _f32p]
+        L.svc_oracle_ransac_iter_count.restype = C.c_uint32
+        L.svc_oracle_ransac_iter_count.argtypes = [RansacParams]
+        L.svc_oracle_ransac.restype = None
+        L.svc_oracle_ransac.argtypes = [_f32p, C.c_uint32, RansacParams, _u32p, C.c_uint32,
+                                        _f32p, _f32p, _u32p, _u32p]
+        L.svc_oracle_fg_mask.restype = None
+        L.svc_oracle_fg_mask.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_quant.restype = None
+        L.svc_oracle_quant.argtypes = [_f32p, C.c_uint64, C.c_uint32]
+        L.svc_oracle_quant_frame.restype = None
+        L.svc_oracle_quant_frame.argtypes = [_f32p] + [C.c_uint32] * 4 + [_u32p, C.c_uint32, C.c_uint32]
+        L.svc_oracle_dct_frame_f64.restype = None
+        L.svc_oracle_dct_frame_f64.argtypes = [_u8p] + [C.c_uint32] * 4 + [_f64p]
+        L.svc_oracle_dct_frame_f32.restype = None
+        L.svc_oracle_dct_frame_f32.argtypes = [_u8p] + [C.c_uint32] * 4 + [_f32p]
+
+    # -- motion --
+    def ebma(self, tracked, anchor, r, bw, bh):
+        h, w = tracked.shape
+        n = (w // bw) * (h // bh)
+        mv = np.empty((n, 2), np.float32)
+        mad = np.empty(n, np.float32)
+        self.lib.svc_oracle_ebma(_ptr(tracked, _u8p), _ptr(anchor, _u8p), w, h, r, bw, bh,
+                                 _ptr(mv, _f32p), _ptr(mad, _f32p))
+        return mv, mad
+
+    def refine(self, tracked, anchor, bw, bh, r, mv, mad):
+        h, w = tracked.shape
+        mv = np.ascontiguousarray(mv, np.float32).copy()
+        mad = np.ascontiguousarray(mad, np.float32).copy()
+        self.lib.svc_oracle_refine(_ptr(tracked, _u8p), _ptr(anchor, _u8p), w, h, bw, bh, r,
+                                   _ptr(mv, _f32p), _ptr(mad, _f32p))
+        return mv, mad
+
+    def hbma(self, tracked_pyr, anchor_pyr, r, bw, bh):
+        h, w = tracked_pyr[0].shape
+        n = (w // bw) * (h // bh)
+        mv = np.empty((n, 2), np.float32)
+        mad = np.empty(n, np.float32)
+        rc = self.lib.svc_oracle_hbma(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr),
+                                      len(tracked_pyr), w, h, r, bw, bh,
+                                      _ptr(mv, _f32p), _ptr(mad, _f32p))
+        if rc:
+            raise ValueError("svc_oracle_hbma: precondition violated")
+        return mv, mad
+
+    def hbma16_sse2(self, tracked_pyr, anchor_pyr, r):
+        assert len(tracked_pyr) == 4
+        h, w = tracked_pyr[0].shape
+        n = (w // 16) * (h // 16)
+        mv = np.empty((n, 2), np.float32)
+        mad = np.empty(n, np.float32)
+        rc = self.lib.svc_oracle_hbma16_sse2(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr),
+                                             w, h, r, _ptr(mv, _f32p), _ptr(mad, _f32p))
+        if rc:
+            raise ValueError("svc_oracle_hbma16_sse2: precondition violated")
+        return mv, mad
+
+    # -- RANSAC --
+    def ransac_iter_count(self, **p) -> int:
+        return int(self.lib.svc_oracle_ransac_iter_count(RansacParams(**p)))
+
+    def ransac(self, mv, samples, gm_in=(0.0, 0.0), n: Optional[int] = None, **p):
+        """`mv` may hold n + 1 vectors (see svc_oracle.h); n defaults to len(mv)."""
+        mv = np.ascontiguousarray(mv, np.float32)
+        n = len(mv) if n is None else n
+        samples = np.ascontiguousarray(samples, np.uint32)
+        params = RansacParams(**p)
+        iters = samples.size // params.subset_sz
+        rmse = C.c_float(0)
+        gm = np.array(gm_in, np.float32)
+        inl = np.empty(max(n, 1), np.uint32)
+        cnt = C.c_uint32(0)
+        self.lib.svc_oracle_ransac(_ptr(mv, _f32p), n, params, _ptr(samples, _u32p), iters,
+                                   C.byref(rmse), _ptr(gm, _f32p), _ptr(inl, _u32p), C.byref(cnt))
+        return gm, np.float32(rmse.value), inl[:cnt.value].copy()
+
+    def fg_mask(self, inliers, n):
+        inliers = np.ascontiguousarray(inliers, np.uint32)
+        mask = np.empty(n, np.uint8)
+        self.lib.svc_oracle_fg_mask(_ptr(inliers, _u32p), inliers.size, n, _ptr(mask, _u8p))
+        return mask
+
+    # -- quant / DCT --
+    def quant(self, coeffs, step):
+        out = np.ascontiguousarray(coeffs, np.float32).copy()
+        self.lib.svc_oracle_quant(_ptr(out, _f32p), out.size, step)
+        return out
+
+    def quant_frame(self, planes, mv_bw, mv_bh, block_types, fg_step, bg_step):
+        out = np.ascontiguousarray(planes, np.float32).copy()
+        _, h, w = out.shape
+        bt = np.ascontiguousarray(block_types, np.uint32)
+        self.lib.svc_oracle_quant_frame(_ptr(out, _f32p), w, h, mv_bw, mv_bh, _ptr(bt, _u32p),
+                                        fg_step, bg_step)
+        return out
+
+    def dct_frame_f64(self, bgr, bw, bh):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        out = np.empty((3, h, w), np.float64)
+        self.lib.svc_oracle_dct_frame_f64(_ptr(bgr, _u8p), w, h, bw, bh, _ptr(out, _f64p))
+        return out
+
+    def dct_frame_f32(self, bgr, bw, bh):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        out = np.empty((3, h, w), np.float32)
+        self.lib.svc_oracle_dct_frame_f32(_ptr(bgr, _u8p), w, h, bw, bh, _ptr(out, _f32p))
+        return out
+
+
+class Reference:
+    """The unmodified reference libs/motion.cpp (oracle/_ref/libsvc_ref.so)."""
+
+    def __init__(self, path: str = REF_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
+        L = self.lib = C.CDLL(path)
+        L.svc_ref_seed.restype = C.c_uint
+        L.svc_ref_has_sse2.restype = C.c_int
+        L.svc_ref_ebma.restype = None
+        L.svc_ref_ebma.argtypes = [_u8p, _u8p] + [C.c_uint32] * 5 + [_f32p, _f32p]
+        L.svc_ref_hbma.restype = None
+        L.svc_ref_hbma.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 6 + [_f32p, _f32p]
+        L.svc_ref_hbma16_sse2.restype = None
+        L.svc_ref_hbma16_sse2.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 3 + [_f32p, _f32p]
+        L.svc_ref_ransac.restype = C.c_uint32
+        L.svc_ref_ransac.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                     _f32p, _f32p, _u32p]
+        L.svc_ref_ransac_draw.restype = None
+        L.svc_ref_ransac_draw.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_SO)
+
+    def ebma(self, tracked, anchor, r, bw, bh):
+        h, w = tracked.shape
+        n = (w // bw) * (h // bh)
+        mv = np.empty((n, 2), np.float32)
+        mad = np.empty(n, np.float32)
+        self.lib.svc_ref_ebma(_ptr(tracked, _u8p), _ptr(anchor, _u8p), w, h, r, bw, bh,
+                              _ptr(mv, _f32p), _ptr(mad, _f32p))
+        return mv, mad
+
+    def hbma(self, tracked_pyr, anchor_pyr, r, bw, bh):
+        h, w = tracked_pyr[0].shape
+        n = (w // bw) * (h // bh)
+        mv = np.empty((n, 2), np.float32)
+        mad = np.empty(n, np.float32)
+        self.lib.svc_ref_hbma(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr), len(tracked_pyr),
+                              w, h, r, bw, bh, _ptr(mv, _f32p), _ptr(mad, _f32p))
+        return mv, mad
+
+    def hbma16_sse2(self, tracked_pyr, anchor_pyr, r):
+        assert len(tracked_pyr) == 4 and self.lib.svc_ref_has_sse2()
+        h, w = tracked_pyr[0].shape
+        n = (w // 16) * (h // 16)
+        mv = np.empty((n, 2), np.float32)
+        mad = np.empty(n, np.float32)
+        self.lib.svc_ref_hbma16_sse2(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr), w, h, r,
+                                     _ptr(mv, _f32p), _ptr(mad, _f32p))
+        return mv, mad
+
+    def ransac(self, mv_n_plus_1, n, gm_in=(0.0, 0.0), **p):
+        """`mv_n_plus_1` holds n + 1 vectors (the reference may read entry n)."""
+        mv = np.ascontiguousarray(mv_n_plus_1, np.float32)
+        assert len(mv) == n + 1
+        rmse = C.c_float(0)
+        gm = np.array(gm_in, np.float32)
+        inl = np.empty(max(n, 1), np.uint32)
+        cnt = self.lib.svc_ref_ransac(_ptr(mv, _f32p), n, p["subset_sz"], p["inlier_thresh"],
+                                      p["success_prob"], p["inlier_ratio"], C.byref(rmse),
+                                      _ptr(gm, _f32p), _ptr(inl, _u32p))
+        return gm, np.float32(rmse.value), inl[:cnt].copy()
+
+    def ransac_draw(self, n, subset_sz, iter_count):
+        s = np.empty(iter_count * subset_sz, np.uint32)
+        self.lib.svc_ref_ransac_draw(n, subset_sz, iter_count, _ptr(s, _u32p))
+        return s

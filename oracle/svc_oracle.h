@@ -1,0 +1,128 @@
+/*
+ * svc_oracle.h -- CPU restatement of the reference encode hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / the reported CPU
+ * baseline.  The product path (scalable_video_codec_amd/csrc + include/) never
+ * links, imports or falls back to it.
+ *
+ * Parity status
+ *   HBMA / EBMA / refinement / RANSAC : PINNED.  Checked bit-for-bit against
+ *       the unmodified reference libs/motion.cpp compiled in place into
+ *       oracle/_ref/ (tests/test_oracle_vs_ref.py) and against golden vectors
+ *       the reference produced (tests/golden/, made by tests/golden/make_golden.py).
+ *   quantisation : restated from libs/decoder.cpp:130-144, pinned by the hand
+ *       vectors of SURVEY.md 8(c) (the TU needs OpenCV, so it cannot be built).
+ *   DCT : PARITY UNPINNED.  The arithmetic lives in OpenCV 3.4.x cv::dct
+ *       (libs/encoder.cpp:335), which is neither vendored nor installed.  The
+ *       oracle of record is the float64 orthonormal DCT-II from its definition.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).
+ */
+#ifndef SVC_ORACLE_H
+#define SVC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  float x;
+  float y;
+} svc_oracle_vec2f; /* libs/math.hpp:181-185 (Vec2f) */
+
+typedef struct {
+  uint32_t subset_sz;
+  float inlier_thresh;
+  float success_prob;
+  float inlier_ratio;
+} svc_oracle_ransac_params; /* libs/motion.hpp:60-79 (RansacParams) */
+
+/* libs/motion.cpp:17-43 (Mad).  a = tracked, b = anchor in every caller. */
+float svc_oracle_mad(const uint8_t* a_frame, const uint8_t* b_frame,
+                     uint32_t frame_w, uint32_t ax, uint32_t ay, uint32_t bx,
+                     uint32_t by, uint32_t block_w, uint32_t block_h);
+
+/* libs/motion.cpp:268-340 (EstimateMotionExhaustiveSearch). */
+void svc_oracle_ebma(const uint8_t* tracked, const uint8_t* anchor,
+                     uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                     uint32_t block_w, uint32_t block_h, svc_oracle_vec2f* mv,
+                     float* min_mad);
+
+/* libs/motion.cpp:342-410 (RefineHierMotionEst). */
+void svc_oracle_refine(const uint8_t* tracked, const uint8_t* anchor,
+                       uint32_t frame_w, uint32_t frame_h, uint32_t block_w,
+                       uint32_t block_h, uint32_t search_range,
+                       svc_oracle_vec2f* mv, float* min_mad);
+
+/* libs/motion.cpp:412-465 (EstimateMotionHierarchical).  Returns 0, or 1 when
+ * a precondition the reference only asserts (:422-433) is violated. */
+int svc_oracle_hbma(const uint8_t* const* tracked_pyr,
+                    const uint8_t* const* anchor_pyr, uint32_t level_count,
+                    uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                    uint32_t block_w, uint32_t block_h, svc_oracle_vec2f* mv,
+                    float* min_mad);
+
+/* libs/motion.cpp:691-749 (EstimateMotionHierarchical16x16Sse2): L = 4,
+ * 16x16, psadbw at the two finest levels (:472-550).  CPU-baseline "port". */
+int svc_oracle_hbma16_sse2(const uint8_t* const* tracked_pyr,
+                           const uint8_t* const* anchor_pyr, uint32_t frame_w,
+                           uint32_t frame_h, uint32_t search_range,
+                           svc_oracle_vec2f* mv, float* min_mad);
+
+/* libs/motion.cpp:144-149 (IterCount). */
+uint32_t svc_oracle_ransac_iter_count(svc_oracle_ransac_params p);
+
+/*
+ * libs/motion.cpp:182-266 (EstimateGlobalMotionRansac) with the random draws
+ * made explicit: `samples` holds iter_count * subset_sz indices, iteration-major,
+ * i.e. exactly the accepted values of `subset[i] = distrib(reng)` (:215).  The
+ * reference draws from [0, N] inclusive (:208, off by one); an index equal to N
+ * is honoured here as a plain array index, so the caller owns motion_field[N]
+ * in that case.  `global_motion` is in/out: its incoming value is what the
+ * reference reads uninitialised at :241-242 when no iteration found
+ * subset_sz inliers.  `inliers` must hold N entries.
+ */
+void svc_oracle_ransac(const svc_oracle_vec2f* motion_field, uint32_t n,
+                       svc_oracle_ransac_params params, const uint32_t* samples,
+                       uint32_t iter_count, float* rmse,
+                       svc_oracle_vec2f* global_motion, uint32_t* inliers,
+                       uint32_t* inlier_count);
+
+/* libs/encoder.cpp:507-513: fg mask = 255 everywhere except RANSAC inliers. */
+void svc_oracle_fg_mask(const uint32_t* inliers, uint32_t inlier_count,
+                        uint32_t n, uint8_t* mask);
+
+/* libs/decoder.cpp:130-144 (quant lines of DecodeBlock), one coefficient run. */
+void svc_oracle_quant(float* coeffs, uint64_t n, uint32_t step);
+
+/* libs/decoder.cpp:130-135 step choice + :140-144, applied to a planar frame
+ * laid out as libs/encoder.cpp:323-339 leaves it (3 planes, H x W f32); the
+ * type of the tile at (x, y) is block_types[(y / mv_bh) * mv_fw + x / mv_bw]
+ * (libs/encoder.cpp:243-249). */
+void svc_oracle_quant_frame(float* planes, uint32_t w, uint32_t h,
+                            uint32_t mv_bw, uint32_t mv_bh,
+                            const uint32_t* block_types, uint32_t fg_step,
+                            uint32_t bg_step);
+
+/* libs/encoder.cpp:323-339 (Dct) with cv::dct restated as the float64
+ * orthonormal DCT-II.  `bgr` is H x W x 3 u8 interleaved (what :638 converts
+ * to f32); `planes64` receives 3 planar H x W doubles in B, G, R order. */
+void svc_oracle_dct_frame_f64(const uint8_t* bgr, uint32_t w, uint32_t h,
+                              uint32_t block_w, uint32_t block_h,
+                              double* planes64);
+
+/* Same result rounded once to f32 -- the CPU baseline the bench times. */
+void svc_oracle_dct_frame_f32(const uint8_t* bgr, uint32_t w, uint32_t h,
+                              uint32_t block_w, uint32_t block_h,
+                              float* planes32);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SVC_ORACLE_H */
