@@ -1,0 +1,193 @@
+/*
+ * svc_hip.h -- C ABI of the MI355X (gfx950) encode hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its hot path is
+ * plain C++ free functions (libs/motion.hpp:100-153) plus two file-static helpers
+ * (Dct, libs/encoder.cpp:323-339; the quant lines of DecodeBlock,
+ * libs/decoder.cpp:130-144).  include/svc/motion.hpp re-declares those C++
+ * signatures verbatim and implements them on top of the *_host entry points
+ * below; everything that touches the GPU goes through this header and nothing
+ * else.  Plain pointers and sizes only -- no C++ or torch types.
+ *
+ * Conventions
+ *  - Every function returns an svc_status (0 = ok).  svc_hip_last_error() gives
+ *    the message of the calling thread's last failure.  The reference's functions
+ *    return void and only assert their preconditions (libs/motion.cpp:417-433);
+ *    here a violated precondition is SVC_ERR_INVALID_ARG, never UB.
+ *  - "d_" pointers are device (HBM) pointers; everything else is host memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  The
+ *    device-pointer entry points only enqueue work: no allocation, no
+ *    synchronisation, safe to capture into a hipGraph.
+ *  - A packed pyramid is the L level planes of one frame back to back, level 0
+ *    (full resolution) first, each plane (W>>l) x (H>>l) u8, row stride = width
+ *    (the layout of the cv::Mat1b planes the reference passes,
+ *    libs/encoder.cpp:197-219).  Its size is svc_hip_pyramid_bytes().
+ *  - A motion field is (W/block_w) x (H/block_h) row-major (libs/motion.cpp:284-306);
+ *    MVs are {x, y} f32 pairs (Vec2f, libs/math.hpp:181-185).
+ */
+#ifndef SVC_HIP_H
+#define SVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum svc_status {
+  SVC_OK = 0,
+  SVC_ERR_INVALID_ARG = 1, /* a precondition the reference asserts is violated */
+  SVC_ERR_UNSUPPORTED = 2, /* valid for the reference, outside this build's kernels */
+  SVC_ERR_HIP = 3,         /* a HIP runtime call failed (message has the hipError) */
+  SVC_ERR_NO_DEVICE = 4
+} svc_status;
+
+/* libs/motion.hpp:60-79 (RansacParams), same field order and types. */
+typedef struct svc_ransac_params {
+  uint32_t subset_sz;
+  float inlier_thresh;
+  float success_prob;
+  float inlier_ratio;
+} svc_ransac_params;
+
+/* flags for svc_hip_hbma_pairs / svc_hip_hbma_host */
+#define SVC_HBMA_AUTO 0u
+#define SVC_HBMA_FORCE_WAVE_PER_BLOCK 1u /* per-level LDS-staged kernel (any shape) */
+#define SVC_HBMA_FORCE_FUSED 2u          /* fused all-level kernel; UNSUPPORTED if the shape does not fit */
+
+const char* svc_hip_last_error(void);
+int svc_hip_abi_version(void);
+int svc_hip_device_count(int* count);
+
+/* Bytes of one packed pyramid. */
+uint64_t svc_hip_pyramid_bytes(uint32_t frame_w, uint32_t frame_h, uint32_t level_count);
+
+/* ------------------------------------------------------------------------- *
+ * Motion estimation, device-resident and batched over frame pairs.
+ * Pair p reads the tracked pyramid at d_tracked + p * pair_stride_bytes and the
+ * anchor pyramid at d_anchor + p * pair_stride_bytes.  For a clip stored as
+ * consecutive packed pyramids, d_anchor = d_tracked + pair_stride_bytes gives the
+ * reference's frame order (tracked = previous source frame, libs/encoder.cpp:661-663).
+ * Outputs: d_mv_xy [n_pairs][blocks][2], d_min_mad [n_pairs][blocks], both fully
+ * overwritten (libs/motion.cpp:288-291).
+ * ------------------------------------------------------------------------- */
+
+/* replaces EstimateMotionHierarchical, libs/motion.hpp:134-138 / motion.cpp:412-465 */
+int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor,
+                       uint64_t pair_stride_bytes, uint32_t n_pairs,
+                       uint32_t level_count, uint32_t frame_w, uint32_t frame_h,
+                       uint32_t search_range, uint32_t block_w, uint32_t block_h,
+                       float* d_mv_xy, float* d_min_mad, uint32_t flags,
+                       void* stream);
+
+/* replaces EstimateMotionExhaustiveSearch, libs/motion.hpp:106-110 / motion.cpp:268-340.
+ * Planes are single-level here: pair p's planes sit at base + p * pair_stride_bytes. */
+int svc_hip_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor,
+                       uint64_t pair_stride_bytes, uint32_t n_pairs,
+                       uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                       uint32_t block_w, uint32_t block_h, float* d_mv_xy,
+                       float* d_min_mad, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Global motion (RANSAC), batched over frames.  Replaces
+ * EstimateGlobalMotionRansac, libs/motion.hpp:100-103 / motion.cpp:182-266, with
+ * the random draws made explicit: d_samples is [n_frames][iter_count][subset_sz]
+ * accepted sample indices (each < blocks; the reference's inclusive upper bound,
+ * motion.cpp:208, is an out-of-bounds read and is not reproduced).
+ * Outputs per frame: d_gm_xy [2] (in/out, see motion.cpp:241-242), d_rmse,
+ * d_inlier_mask [blocks] u8 (1 = inlier, i.e. background; the ascending index
+ * list of motion.cpp:261-265 is the positions of the 1s), d_inlier_count.
+ * ------------------------------------------------------------------------- */
+uint32_t svc_hip_ransac_iter_count(svc_ransac_params params); /* motion.cpp:144-149 */
+
+int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
+                          svc_ransac_params params, const uint32_t* d_samples,
+                          uint32_t iter_count, float* d_gm_xy, float* d_rmse,
+                          uint8_t* d_inlier_mask, uint32_t* d_inlier_count,
+                          void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Transform.  d_bgr: n_frames frames of H x W x 3 u8, interleaved B,G,R (the
+ * padded frame the reference converts to f32 at libs/encoder.cpp:638), frame f at
+ * d_bgr + f * frame_stride_bytes.  d_planes: [n_frames][3][H][W] f32, plane order
+ * B,G,R (cv::split, encoder.cpp:328); coefficient (v,u) of the tile at (x,y) is at
+ * row y+v, column x+u (in-place cv::dct on the ROI, encoder.cpp:330-337).
+ * block_w/block_h in {8, 16}, dividing W and H.
+ * ------------------------------------------------------------------------- */
+
+/* replaces static Dct, libs/encoder.cpp:323-339 */
+int svc_hip_dct_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes,
+                       uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                       uint32_t block_w, uint32_t block_h, float* d_planes,
+                       void* stream);
+
+/* Dct followed by the decoder's quantise-round-dequantise (libs/decoder.cpp:130-144)
+ * in one pass.  d_block_types: [n_frames][mv blocks] region ids, 0 = background
+ * (libs/codec.hpp:6); the tile at (x,y) takes the type of MV block
+ * (y / mv_block_h) * (W / mv_block_w) + x / mv_block_w (encoder.cpp:243-249). */
+int svc_hip_dct_quant_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes,
+                             uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                             uint32_t block_w, uint32_t block_h,
+                             const uint32_t* d_block_types, uint32_t mv_block_w,
+                             uint32_t mv_block_h, uint32_t fg_step,
+                             uint32_t bg_step, float* d_planes, void* stream);
+
+/* replaces the quant lines of DecodeBlock, libs/decoder.cpp:140-144, in place */
+int svc_hip_quant(float* d_coeffs, uint64_t n, uint32_t step, void* stream);
+
+int svc_hip_quant_frames(float* d_planes, uint32_t n_frames, uint32_t frame_w,
+                         uint32_t frame_h, uint32_t mv_block_w, uint32_t mv_block_h,
+                         const uint32_t* d_block_types, uint32_t fg_step,
+                         uint32_t bg_step, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Pre-step: luma + pyramid on the device, so the pyramid never
+ * crosses PCIe.  Stands in for cv::cvtColor(BGR2YUV) + cv::extractChannel +
+ * cv::buildPyramid (libs/encoder.cpp:468-470) with this repo's fixed-point
+ * definitions (parity with OpenCV unpinned offline).
+ * d_pyr: [n_frames] packed pyramids, frame f at d_pyr + f * pyr_stride_bytes.
+ * ------------------------------------------------------------------------- */
+int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes,
+                                uint32_t n_frames, uint32_t frame_w,
+                                uint32_t frame_h, uint32_t level_count,
+                                uint8_t* d_pyr, uint64_t pyr_stride_bytes,
+                                void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Host-pointer forms: what the C++ wrappers of include/svc/motion.hpp call.  They
+ * stage through pinned buffers owned by the library, run the device entry point
+ * on an internal stream and synchronise before returning (the reference's calls
+ * are synchronous, libs/encoder.cpp:472-498).  Thread-safe; per-thread staging.
+ * ------------------------------------------------------------------------- */
+int svc_hip_hbma_host(const uint8_t* const* tracked_pyr,
+                      const uint8_t* const* anchor_pyr, uint32_t level_count,
+                      uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                      uint32_t block_w, uint32_t block_h, float* mv_xy,
+                      float* min_mad, uint32_t flags);
+
+int svc_hip_ebma_host(const uint8_t* tracked, const uint8_t* anchor,
+                      uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                      uint32_t block_w, uint32_t block_h, float* mv_xy,
+                      float* min_mad);
+
+int svc_hip_ransac_host(const float* mv_xy, uint32_t blocks,
+                        svc_ransac_params params, const uint32_t* samples,
+                        uint32_t iter_count, float* gm_xy, float* rmse,
+                        uint32_t* inlier_indices, uint32_t* inlier_count);
+
+int svc_hip_dct_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h,
+                     uint32_t block_w, uint32_t block_h, float* planes);
+
+int svc_hip_dct_quant_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h,
+                           uint32_t block_w, uint32_t block_h,
+                           const uint32_t* block_types, uint32_t mv_block_w,
+                           uint32_t mv_block_h, uint32_t fg_step, uint32_t bg_step,
+                           float* planes);
+
+int svc_hip_quant_host(float* coeffs, uint64_t n, uint32_t step);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SVC_HIP_H */

@@ -1,0 +1,94 @@
+"""In-tree build of the native libraries (hipcc cross-compiles gfx950 without a GPU).
+
+  libsvc_hip.so     HIP kernels + the C ABI of include/svc_hip.h
+  libsvc_motion.so  C++ wrappers with the reference's own signatures
+                    (include/svc/motion.hpp), on top of the C ABI
+
+Both land next to this file; they are git-ignored but travel to the GPU box.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+OBJ = os.path.join(PKG, "_obj")
+LIB_HIP = os.path.join(PKG, "libsvc_hip.so")
+LIB_MOTION = os.path.join(PKG, "libsvc_motion.so")
+
+HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip"]
+HOST_SOURCES = [os.path.join("host", "motion_hip.cpp")]
+
+# -ffp-contract=off: the reference's float expressions (RANSAC inlier test, quant) are
+# evaluated without FMA on baseline x86-64; the DCT asks for its FMAs explicitly.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X path cannot be built")
+    return exe
+
+
+def _newer(target: str, deps: List[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def _run(cmd: List[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build step failed: {os.path.basename(cmd[-1])}")
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "dct_tables.inc"),
+               os.path.join(INCLUDE, "svc_hip.h")]
+    jobs, objs = [], []
+    for s in HIP_SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not _newer(obj, [src] + headers):
+            jobs.append([_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj])
+    if jobs:
+        if verbose:
+            print(f"[build] compiling {len(jobs)} HIP translation unit(s) for gfx950", flush=True)
+        with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or not os.path.exists(LIB_HIP):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP, *objs])
+    return LIB_HIP
+
+
+def build_motion(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(INCLUDE, "svc", h) for h in ("motion.hpp", "math.hpp", "types.hpp")]
+    if force or not _newer(LIB_MOTION, deps + [LIB_HIP]):
+        cxx = shutil.which("g++") or "g++"
+        _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", f"-I{INCLUDE}", f"-I{os.path.join(INCLUDE, 'svc')}",
+              "-o", LIB_MOTION, *srcs, f"-L{PKG}", "-lsvc_hip", "-Wl,-rpath,$ORIGIN"])
+    return LIB_MOTION
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force, verbose)
+    build_motion(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print(LIB_HIP)
+    print(LIB_MOTION)

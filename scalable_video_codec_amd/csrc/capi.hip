@@ -1,0 +1,381 @@
+// capi.hip -- the extern "C" surface declared in include/svc_hip.h.
+//
+// Device-pointer entry points validate, pick a kernel and enqueue.  Host-pointer
+// entry points add pinned staging, an internal stream and a final synchronise, so
+// that the C++ wrappers of include/svc/motion.hpp behave like the reference's
+// synchronous calls (libs/encoder.cpp:472-498).
+#include <cmath>
+#include <cstring>
+
+#include "svc_common.hpp"
+
+namespace svc {
+
+static thread_local char g_err[kErrBufSize] = "";
+char* last_error_buf() { return g_err; }
+
+bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
+int launch_hbma_fused(const uint8_t*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                      uint32_t, float*, float*, hipStream_t);
+int launch_hbma_wave(const uint8_t*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                     uint32_t, uint32_t, uint32_t, float*, float*, hipStream_t);
+
+static inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// The reference's asserts (libs/motion.cpp:417-433) as a status, plus what a
+// pyramid needs to be well formed (every level an exact halving).
+static int validate_hbma(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh) {
+  SVC_REQUIRE(levels > 0 && levels <= 16, "hbma: level_count %u out of range (motion.cpp:422)", levels);
+  SVC_REQUIRE(bw > 0 && bh > 0, "hbma: block %ux%u must be positive (motion.cpp:423-424)", bw, bh);
+  SVC_REQUIRE(w > 0 && h > 0, "hbma: frame %ux%u must be positive (motion.cpp:425-426)", w, h);
+  SVC_REQUIRE(w % bw == 0 && h % bh == 0, "hbma: frame %ux%u not divisible by block %ux%u (motion.cpp:428-429)", w, h, bw, bh);
+  const uint32_t f = 1u << (levels - 1);
+  SVC_REQUIRE(range >= f, "hbma: search_range %u < 2^(levels-1) = %u (motion.cpp:433)", range, f);
+  SVC_REQUIRE(bw % f == 0 && bh % f == 0 && w % f == 0 && h % f == 0,
+              "hbma: block %ux%u and frame %ux%u must be divisible by 2^(levels-1) = %u", bw, bh, w, h, f);
+  return SVC_OK;
+}
+
+int launch_hbma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride, uint32_t n_pairs,
+                uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh,
+                float* d_mv, float* d_mad, uint32_t flags, hipStream_t stream) {
+  const bool can_fuse = fused_supported(levels, w, h, range, bw, bh) && aligned(d_tracked, 4) &&
+                        aligned(d_anchor, 4) && pair_stride % 4 == 0 && aligned(d_mv, 8);
+  if (flags & SVC_HBMA_FORCE_FUSED) {
+    if (!can_fuse)
+      return fail(SVC_ERR_UNSUPPORTED, "hbma: fused kernel needs 16x16 blocks, 3-4 levels, r_top in {1,2}, 4-byte aligned planes");
+    return launch_hbma_fused(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, d_mv, d_mad, stream);
+  }
+  if (can_fuse && !(flags & SVC_HBMA_FORCE_WAVE_PER_BLOCK))
+    return launch_hbma_fused(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, d_mv, d_mad, stream);
+  return launch_hbma_wave(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, bw, bh, d_mv, d_mad, stream);
+}
+
+// ---- per-thread staging for the host-pointer entry points ----------------------
+struct Staging {
+  hipStream_t stream = nullptr;
+  uint8_t* dev = nullptr;
+  uint8_t* pin = nullptr;
+  size_t cap = 0;
+  ~Staging() {
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int ensure(size_t bytes) {
+    if (!stream) SVC_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (bytes <= cap) return SVC_OK;
+    if (dev) { (void)hipFree(dev); dev = nullptr; }
+    if (pin) { (void)hipHostFree(pin); pin = nullptr; }
+    cap = 0;
+    size_t want = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    SVC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), want));
+    SVC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), want, hipHostMallocDefault));
+    cap = want;
+    return SVC_OK;
+  }
+};
+static thread_local Staging g_stage;
+
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(SVC_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU path",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  return SVC_OK;
+}
+
+}  // namespace svc
+
+using namespace svc;
+
+extern "C" {
+
+const char* svc_hip_last_error(void) { return g_err; }
+int svc_hip_abi_version(void) { return 1; }
+
+int svc_hip_device_count(int* count) {
+  SVC_REQUIRE(count, "device_count: null output");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *count = e == hipSuccess ? n : 0;
+  return SVC_OK;
+}
+
+uint64_t svc_hip_pyramid_bytes(uint32_t w, uint32_t h, uint32_t levels) { return pyramid_bytes(w, h, levels); }
+
+int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride_bytes,
+                       uint32_t n_pairs, uint32_t level_count, uint32_t frame_w, uint32_t frame_h,
+                       uint32_t search_range, uint32_t block_w, uint32_t block_h, float* d_mv_xy,
+                       float* d_min_mad, uint32_t flags, void* stream) {
+  SVC_REQUIRE(d_tracked && d_anchor && d_mv_xy && d_min_mad, "hbma: null pointer (motion.cpp:417-420)");
+  int rc = validate_hbma(level_count, frame_w, frame_h, search_range, block_w, block_h);
+  if (rc) return rc;
+  SVC_REQUIRE(n_pairs <= 1 || pair_stride_bytes >= pyramid_bytes(frame_w, frame_h, level_count),
+              "hbma: pair stride %llu smaller than one pyramid", (unsigned long long)pair_stride_bytes);
+  return launch_hbma(d_tracked, d_anchor, pair_stride_bytes, n_pairs, level_count, frame_w, frame_h,
+                     search_range, block_w, block_h, d_mv_xy, d_min_mad, flags, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride_bytes,
+                       uint32_t n_pairs, uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                       uint32_t block_w, uint32_t block_h, float* d_mv_xy, float* d_min_mad, void* stream) {
+  SVC_REQUIRE(d_tracked && d_anchor && d_mv_xy && d_min_mad, "ebma: null pointer (motion.cpp:273-276)");
+  SVC_REQUIRE(block_w > 0 && block_h > 0, "ebma: block must be positive (motion.cpp:278-279)");
+  SVC_REQUIRE(frame_w > 0 && frame_h > 0 && frame_w % block_w == 0 && frame_h % block_h == 0,
+              "ebma: frame %ux%u not divisible by block %ux%u (motion.cpp:281-282)", frame_w, frame_h, block_w, block_h);
+  return launch_ebma(d_tracked, d_anchor, pair_stride_bytes, n_pairs, frame_w, frame_h, search_range,
+                     block_w, block_h, d_mv_xy, d_min_mad, static_cast<hipStream_t>(stream));
+}
+
+uint32_t svc_hip_ransac_iter_count(svc_ransac_params p) {
+  // libs/motion.cpp:144-149, f32 throughout
+  float num = std::log(1 - p.success_prob);
+  float den = std::log(1 - std::pow(p.inlier_ratio, (float)p.subset_sz));
+  return (uint32_t)std::ceil(num / den);
+}
+
+int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
+                          const uint32_t* d_samples, uint32_t iter_count, float* d_gm_xy, float* d_rmse,
+                          uint8_t* d_inlier_mask, uint32_t* d_inlier_count, void* stream) {
+  SVC_REQUIRE(d_mv_xy && d_gm_xy && d_rmse && d_inlier_mask && d_inlier_count, "ransac: null pointer (motion.cpp:189-192)");
+  SVC_REQUIRE(iter_count == 0 || d_samples, "ransac: null samples");
+  SVC_REQUIRE(params.subset_sz > 0 && blocks >= params.subset_sz,
+              "ransac: motion field of %u smaller than subset %u (motion.cpp:194)", blocks, params.subset_sz);
+  SVC_REQUIRE(aligned(d_mv_xy, 8), "ransac: motion field must be 8-byte aligned");
+  return launch_ransac(d_mv_xy, blocks, n_frames, params, d_samples, iter_count, d_gm_xy, d_rmse,
+                       d_inlier_mask, d_inlier_count, static_cast<hipStream_t>(stream));
+}
+
+static int validate_dct(const void* in, const void* out, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh) {
+  SVC_REQUIRE(in && out, "dct: null pointer");
+  SVC_REQUIRE(bw > 0 && bh > 0, "dct: block must be positive (encoder.cpp:325-326)");
+  SVC_REQUIRE(w > 0 && h > 0 && w % bw == 0 && h % bh == 0, "dct: frame %ux%u not divisible by block %ux%u", w, h, bw, bh);
+  return SVC_OK;
+}
+
+int svc_hip_dct_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
+                       uint32_t frame_h, uint32_t block_w, uint32_t block_h, float* d_planes, void* stream) {
+  int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block_w, block_h);
+  if (rc) return rc;
+  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_planes, 8),
+              "dct: frames must be 16-byte aligned (stride too), planes 8-byte aligned");
+  return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block_w, block_h, nullptr, 0, 0, 1, 1,
+                    false, d_planes, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_dct_quant_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames,
+                             uint32_t frame_w, uint32_t frame_h, uint32_t block_w, uint32_t block_h,
+                             const uint32_t* d_block_types, uint32_t mv_block_w, uint32_t mv_block_h,
+                             uint32_t fg_step, uint32_t bg_step, float* d_planes, void* stream) {
+  int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block_w, block_h);
+  if (rc) return rc;
+  SVC_REQUIRE(d_block_types, "dct_quant: null block types");
+  SVC_REQUIRE(fg_step > 0 && bg_step > 0, "dct_quant: quant steps must be positive (decoder.cpp:35-47)");
+  // transform block <= MV block and divides it (libs/encoder.cpp:62-142 Validate)
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && mv_block_w % block_w == 0 && mv_block_h % block_h == 0 &&
+                  frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "dct_quant: MV block %ux%u must be a multiple of the transform block %ux%u and divide the frame",
+              mv_block_w, mv_block_h, block_w, block_h);
+  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_planes, 8),
+              "dct: frames must be 16-byte aligned (stride too), planes 8-byte aligned");
+  return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block_w, block_h, d_block_types,
+                    mv_block_w, mv_block_h, fg_step, bg_step, true, d_planes, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_quant(float* d_coeffs, uint64_t n, uint32_t step, void* stream) {
+  SVC_REQUIRE(d_coeffs || n == 0, "quant: null pointer");
+  SVC_REQUIRE(step > 0, "quant: step must be positive (decoder.cpp:35-47)");
+  return launch_quant(d_coeffs, n, step, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_quant_frames(float* d_planes, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                         uint32_t mv_block_w, uint32_t mv_block_h, const uint32_t* d_block_types,
+                         uint32_t fg_step, uint32_t bg_step, void* stream) {
+  SVC_REQUIRE(d_planes && d_block_types, "quant_frames: null pointer");
+  SVC_REQUIRE(fg_step > 0 && bg_step > 0, "quant_frames: steps must be positive");
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "quant_frames: frame %ux%u not divisible by MV block %ux%u", frame_w, frame_h, mv_block_w, mv_block_h);
+  return launch_quant_frames(d_planes, n_frames, frame_w, frame_h, mv_block_w, mv_block_h, d_block_types,
+                             fg_step, bg_step, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames,
+                                uint32_t frame_w, uint32_t frame_h, uint32_t level_count, uint8_t* d_pyr,
+                                uint64_t pyr_stride_bytes, void* stream) {
+  SVC_REQUIRE(d_bgr && d_pyr, "luma_pyramid: null pointer");
+  SVC_REQUIRE(level_count > 0 && level_count <= 16, "luma_pyramid: level_count %u out of range", level_count);
+  const uint32_t f = 1u << (level_count - 1);
+  SVC_REQUIRE(frame_w > 0 && frame_h > 0 && frame_w % f == 0 && frame_h % f == 0,
+              "luma_pyramid: frame %ux%u must be divisible by 2^(levels-1) = %u", frame_w, frame_h, f);
+  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0,
+              "luma_pyramid: frames and pyramids must be 16-byte aligned (strides too)");
+  SVC_REQUIRE(n_frames <= 1 || pyr_stride_bytes >= pyramid_bytes(frame_w, frame_h, level_count),
+              "luma_pyramid: pyramid stride too small");
+  return launch_luma_pyramid(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, level_count, d_pyr,
+                             pyr_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+// ---- host-pointer forms -----------------------------------------------------------
+
+int svc_hip_hbma_host(const uint8_t* const* tracked_pyr, const uint8_t* const* anchor_pyr, uint32_t level_count,
+                      uint32_t frame_w, uint32_t frame_h, uint32_t search_range, uint32_t block_w,
+                      uint32_t block_h, float* mv_xy, float* min_mad, uint32_t flags) {
+  SVC_REQUIRE(tracked_pyr && anchor_pyr && mv_xy && min_mad, "hbma: null pointer (motion.cpp:417-420)");
+  int rc = validate_hbma(level_count, frame_w, frame_h, search_range, block_w, block_h);
+  if (rc) return rc;
+  for (uint32_t l = 0; l < level_count; ++l)
+    SVC_REQUIRE(tracked_pyr[l] && anchor_pyr[l], "hbma: null plane at level %u", l);
+  if ((rc = require_device())) return rc;
+  const size_t pyr = up256(pyramid_bytes(frame_w, frame_h, level_count));
+  const size_t blocks = (size_t)(frame_w / block_w) * (frame_h / block_h);
+  const size_t out_off = 2 * pyr, out_bytes = blocks * 12;
+  if ((rc = g_stage.ensure(out_off + up256(out_bytes)))) return rc;
+  size_t o = 0;
+  for (uint32_t l = 0; l < level_count; ++l) {
+    const size_t n = (size_t)(frame_w >> l) * (frame_h >> l);
+    std::memcpy(g_stage.pin + o, tracked_pyr[l], n);
+    std::memcpy(g_stage.pin + pyr + o, anchor_pyr[l], n);
+    o += n;
+  }
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, 2 * pyr, hipMemcpyHostToDevice, g_stage.stream));
+  float* d_mv = reinterpret_cast<float*>(g_stage.dev + out_off);
+  float* d_mad = d_mv + 2 * blocks;
+  rc = launch_hbma(g_stage.dev, g_stage.dev + pyr, pyr, 1, level_count, frame_w, frame_h, search_range, block_w,
+                   block_h, d_mv, d_mad, flags, g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin + out_off, d_mv, out_bytes, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(mv_xy, g_stage.pin + out_off, blocks * 8);
+  std::memcpy(min_mad, g_stage.pin + out_off + blocks * 8, blocks * 4);
+  return SVC_OK;
+}
+
+int svc_hip_ebma_host(const uint8_t* tracked, const uint8_t* anchor, uint32_t frame_w, uint32_t frame_h,
+                      uint32_t search_range, uint32_t block_w, uint32_t block_h, float* mv_xy, float* min_mad) {
+  SVC_REQUIRE(tracked && anchor && mv_xy && min_mad, "ebma: null pointer (motion.cpp:273-276)");
+  SVC_REQUIRE(block_w > 0 && block_h > 0, "ebma: block must be positive (motion.cpp:278-279)");
+  SVC_REQUIRE(frame_w > 0 && frame_h > 0 && frame_w % block_w == 0 && frame_h % block_h == 0,
+              "ebma: frame %ux%u not divisible by block %ux%u (motion.cpp:281-282)", frame_w, frame_h, block_w, block_h);
+  int rc = require_device();
+  if (rc) return rc;
+  const size_t plane = up256((size_t)frame_w * frame_h);
+  const size_t blocks = (size_t)(frame_w / block_w) * (frame_h / block_h);
+  const size_t out_off = 2 * plane, out_bytes = blocks * 12;
+  if ((rc = g_stage.ensure(out_off + up256(out_bytes)))) return rc;
+  std::memcpy(g_stage.pin, tracked, (size_t)frame_w * frame_h);
+  std::memcpy(g_stage.pin + plane, anchor, (size_t)frame_w * frame_h);
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, 2 * plane, hipMemcpyHostToDevice, g_stage.stream));
+  float* d_mv = reinterpret_cast<float*>(g_stage.dev + out_off);
+  float* d_mad = d_mv + 2 * blocks;
+  rc = launch_ebma(g_stage.dev, g_stage.dev + plane, plane, 1, frame_w, frame_h, search_range, block_w, block_h,
+                   d_mv, d_mad, g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin + out_off, d_mv, out_bytes, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(mv_xy, g_stage.pin + out_off, blocks * 8);
+  std::memcpy(min_mad, g_stage.pin + out_off + blocks * 8, blocks * 4);
+  return SVC_OK;
+}
+
+int svc_hip_ransac_host(const float* mv_xy, uint32_t blocks, svc_ransac_params params, const uint32_t* samples,
+                        uint32_t iter_count, float* gm_xy, float* rmse, uint32_t* inlier_indices,
+                        uint32_t* inlier_count) {
+  SVC_REQUIRE(mv_xy && gm_xy && rmse && inlier_indices && inlier_count, "ransac: null pointer (motion.cpp:189-192)");
+  SVC_REQUIRE(iter_count == 0 || samples, "ransac: null samples");
+  SVC_REQUIRE(params.subset_sz > 0 && blocks >= params.subset_sz,
+              "ransac: motion field of %u smaller than subset %u (motion.cpp:194)", blocks, params.subset_sz);
+  for (size_t i = 0; i < (size_t)iter_count * params.subset_sz; ++i)
+    SVC_REQUIRE(samples[i] < blocks, "ransac: sample index %u out of range [0, %u)", samples[i], blocks);
+  int rc = require_device();
+  if (rc) return rc;
+  const size_t mv_b = up256((size_t)blocks * 8), smp_b = up256((size_t)iter_count * params.subset_sz * 4 + 4);
+  const size_t mask_b = up256(blocks), misc_b = 256;
+  if ((rc = g_stage.ensure(mv_b + smp_b + mask_b + misc_b))) return rc;
+  uint8_t* p = g_stage.pin;
+  std::memcpy(p, mv_xy, (size_t)blocks * 8);
+  std::memcpy(p + mv_b, samples, (size_t)iter_count * params.subset_sz * 4);
+  float* misc = reinterpret_cast<float*>(p + mv_b + smp_b + mask_b);
+  misc[0] = gm_xy[0];
+  misc[1] = gm_xy[1];
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, p, mv_b + smp_b + mask_b + misc_b, hipMemcpyHostToDevice, g_stage.stream));
+  uint8_t* d = g_stage.dev;
+  float* d_misc = reinterpret_cast<float*>(d + mv_b + smp_b + mask_b);
+  rc = launch_ransac(reinterpret_cast<const float*>(d), blocks, 1, params, reinterpret_cast<const uint32_t*>(d + mv_b),
+                     iter_count, d_misc, d_misc + 2, d + mv_b + smp_b, reinterpret_cast<uint32_t*>(d_misc + 3),
+                     g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(p + mv_b + smp_b, d + mv_b + smp_b, mask_b + misc_b, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  gm_xy[0] = misc[0];
+  gm_xy[1] = misc[1];
+  *rmse = misc[2];
+  const uint8_t* mask = p + mv_b + smp_b;
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < blocks; ++i)
+    if (mask[i]) inlier_indices[k++] = i;  // ascending, as motion.cpp:244-253 collects them
+  *inlier_count = k;
+  return SVC_OK;
+}
+
+static int dct_host_common(const uint8_t* bgr, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh,
+                           const uint32_t* types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg, uint32_t bg,
+                           bool quant, float* planes) {
+  int rc = validate_dct(bgr, planes, w, h, bw, bh);
+  if (rc) return rc;
+  if ((rc = require_device())) return rc;
+  const size_t in_b = up256((size_t)w * h * 3), out_b = (size_t)w * h * 12;
+  const size_t nt = quant ? (size_t)(w / mv_bw) * (h / mv_bh) : 0, t_b = up256(nt * 4);
+  if ((rc = g_stage.ensure(in_b + t_b + up256(out_b)))) return rc;
+  std::memcpy(g_stage.pin, bgr, (size_t)w * h * 3);
+  if (quant) std::memcpy(g_stage.pin + in_b, types, nt * 4);
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, in_b + t_b, hipMemcpyHostToDevice, g_stage.stream));
+  float* d_out = reinterpret_cast<float*>(g_stage.dev + in_b + t_b);
+  rc = launch_dct(g_stage.dev, in_b, 1, w, h, bw, bh, reinterpret_cast<const uint32_t*>(g_stage.dev + in_b), mv_bw,
+                  mv_bh, fg, bg, quant, d_out, g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin + in_b + t_b, d_out, out_b, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(planes, g_stage.pin + in_b + t_b, out_b);
+  return SVC_OK;
+}
+
+int svc_hip_dct_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h, uint32_t block_w, uint32_t block_h,
+                     float* planes) {
+  return dct_host_common(bgr, frame_w, frame_h, block_w, block_h, nullptr, 0, 0, 1, 1, false, planes);
+}
+
+int svc_hip_dct_quant_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h, uint32_t block_w,
+                           uint32_t block_h, const uint32_t* block_types, uint32_t mv_block_w,
+                           uint32_t mv_block_h, uint32_t fg_step, uint32_t bg_step, float* planes) {
+  SVC_REQUIRE(block_types, "dct_quant: null block types");
+  SVC_REQUIRE(fg_step > 0 && bg_step > 0, "dct_quant: quant steps must be positive");
+  SVC_REQUIRE(block_w > 0 && block_h > 0 && mv_block_w > 0 && mv_block_h > 0 && mv_block_w % block_w == 0 &&
+                  mv_block_h % block_h == 0 && frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "dct_quant: MV block %ux%u must be a multiple of the transform block %ux%u and divide the frame",
+              mv_block_w, mv_block_h, block_w, block_h);
+  return dct_host_common(bgr, frame_w, frame_h, block_w, block_h, block_types, mv_block_w, mv_block_h, fg_step,
+                         bg_step, true, planes);
+}
+
+int svc_hip_quant_host(float* coeffs, uint64_t n, uint32_t step) {
+  SVC_REQUIRE(coeffs || n == 0, "quant: null pointer");
+  SVC_REQUIRE(step > 0, "quant: step must be positive");
+  if (n == 0) return SVC_OK;
+  int rc = require_device();
+  if (rc) return rc;
+  if ((rc = g_stage.ensure(n * 4))) return rc;
+  std::memcpy(g_stage.pin, coeffs, n * 4);
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, n * 4, hipMemcpyHostToDevice, g_stage.stream));
+  rc = launch_quant(reinterpret_cast<float*>(g_stage.dev), n, step, g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin, g_stage.dev, n * 4, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(coeffs, g_stage.pin, n * 4);
+  return SVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// hbma_fused.hip -- EstimateMotionHierarchical as ONE launch: every pyramid level
+// of one 16x16 MV block is searched by one lane.
+//
+// Why this shape.  A block's MV at level l depends only on the SAME block's MV at
+// level l+1 (reference libs/motion.cpp:451-464 walks the levels, but never reads a
+// neighbour's vector), so the whole coarse-to-fine chain is private to a block: no
+// inter-level grid sync, no MV round trip through HBM, one launch per batch of
+// frame pairs.  With <= 25 candidates per level (R_top = R / 2^(L-1) in {1, 2}) a
+// wave-per-block search would idle most lanes; a lane-per-block search keeps all 64
+// busy and makes the anchor loads of a wave one contiguous run per row (64
+// horizontally adjacent blocks x 16 B = 1 KiB), while the tracked-window rows of
+// neighbouring lanes overlap in the same L1 lines.
+//
+// SAD engine.  v_qsad_pk_u16_u8 returns, for one 4-byte anchor word, the four SADs
+// against the tracked bytes at offsets 0..3 of an 8-byte window, accumulated as
+// 4 x u16 (a 16x16 block's SAD <= 65280 fits).  The window origin is ALIGNED DOWN
+// to 4 bytes, so the +-R_top candidates land on columns j = shift .. shift + 2 R_top
+// (shift = origin & 3) of an 8-column grid = exactly two QSADs per anchor word and
+// no realignment of the tracked data at all.  Columns outside the reference's
+// clamped window (libs/motion.cpp:375-385) are masked at selection time.
+//
+// Arithmetic.  All block areas are powers of two, so MAD = sad / area is an exact
+// dyadic rational; the MAD carried across levels (libs/motion.cpp:401 compares a
+// level-l MAD with the level-(l+1) minimum) is kept as the integer sad << 2l
+// (units of 1/256) and converted once at the end: bit-identical to the float path.
+#include "svc_common.hpp"
+
+namespace svc {
+
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct FusedArgs {
+  const uint8_t* tracked;
+  const uint8_t* anchor;
+  uint64_t pair_stride;
+  uint32_t n_items;  // pairs * blocks
+  uint32_t blocks;
+  uint32_t mfw;
+  uint32_t w, h;     // base-level frame size
+  float* mv;
+  float* mad;
+};
+
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) {
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Loads N consecutive dwords of a tracked row.  CLAMP (top level only, the last
+// plane of a packed pyramid): every dword's column is clamped into the row, so
+// nothing past the pyramid is ever touched; a clamped dword only feeds masked
+// candidates.
+template <int N, bool CLAMP>
+__device__ __forceinline__ void load_row(const uint8_t* row, int a0, int fw, uint32_t (&m)[N]) {
+  if (CLAMP) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      m[k] = *reinterpret_cast<const uint32_t*>(row + min(a0 + 4 * k, fw - 4));
+  } else {
+    const uint8_t* p = row + a0;
+    if (N == 6) {
+      u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+      u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(p + 16);
+      m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w; m[4] = u.x; m[5] = u.y;
+    } else if (N == 4) {
+      u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+      m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) m[k] = *reinterpret_cast<const uint32_t*>(p + 4 * k);
+    }
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void load_anchor_row(const uint8_t* p, uint32_t (&a)[NW]) {
+  if (NW == 4) {
+    u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+  } else if (NW == 2) {
+    u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(p);
+    a[0] = v.x; a[1] = v.y;
+  } else {
+    a[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+}
+
+struct Window {
+  int a0, wy;            // origin of the 8-column x (2RT+1)-row candidate grid
+  int jlo, jhi, dlo, dhi;  // the reference's clamped window inside that grid
+};
+
+template <int B, int RT>
+__device__ __forceinline__ Window make_window(int cx, int cy, int fw, int fh) {
+  Window w;
+  const int x0 = max(0, cx - RT), x1 = min(fw - B + 1, cx + RT + 1);  // motion.cpp:381-385
+  const int y0 = max(0, cy - RT), y1 = min(fh - B + 1, cy + RT + 1);  // :375-379
+  w.a0 = max(0, (cx - RT) & ~3);
+  w.wy = min(max(cy - RT, 0), fh - (B + 2 * RT));
+  w.jlo = x0 - w.a0; w.jhi = x1 - w.a0;
+  w.dlo = y0 - w.wy; w.dhi = y1 - w.wy;
+  return w;
+}
+
+// Picks the winner of a (2RT+1) x 8 grid of SADs in the reference's raster order.
+// TOP: `<=` so the last minimum wins, and the MV is zeroed when every candidate
+// updated (motion.cpp:324-337).  Refinement: strict `<` against the carried,
+// scaled minimum (motion.cpp:401).
+template <int RT, bool TOP, int SHIFT, typename GetSad>
+__device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad sad_at, int& mvx,
+                                       int& mvy, uint32_t& best) {
+  constexpr int NDY = 2 * RT + 1;
+  uint32_t mn = TOP ? 0xFFFFFFFFu : best;
+  int bj = -1, bd = 0, updates = 0, nvalid = 0;
+#pragma unroll
+  for (int d = 0; d < NDY; ++d) {
+    const bool row_ok = d >= w.dlo && d < w.dhi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t s = sad_at(d, j) << SHIFT;
+      const bool valid = row_ok && j >= w.jlo && j < w.jhi;
+      if (TOP) {
+        if (valid) {
+          ++nvalid;
+          if (s <= mn) { mn = s; bj = j; bd = d; ++updates; }
+        }
+      } else {
+        if (valid && s < mn) { mn = s; bj = j; bd = d; }
+      }
+    }
+  }
+  if (bj >= 0) {
+    mvx = w.a0 + bj - ax;
+    mvy = w.wy + bd - ay;
+    best = mn;
+  }
+  if (TOP && updates == nvalid) { mvx = 0; mvy = 0; }
+}
+
+// One level with block size B >= 4.
+template <int B, int RT, bool TOP, int SHIFT>
+__device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
+                                             const uint8_t* __restrict__ anc, int fw, int fh,
+                                             int bx, int by, int& mvx, int& mvy, uint32_t& best) {
+  constexpr int NW = B / 4, ND = NW + 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  const int ax = bx * B, ay = by * B;
+  const Window w = make_window<B, RT>(ax + mvx, ay + mvy, fw, fh);
+
+  uint64_t acc[NDY][2];
+#pragma unroll
+  for (int d = 0; d < NDY; ++d) acc[d][0] = acc[d][1] = 0;
+  uint32_t a[B][NW];
+  const uint8_t* tp = trk + (size_t)w.wy * fw;
+  const uint8_t* ap = anc + (size_t)ay * fw + ax;
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    uint32_t m[ND];
+    load_row<ND, TOP>(tp + (size_t)t * fw, w.a0, fw, m);
+    if (t < B) load_anchor_row<NW>(ap + (size_t)t * fw, a[t < B ? t : 0]);
+#pragma unroll
+    for (int d = 0; d < NDY; ++d) {
+      const int r = t - d;  // anchor row that meets tracked row t at vertical offset d
+      if (r >= 0 && r < B) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          const uint32_t av = a[r >= 0 && r < B ? r : 0][k];
+          acc[d][0] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(m[k], m[k + 1]), av, acc[d][0]);
+          acc[d][1] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(m[k + 1], m[k + 2]), av, acc[d][1]);
+        }
+      }
+    }
+  }
+  select<RT, TOP, SHIFT>(
+      w, ax, ay,
+      [&](int d, int j) { return (uint32_t)(acc[d][j >> 2] >> (16 * (j & 3))) & 0xFFFFu; }, mvx,
+      mvy, best);
+}
+
+// Top level of a 4-level pyramid: 2x2 blocks (reference motion.cpp:719-720).  Two
+// bytes per anchor row do not fill a QSAD word, so this level uses v_sad_u8 on
+// 16-bit slices; it is 1/64 of the pixels of level 0.
+template <int RT, int SHIFT>
+__device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
+                                              const uint8_t* __restrict__ anc, int fw, int fh,
+                                              int bx, int by, int& mvx, int& mvy, uint32_t& best) {
+  constexpr int B = 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  const int ax = bx * B, ay = by * B;
+  const Window w = make_window<B, RT>(ax, ay, fw, fh);
+  uint32_t s[NDY][8];
+#pragma unroll
+  for (int d = 0; d < NDY; ++d)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[d][j] = 0;
+  uint32_t a[B];
+#pragma unroll
+  for (int r = 0; r < B; ++r)
+    a[r] = *reinterpret_cast<const uint16_t*>(anc + (size_t)(ay + r) * fw + ax);
+  const uint8_t* tp = trk + (size_t)w.wy * fw;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    uint32_t m[3];
+    load_row<3, true>(tp + (size_t)t * fw, w.a0, fw, m);
+    uint32_t tj[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tj[j] = __builtin_amdgcn_alignbyte(m[1], m[0], j) & 0xFFFFu;
+#pragma unroll
+    for (int j = 4; j < 8; ++j) tj[j] = __builtin_amdgcn_alignbyte(m[2], m[1], j - 4) & 0xFFFFu;
+#pragma unroll
+    for (int d = 0; d < NDY; ++d) {
+      const int r = t - d;
+      if (r >= 0 && r < B) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          s[d][j] = __builtin_amdgcn_sad_u8(tj[j], a[r >= 0 && r < B ? r : 0], s[d][j]);
+      }
+    }
+  }
+  select<RT, true, SHIFT>(w, ax, ay, [&](int d, int j) { return s[d][j]; }, mvx, mvy, best);
+}
+
+template <int L, int RT>
+__global__ __launch_bounds__(256) void hbma_fused16_kernel(FusedArgs a) {
+  const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+  if (item >= a.n_items) return;
+  const uint32_t pair = item / a.blocks;
+  const uint32_t blk = item - pair * a.blocks;
+  const int by = (int)(blk / a.mfw), bx = (int)(blk - (uint32_t)by * a.mfw);
+
+  const uint8_t* trk = a.tracked + (size_t)pair * a.pair_stride;
+  const uint8_t* anc = a.anchor + (size_t)pair * a.pair_stride;
+  const int w = (int)a.w, h = (int)a.h;
+  const size_t o1 = (size_t)w * h, o2 = o1 + (o1 >> 2), o3 = o2 + (o1 >> 4);
+
+  int mvx = 0, mvy = 0;
+  uint32_t best = 0;
+  if (L == 4) {
+    search_top_b2<RT, 6>(trk + o3, anc + o3, w >> 3, h >> 3, bx, by, mvx, mvy, best);
+    mvx *= 2; mvy *= 2;  // motion.cpp:458-460
+    search_level<4, RT, false, 4>(trk + o2, anc + o2, w >> 2, h >> 2, bx, by, mvx, mvy, best);
+  } else {
+    search_level<4, RT, true, 4>(trk + o2, anc + o2, w >> 2, h >> 2, bx, by, mvx, mvy, best);
+  }
+  mvx *= 2; mvy *= 2;
+  search_level<8, RT, false, 2>(trk + o1, anc + o1, w >> 1, h >> 1, bx, by, mvx, mvy, best);
+  mvx *= 2; mvy *= 2;
+  search_level<16, RT, false, 0>(trk, anc, w, h, bx, by, mvx, mvy, best);
+
+  reinterpret_cast<float2*>(a.mv)[item] = make_float2((float)mvx, (float)mvy);
+  a.mad[item] = (float)best * (1.0f / 256.0f);  // exact: best < 2^24, power-of-two scale
+}
+
+bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw,
+                     uint32_t bh) {
+  if (bw != 16 || bh != 16 || (levels != 3 && levels != 4)) return false;
+  const uint32_t rt = range >> (levels - 1);
+  if (rt != 1 && rt != 2) return false;
+  const uint32_t tw = w >> (levels - 1), th = h >> (levels - 1), tb = 16u >> (levels - 1);
+  // the top plane must hold a whole candidate grid (clamped loads stay in the row)
+  return tw >= tb + 8 && th >= tb + 2 * rt && (w % 16 == 0) && (h % 16 == 0);
+}
+
+int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
+                      uint32_t n_pairs, uint32_t levels, uint32_t w, uint32_t h, uint32_t range,
+                      float* d_mv, float* d_mad, hipStream_t stream) {
+  FusedArgs a;
+  a.tracked = d_tracked;
+  a.anchor = d_anchor;
+  a.pair_stride = pair_stride;
+  a.mfw = w / 16;
+  a.blocks = a.mfw * (h / 16);
+  const uint64_t items = (uint64_t)a.blocks * n_pairs;
+  if (items == 0) return SVC_OK;
+  if (items > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu work items exceed one launch", (unsigned long long)items);
+  a.n_items = (uint32_t)items;
+  a.w = w; a.h = h;
+  a.mv = d_mv;
+  a.mad = d_mad;
+  const dim3 grid(div_up(a.n_items, 256)), block(256);
+  const uint32_t rt = range >> (levels - 1);
+  if (levels == 3 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<3, 2>), grid, block, 0, stream, a);
+  else if (levels == 3 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<3, 1>), grid, block, 0, stream, a);
+  else if (levels == 4 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<4, 1>), grid, block, 0, stream, a);
+  else if (levels == 4 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<4, 2>), grid, block, 0, stream, a);
+  else return fail(SVC_ERR_UNSUPPORTED, "hbma fused: levels=%u r_top=%u not instantiated", levels, rt);
+  return check_launch("hbma_fused16_kernel");
+}
+
+}  // namespace svc

@@ -1,0 +1,259 @@
+// hbma_wave.hip -- one wavefront per MV block, one launch per pyramid level.
+//
+// The shape-agnostic motion search (any block size, any search range, any level
+// count): the kernel behind EstimateMotionExhaustiveSearch (reference
+// libs/motion.cpp:268-340) and, level by level, behind EstimateMotionHierarchical
+// (:412-465) for shapes the fused kernel (hbma_fused.hip) does not cover.
+//
+// Per MV block (one 64-lane wave = one workgroup):
+//   1. the anchor block and the clamped search window of the tracked plane are
+//      staged in LDS with coalesced dword loads (window origin aligned down to 4);
+//   2. candidates are dealt across lanes in raster order; each lane walks its
+//      candidates' rows with v_sad_u8 over 4-byte words, realigning the tracked
+//      word with v_alignbyte_b32;
+//   3. a wave-wide min over packed (sad, index) keys gives the argmin with the
+//      reference's tie rule: top level `<=` => LAST raster minimum (:324),
+//      refinement strict `<` => FIRST raster minimum that beats the MAD carried
+//      from the coarser level (:401);
+//   4. top level only: if the SADs are non-increasing in raster order every
+//      candidate "updated" and the reference zeroes the MV (:333-337).
+// Integer SAD order == float MAD order within a level (sad < 2^23, one correctly
+// rounded divide), so the argmin is done on integers and the single float compare
+// against the carried MAD uses the reference's own expression (float)sad / count.
+#include "svc_common.hpp"
+
+namespace svc {
+
+struct WaveLevelArgs {
+  const uint8_t* tracked;
+  const uint8_t* anchor;
+  uint64_t pair_stride;
+  uint64_t level_off;   // byte offset of this level's plane inside a packed pyramid
+  uint32_t blocks;      // MV blocks per pair
+  uint32_t mfw;         // motion-field width
+  uint32_t fw, fh;      // plane size at this level
+  uint32_t bw, bh;      // block size at this level
+  uint32_t range;       // search range at this level
+  uint32_t a_pitch;     // LDS row pitch of the anchor block (bytes, multiple of 4)
+  uint32_t w_pitch;     // LDS row pitch of the window
+  uint32_t sads_off;    // LDS byte offset of the per-candidate SAD array
+  uint32_t top;         // 1 = EBMA semantics, 0 = refinement semantics
+  float* mv;            // [pairs][blocks][2]
+  float* mad;           // [pairs][blocks]
+};
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+    uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+    uint64_t o = ((uint64_t)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+template <bool DW>
+__global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* lds_anchor = lds;
+  uint8_t* lds_win = lds + (size_t)a.bh * a.a_pitch;
+  uint32_t* lds_sads = reinterpret_cast<uint32_t*>(lds + a.sads_off);
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t item = blockIdx.x;  // pair * blocks + block
+  const uint32_t pair = item / a.blocks;
+  const uint32_t blk = item - pair * a.blocks;
+  const uint32_t by = blk / a.mfw, bx = blk - by * a.mfw;
+  const uint32_t ax = bx * a.bw, ay = by * a.bh;
+
+  const uint8_t* trk = a.tracked + pair * a.pair_stride + a.level_off;
+  const uint8_t* anc = a.anchor + pair * a.pair_stride + a.level_off;
+  float* mv = a.mv + ((size_t)item) * 2;
+  float* mad = a.mad + item;
+
+  // centre of the search (libs/motion.cpp:372-373; the MV was doubled at :458-460)
+  int mvx = 0, mvy = 0;
+  float carried = 0.f;
+  if (!a.top) {
+    mvx = 2 * (int)roundf(mv[0]);
+    mvy = 2 * (int)roundf(mv[1]);
+    carried = *mad;
+  }
+  const uint32_t cx = (uint32_t)((int)ax + mvx), cy = (uint32_t)((int)ay + mvy);
+  // window bounds (:297-310 / :375-385)
+  const int lo_x = (int)cx - (int)a.range, lo_y = (int)cy - (int)a.range;
+  const uint32_t x0 = lo_x < 0 ? 0u : (uint32_t)lo_x;
+  const uint32_t y0 = lo_y < 0 ? 0u : (uint32_t)lo_y;
+  const uint32_t x1 = min(a.fw - a.bw + 1u, cx + a.range + 1u);
+  const uint32_t y1 = min(a.fh - a.bh + 1u, cy + a.range + 1u);
+  const uint32_t nx = x1 - x0, ny = y1 - y0, ncand = nx * ny;
+  const uint32_t win_rows = ny + a.bh - 1;
+
+  uint32_t xshift = 0;  // byte offset of column x0 inside a staged window row
+  if (DW) {
+    const uint32_t x0a = x0 & ~3u;
+    xshift = x0 - x0a;
+    const uint32_t a_dw = a.a_pitch >> 2, w_dw = a.w_pitch >> 2;
+    for (uint32_t i = lane; i < a.bh * a_dw; i += 64) {
+      uint32_t r = i / a_dw, c = i - r * a_dw;
+      reinterpret_cast<uint32_t*>(lds_anchor)[i] =
+          *reinterpret_cast<const uint32_t*>(anc + (size_t)(ay + r) * a.fw + ax + 4 * c);
+    }
+    for (uint32_t i = lane; i < win_rows * w_dw; i += 64) {
+      uint32_t r = i / w_dw, c = i - r * w_dw;
+      // columns past the last needed byte are don't-care; keep them in the row
+      uint32_t col = min(x0a + 4 * c, a.fw - 4u);
+      reinterpret_cast<uint32_t*>(lds_win)[i] =
+          *reinterpret_cast<const uint32_t*>(trk + (size_t)(y0 + r) * a.fw + col);
+    }
+  } else {
+    for (uint32_t i = lane; i < a.bh * a.bw; i += 64) {
+      uint32_t r = i / a.bw, c = i - r * a.bw;
+      lds_anchor[r * a.a_pitch + c] = anc[(size_t)(ay + r) * a.fw + ax + c];
+    }
+    const uint32_t wcols = nx + a.bw - 1;
+    for (uint32_t i = lane; i < win_rows * wcols; i += 64) {
+      uint32_t r = i / wcols, c = i - r * wcols;
+      lds_win[r * a.w_pitch + c] = trk[(size_t)(y0 + r) * a.fw + x0 + c];
+    }
+  }
+  __syncthreads();
+
+  // each lane: candidates lane, lane+64, ... in raster order
+  uint32_t best_sad = 0xFFFFFFFFu, best_idx = 0;
+  for (uint32_t c = lane; c < ncand; c += 64) {
+    const uint32_t iy = c / nx, ix = c - iy * nx;
+    uint32_t sad = 0;
+    if (DW) {
+      const uint32_t a_dw = a.a_pitch >> 2;
+      const uint32_t* a32 = reinterpret_cast<const uint32_t*>(lds_anchor);
+      const uint32_t* w32 = reinterpret_cast<const uint32_t*>(lds_win);
+      for (uint32_t r = 0; r < a.bh; ++r) {
+        const uint32_t o = (iy + r) * a.w_pitch + xshift + ix;
+        const uint32_t* wrow = w32 + (o >> 2);
+        const uint32_t sh = o & 3u;
+        uint32_t lo = wrow[0];
+        for (uint32_t k = 0; k < a.bw / 4; ++k) {
+          uint32_t hi = wrow[k + 1];
+          uint32_t t = __builtin_amdgcn_alignbyte(hi, lo, sh);
+          sad = __builtin_amdgcn_sad_u8(a32[r * a_dw + k], t, sad);
+          lo = hi;
+        }
+      }
+    } else {
+      for (uint32_t r = 0; r < a.bh; ++r)
+        for (uint32_t k = 0; k < a.bw; ++k) {
+          int d = (int)lds_anchor[r * a.a_pitch + k] - (int)lds_win[(iy + r) * a.w_pitch + ix + k];
+          sad += (uint32_t)(d < 0 ? -d : d);
+        }
+    }
+    lds_sads[c] = sad;
+    if (a.top ? (sad <= best_sad) : (sad < best_sad)) {
+      best_sad = sad;
+      best_idx = c;
+    }
+  }
+  __syncthreads();
+
+  // wave argmin: smaller sad first, then LAST index (top) / FIRST index (refine)
+  uint64_t key = ((uint64_t)best_sad << 32) | (a.top ? ~best_idx : best_idx);
+  key = wave_min_u64(key);
+  const uint32_t w_sad = (uint32_t)(key >> 32);
+  const uint32_t w_idx = a.top ? ~(uint32_t)key : (uint32_t)key;
+
+  // top level: did every candidate update, i.e. are the SADs non-increasing?
+  bool mono = true;
+  if (a.top)
+    for (uint32_t c = lane; c < ncand; c += 64)
+      if (c > 0 && lds_sads[c] > lds_sads[c - 1]) mono = false;
+  const bool all_updated = __all(mono);
+
+  if (lane == 0) {
+    const float m = (float)w_sad / (float)(a.bw * a.bh);  // libs/motion.cpp:38-40
+    const uint32_t iy = w_idx / nx, ix = w_idx - iy * nx;
+    float ox = (float)((int)(x0 + ix) - (int)ax);
+    float oy = (float)((int)(y0 + iy) - (int)ay);
+    if (a.top) {
+      if (all_updated) ox = oy = 0.f;  // :333-337, min_mad is kept
+      mv[0] = ox;
+      mv[1] = oy;
+      *mad = m;
+    } else if (m < carried) {  // :401 against the carried value
+      mv[0] = ox;
+      mv[1] = oy;
+      *mad = m;
+    } else {  // nothing beat the coarser level: MV stays 2 x coarse (:458-460)
+      mv[0] = (float)mvx;
+      mv[1] = (float)mvy;
+    }
+  }
+}
+
+static int launch_wave_level(const uint8_t* d_tracked, const uint8_t* d_anchor,
+                             uint64_t pair_stride, uint32_t n_pairs, uint64_t level_off,
+                             uint32_t fw, uint32_t fh, uint32_t bw, uint32_t bh, uint32_t range,
+                             bool top, float* d_mv, float* d_mad, hipStream_t stream) {
+  WaveLevelArgs a;
+  a.tracked = d_tracked;
+  a.anchor = d_anchor;
+  a.pair_stride = pair_stride;
+  a.level_off = level_off;
+  a.mfw = fw / bw;
+  a.blocks = a.mfw * (fh / bh);
+  a.fw = fw; a.fh = fh; a.bw = bw; a.bh = bh;
+  a.range = range;
+  a.top = top ? 1u : 0u;
+  a.mv = d_mv;
+  a.mad = d_mad;
+  a.a_pitch = (bw + 3u) & ~3u;
+  a.w_pitch = ((bw + 2u * range + 3u + 3u) & ~3u) + 4u;
+  const uint64_t win_bytes = (uint64_t)(bh + 2ull * range) * a.w_pitch;
+  uint64_t off = (uint64_t)bh * a.a_pitch + win_bytes;
+  off = (off + 15u) & ~15ull;
+  const uint64_t ncand_max = (2ull * range + 1) * (2ull * range + 1);
+  const uint64_t lds_bytes = off + 4 * ncand_max;
+  if (lds_bytes > 64 * 1024)
+    return fail(SVC_ERR_UNSUPPORTED,
+                "hbma: block %ux%u with search range %u needs %llu B of LDS per block (limit 65536)",
+                bw, bh, range, (unsigned long long)lds_bytes);
+  a.sads_off = (uint32_t)off;
+  const uint64_t grid = (uint64_t)a.blocks * n_pairs;
+  if (grid == 0) return SVC_OK;
+  if (grid > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu work items exceed one launch", (unsigned long long)grid);
+  const bool dw = (bw % 4 == 0) && (fw % 4 == 0) && fw >= 4;
+  if (dw)
+    hipLaunchKernelGGL(hbma_wave_level_kernel<true>, dim3((uint32_t)grid), dim3(64), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL(hbma_wave_level_kernel<false>, dim3((uint32_t)grid), dim3(64), lds_bytes, stream, a);
+  return check_launch("hbma_wave_level_kernel");
+}
+
+// EstimateMotionHierarchical as L dependent launches (libs/motion.cpp:443-464).
+int launch_hbma_wave(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
+                     uint32_t n_pairs, uint32_t levels, uint32_t w, uint32_t h, uint32_t range,
+                     uint32_t bw, uint32_t bh, float* d_mv, float* d_mad, hipStream_t stream) {
+  const uint32_t f = 1u << (levels - 1);
+  const uint32_t r_top = range / f;
+  uint64_t offs[32];
+  uint64_t o = 0;
+  for (uint32_t l = 0; l < levels; ++l) {
+    offs[l] = o;
+    o += (uint64_t)(w >> l) * (h >> l);
+  }
+  for (int l = (int)levels - 1; l >= 0; --l) {
+    int rc = launch_wave_level(d_tracked, d_anchor, pair_stride, n_pairs, offs[l], w >> l, h >> l,
+                               bw >> l, bh >> l, r_top, l == (int)levels - 1, d_mv, d_mad, stream);
+    if (rc) return rc;
+  }
+  return SVC_OK;
+}
+
+int launch_ebma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
+                uint32_t n_pairs, uint32_t w, uint32_t h, uint32_t range, uint32_t bw,
+                uint32_t bh, float* d_mv, float* d_mad, hipStream_t stream) {
+  return launch_wave_level(d_tracked, d_anchor, pair_stride, n_pairs, 0, w, h, bw, bh, range, true,
+                           d_mv, d_mad, stream);
+}
+
+}  // namespace svc

@@ -1,0 +1,147 @@
+// ransac.hip -- EstimateGlobalMotionRansac (reference libs/motion.cpp:182-266),
+// batched: one workgroup per frame's motion field.
+//
+// The reference seeds a function-local static engine from std::random_device
+// (:186-187) and draws from [0, N] inclusive (:208, an out-of-bounds read).  Here the
+// accepted draws are an explicit input (svc_hip.h), so a run is reproducible and
+// checkable; everything downstream of the draws is bit-identical:
+//   - the model of an iteration is the SEQUENTIAL f32 sum of the sampled MVs times
+//     1/n (:151-163) -- one lane does it, n is tiny;
+//   - the inlier test is elementwise f32, (gm.x-m.x)^2 + (gm.y-m.y)^2 < thresh^2
+//     (:228), evaluated by all lanes with FP contraction off (the reference is built
+//     for baseline x86-64: no FMA);
+//   - `>=` keeps the LATER of two equally good iterations (:233);
+//   - the final mean and RMSE over the inliers are sequential f32 sums in index order
+//     (:255-259), which are order-dependent, so one lane walks the mask.  That serial
+//     tail is ~N dependent adds per frame; frames run in parallel on separate CUs and
+//     the whole launch sits beside the DCT on another stream.
+#include "svc_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace svc {
+
+struct RansacArgs {
+  const float* mv;       // [frames][blocks][2]
+  const uint32_t* samples;  // [frames][iters][subset]
+  uint32_t blocks, iters, subset;
+  float thresh;
+  float* gm;             // [frames][2] in/out
+  float* rmse;           // [frames]
+  uint8_t* mask;         // [frames][blocks]
+  uint32_t* count;       // [frames]
+};
+
+__device__ __forceinline__ bool is_inlier(float gx, float gy, float mx, float my, float t2) {
+  const float dx = gx - mx, dy = gy - my;
+  return dx * dx + dy * dy < t2;
+}
+
+__global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
+  __shared__ float s_gm[2];
+  __shared__ uint32_t s_cnt[4];
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x;
+  const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * a.blocks;
+  const uint32_t* samples = a.samples + (size_t)frame * a.iters * a.subset;
+  uint8_t* mask = a.mask + (size_t)frame * a.blocks;
+  const float t2 = a.thresh * a.thresh;
+
+  uint32_t best_n = 0, best_it = 0;
+  float bgx = 0.f, bgy = 0.f;
+  for (uint32_t it = 0; it < a.iters; ++it) {
+    if (tid == 0) {
+      float sx = 0.f, sy = 0.f;
+      for (uint32_t i = 0; i < a.subset; ++i) {
+        const float2 m = mv[samples[(size_t)it * a.subset + i]];
+        sx = sx + m.x;
+        sy = sy + m.y;
+      }
+      const float inv = 1.0f / (float)a.subset;
+      s_gm[0] = sx * inv;
+      s_gm[1] = sy * inv;
+    }
+    __syncthreads();
+    const float gx = s_gm[0], gy = s_gm[1];
+    uint32_t n = 0;
+    for (uint32_t i = tid; i < a.blocks; i += 256) {
+      const float2 m = mv[i];
+      n += is_inlier(gx, gy, m.x, m.y, t2) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = n;
+    __syncthreads();
+    const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (total >= best_n) {  // motion.cpp:233
+      best_n = total;
+      best_it = it;
+      bgx = gx;
+      bgy = gy;
+    }
+    __syncthreads();  // s_gm / s_cnt are rewritten next iteration
+  }
+
+  // mask of the winning model's inliers (== best_inliers, motion.cpp:236 / :244-253)
+  for (uint32_t i = tid; i < a.blocks; i += 256) {
+    const float2 m = mv[i];
+    mask[i] = (a.iters > 0 && is_inlier(bgx, bgy, m.x, m.y, t2)) ? 1 : 0;
+  }
+  __syncthreads();
+
+  if (tid == 0) {
+    float out_gx = bgx, out_gy = bgy, acc = 0.f, r;
+    if (best_n < a.subset) {
+      // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
+      const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
+      for (uint32_t i = 0; i < a.subset; ++i) {
+        const float2 m = mv[samples[(size_t)best_it * a.subset + i]];
+        const float dx = m.x - ix, dy = m.y - iy;
+        acc += dx * dx + dy * dy;
+      }
+      r = sqrtf(acc / (float)a.subset);
+    } else {
+      float sx = 0.f, sy = 0.f;
+      for (uint32_t i = 0; i < a.blocks; ++i)
+        if (mask[i]) {
+          const float2 m = mv[i];
+          sx = sx + m.x;
+          sy = sy + m.y;
+        }
+      const float inv = 1.0f / (float)best_n;
+      out_gx = sx * inv;
+      out_gy = sy * inv;
+      for (uint32_t i = 0; i < a.blocks; ++i)
+        if (mask[i]) {
+          const float2 m = mv[i];
+          const float dx = m.x - out_gx, dy = m.y - out_gy;
+          acc += dx * dx + dy * dy;
+        }
+      r = sqrtf(acc / (float)best_n);
+    }
+    a.gm[2 * frame] = out_gx;
+    a.gm[2 * frame + 1] = out_gy;
+    a.rmse[frame] = r;
+    a.count[frame] = best_n;
+  }
+}
+
+int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
+                  const uint32_t* d_samples, uint32_t iters, float* d_gm, float* d_rmse,
+                  uint8_t* d_mask, uint32_t* d_count, hipStream_t stream) {
+  if (n_frames == 0) return SVC_OK;
+  RansacArgs a;
+  a.mv = d_mv;
+  a.samples = d_samples;
+  a.blocks = blocks;
+  a.iters = iters;
+  a.subset = params.subset_sz;
+  a.thresh = params.inlier_thresh;
+  a.gm = d_gm;
+  a.rmse = d_rmse;
+  a.mask = d_mask;
+  a.count = d_count;
+  hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), 0, stream, a);
+  return check_launch("ransac_kernel");
+}
+
+}  // namespace svc

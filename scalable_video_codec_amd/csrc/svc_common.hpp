@@ -1,0 +1,79 @@
+// svc_common.hpp -- error plumbing shared by the C-ABI translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "svc_hip.h"
+
+namespace svc {
+
+// Per-thread message behind svc_hip_last_error().
+char* last_error_buf();
+constexpr int kErrBufSize = 512;
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), kErrBufSize, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define SVC_HIP_TRY(expr)                                                       \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess)                                                       \
+      return ::svc::fail(SVC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                         hipGetErrorString(e_), __FILE__, __LINE__);            \
+  } while (0)
+
+#define SVC_REQUIRE(cond, ...)                                                  \
+  do {                                                                          \
+    if (!(cond)) return ::svc::fail(SVC_ERR_INVALID_ARG, __VA_ARGS__);          \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(SVC_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return SVC_OK;
+}
+
+inline uint64_t pyramid_bytes(uint32_t w, uint32_t h, uint32_t levels) {
+  uint64_t n = 0;
+  for (uint32_t l = 0; l < levels; ++l) n += (uint64_t)(w >> l) * (h >> l);
+  return n;
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------
+
+int launch_hbma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
+                uint32_t n_pairs, uint32_t levels, uint32_t w, uint32_t h, uint32_t range,
+                uint32_t bw, uint32_t bh, float* d_mv, float* d_mad, uint32_t flags,
+                hipStream_t stream);
+int launch_ebma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
+                uint32_t n_pairs, uint32_t w, uint32_t h, uint32_t range, uint32_t bw,
+                uint32_t bh, float* d_mv, float* d_mad, hipStream_t stream);
+int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
+               uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
+               uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
+               hipStream_t stream);
+int launch_quant(float* d_coeffs, uint64_t n, uint32_t step, hipStream_t stream);
+int launch_quant_frames(float* d_planes, uint32_t n_frames, uint32_t w, uint32_t h,
+                        uint32_t mv_bw, uint32_t mv_bh, const uint32_t* d_types,
+                        uint32_t fg_step, uint32_t bg_step, hipStream_t stream);
+int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames,
+                  svc_ransac_params params, const uint32_t* d_samples, uint32_t iters,
+                  float* d_gm, float* d_rmse, uint8_t* d_mask, uint32_t* d_count,
+                  hipStream_t stream);
+int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames,
+                        uint32_t w, uint32_t h, uint32_t levels, uint8_t* d_pyr,
+                        uint64_t pyr_stride, hipStream_t stream);
+
+}  // namespace svc

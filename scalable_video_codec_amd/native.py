@@ -1,0 +1,272 @@
+"""ctypes binding of the C ABI (include/svc_hip.h) for the Python harness.
+
+PyTorch is used for device memory and streams only; every computation below runs
+in the hand-written HIP kernels of csrc/ through libsvc_hip.so.  There is no
+fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libsvc_hip.so")
+MOTION_LIB_PATH = os.path.join(PKG, "libsvc_motion.so")
+
+SVC_OK, SVC_ERR_INVALID_ARG, SVC_ERR_UNSUPPORTED, SVC_ERR_HIP, SVC_ERR_NO_DEVICE = range(5)
+HBMA_AUTO, HBMA_FORCE_WAVE_PER_BLOCK, HBMA_FORCE_FUSED = 0, 1, 2
+
+
+class SvcError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"svc_hip status {status}: {message}")
+        self.status = status
+
+
+class RansacParams(C.Structure):
+    _fields_ = [("subset_sz", C.c_uint32), ("inlier_thresh", C.c_float),
+                ("success_prob", C.c_float), ("inlier_ratio", C.c_float)]
+
+
+_vp = C.c_void_p
+_u32, _u64 = C.c_uint32, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/svc_hip.h one to one
+SIGNATURES = {
+    "svc_hip_last_error": (C.c_char_p, []),
+    "svc_hip_abi_version": (C.c_int, []),
+    "svc_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "svc_hip_pyramid_bytes": (_u64, [_u32, _u32, _u32]),
+    "svc_hip_hbma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp]),
+    "svc_hip_ebma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
+    "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "svc_hip_dct_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "svc_hip_dct_quant_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
+    "svc_hip_quant_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _vp]),
+    "svc_hip_luma_pyramid_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
+    "svc_hip_hbma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32]),
+    "svc_hip_ebma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "svc_hip_ransac_host": (C.c_int, [_vp, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "svc_hip_dct_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp]),
+    "svc_hip_dct_quant_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp]),
+    "svc_hip_quant_host": (C.c_int, [_vp, _u64, _u32]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads libsvc_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `python -m scalable_video_codec_amd.build` "
+                "(or __graft_entry__.build()); the MI355X path has no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != SVC_OK:
+        raise SvcError(rc, load().svc_hip_last_error().decode())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype) -> int:
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+def ransac_iter_count(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5) -> int:
+    return int(load().svc_hip_ransac_iter_count(RansacParams(subset_sz, inlier_thresh, success_prob, inlier_ratio)))
+
+
+def pyramid_bytes(w: int, h: int, levels: int) -> int:
+    return int(load().svc_hip_pyramid_bytes(w, h, levels))
+
+
+def pyramid_stride(w: int, h: int, levels: int) -> int:
+    """Packed-pyramid stride used by the harness: rounded up to 256 B."""
+    return (pyramid_bytes(w, h, levels) + 255) // 256 * 256
+
+
+# ---- device-resident, batched ---------------------------------------------------
+
+def hbma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_pairs: int,
+               levels: int, w: int, h: int, search_range: int, block_w: int = 16, block_h: int = 16,
+               flags: int = HBMA_AUTO, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """tracked/anchor: u8 CUDA tensors whose data_ptr is pair 0's packed pyramid."""
+    blocks = (w // block_w) * (h // block_h)
+    if out is None:
+        mv = torch.empty((n_pairs, blocks, 2), dtype=torch.float32, device=tracked.device)
+        mad = torch.empty((n_pairs, blocks), dtype=torch.float32, device=tracked.device)
+    else:
+        mv, mad = out
+    _check(load().svc_hip_hbma_pairs(_dev(tracked, torch.uint8), _dev(anchor, torch.uint8), pair_stride, n_pairs,
+                                     levels, w, h, search_range, block_w, block_h,
+                                     _dev(mv, torch.float32), _dev(mad, torch.float32), flags, _stream()))
+    return mv, mad
+
+
+def ebma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_pairs: int, w: int, h: int,
+               search_range: int, block_w: int, block_h: int):
+    blocks = (w // block_w) * (h // block_h)
+    mv = torch.empty((n_pairs, blocks, 2), dtype=torch.float32, device=tracked.device)
+    mad = torch.empty((n_pairs, blocks), dtype=torch.float32, device=tracked.device)
+    _check(load().svc_hip_ebma_pairs(_dev(tracked, torch.uint8), _dev(anchor, torch.uint8), pair_stride, n_pairs,
+                                     w, h, search_range, block_w, block_h,
+                                     _dev(mv, torch.float32), _dev(mad, torch.float32), _stream()))
+    return mv, mad
+
+
+def ransac_frames(mv: torch.Tensor, samples: torch.Tensor, gm_in: Optional[torch.Tensor] = None,
+                  subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5, out=None):
+    """mv: (frames, blocks, 2) f32; samples: (frames, iters, subset) i32/u32 as int32 storage."""
+    frames, blocks, _ = mv.shape
+    iters = samples.shape[1] if samples.numel() else 0
+    if out is None:
+        gm = torch.zeros((frames, 2), dtype=torch.float32, device=mv.device) if gm_in is None else gm_in.clone()
+        rmse = torch.empty(frames, dtype=torch.float32, device=mv.device)
+        mask = torch.empty((frames, blocks), dtype=torch.uint8, device=mv.device)
+        count = torch.empty(frames, dtype=torch.int32, device=mv.device)
+    else:
+        gm, rmse, mask, count = out
+    p = RansacParams(subset_sz, inlier_thresh, success_prob, inlier_ratio)
+    _check(load().svc_hip_ransac_frames(_dev(mv, torch.float32), blocks, frames, p, _dev(samples, torch.int32),
+                                        iters, _dev(gm, torch.float32), _dev(rmse, torch.float32),
+                                        _dev(mask, torch.uint8), _dev(count, torch.int32), _stream()))
+    return gm, rmse, mask, count
+
+
+def dct_frames(bgr: torch.Tensor, block: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bgr: (frames, H, W, 3) u8 -> (frames, 3, H, W) f32 coefficient planes."""
+    n, h, w, _ = bgr.shape
+    if out is None:
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=bgr.device)
+    _check(load().svc_hip_dct_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, block,
+                                     _dev(out, torch.float32), _stream()))
+    return out
+
+
+def dct_quant_frames(bgr: torch.Tensor, block: int, block_types: torch.Tensor, mv_block: int, fg_step: int,
+                     bg_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, h, w, _ = bgr.shape
+    if out is None:
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=bgr.device)
+    _check(load().svc_hip_dct_quant_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, block,
+                                           _dev(block_types, torch.int32), mv_block, mv_block, fg_step, bg_step,
+                                           _dev(out, torch.float32), _stream()))
+    return out
+
+
+def quant_(coeffs: torch.Tensor, step: int) -> torch.Tensor:
+    _check(load().svc_hip_quant(_dev(coeffs, torch.float32), coeffs.numel(), step, _stream()))
+    return coeffs
+
+
+def quant_frames_(planes: torch.Tensor, block_types: torch.Tensor, mv_block: int, fg_step: int, bg_step: int):
+    n, _, h, w = planes.shape
+    _check(load().svc_hip_quant_frames(_dev(planes, torch.float32), n, w, h, mv_block, mv_block,
+                                       _dev(block_types, torch.int32), fg_step, bg_step, _stream()))
+    return planes
+
+
+def luma_pyramid_frames(bgr: torch.Tensor, levels: int, out: Optional[torch.Tensor] = None,
+                        stride: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """bgr: (frames, H, W, 3) u8 -> (flat u8 buffer of `frames` packed pyramids, stride)."""
+    n, h, w, _ = bgr.shape
+    stride = pyramid_stride(w, h, levels) if stride is None else stride
+    if out is None:
+        out = torch.empty(n * stride, dtype=torch.uint8, device=bgr.device)
+    _check(load().svc_hip_luma_pyramid_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, levels,
+                                              _dev(out, torch.uint8), stride, _stream()))
+    return out, stride
+
+
+# ---- host-pointer forms (numpy in, numpy out): what include/svc/motion.hpp calls ----
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+def hbma_host(tracked_pyr, anchor_pyr, search_range: int, block_w: int = 16, block_h: int = 16,
+              flags: int = HBMA_AUTO):
+    import numpy as np
+    levels = len(tracked_pyr)
+    h, w = tracked_pyr[0].shape
+    tp = (_vp * levels)(*[_np_ptr(np.ascontiguousarray(p)) for p in tracked_pyr])
+    ap = (_vp * levels)(*[_np_ptr(np.ascontiguousarray(p)) for p in anchor_pyr])
+    blocks = (w // block_w) * (h // block_h) if block_w and block_h else 0
+    mv = np.empty((max(blocks, 1), 2), np.float32)
+    mad = np.empty(max(blocks, 1), np.float32)
+    _check(load().svc_hip_hbma_host(C.cast(tp, _vp), C.cast(ap, _vp), levels, w, h, search_range, block_w, block_h,
+                                    _np_ptr(mv), _np_ptr(mad), flags))
+    return mv[:blocks], mad[:blocks]
+
+
+def ebma_host(tracked, anchor, search_range: int, block_w: int, block_h: int):
+    import numpy as np
+    h, w = tracked.shape
+    blocks = (w // block_w) * (h // block_h)
+    mv = np.empty((blocks, 2), np.float32)
+    mad = np.empty(blocks, np.float32)
+    _check(load().svc_hip_ebma_host(_np_ptr(np.ascontiguousarray(tracked)), _np_ptr(np.ascontiguousarray(anchor)),
+                                    w, h, search_range, block_w, block_h, _np_ptr(mv), _np_ptr(mad)))
+    return mv, mad
+
+
+def ransac_host(mv, samples, gm_in=(0.0, 0.0), subset_sz=1, inlier_thresh=7.5, success_prob=0.99,
+                inlier_ratio=0.5):
+    import numpy as np
+    mv = np.ascontiguousarray(mv, np.float32)
+    samples = np.ascontiguousarray(samples, np.uint32)
+    n = len(mv)
+    gm = np.array(gm_in, np.float32)
+    rmse = C.c_float(0)
+    inl = np.empty(max(n, 1), np.uint32)
+    cnt = C.c_uint32(0)
+    p = RansacParams(subset_sz, inlier_thresh, success_prob, inlier_ratio)
+    iters = samples.size // subset_sz if subset_sz else 0
+    _check(load().svc_hip_ransac_host(_np_ptr(mv), n, p, _np_ptr(samples), iters, _np_ptr(gm),
+                                      C.cast(C.byref(rmse), _vp), _np_ptr(inl), C.cast(C.byref(cnt), _vp)))
+    return gm, np.float32(rmse.value), inl[:cnt.value].copy()
+
+
+def dct_host(bgr, block: int):
+    import numpy as np
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    out = np.empty((3, h, w), np.float32)
+    _check(load().svc_hip_dct_host(_np_ptr(bgr), w, h, block, block, _np_ptr(out)))
+    return out
+
+
+def dct_quant_host(bgr, block: int, block_types, mv_block: int, fg_step: int, bg_step: int):
+    import numpy as np
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    bt = np.ascontiguousarray(block_types, np.uint32)
+    h, w, _ = bgr.shape
+    out = np.empty((3, h, w), np.float32)
+    _check(load().svc_hip_dct_quant_host(_np_ptr(bgr), w, h, block, block, _np_ptr(bt), mv_block, mv_block,
+                                         fg_step, bg_step, _np_ptr(out)))
+    return out
+
+
+def quant_host(coeffs, step: int):
+    import numpy as np
+    out = np.ascontiguousarray(coeffs, np.float32).copy()
+    _check(load().svc_hip_quant_host(_np_ptr(out), out.size, step))
+    return out

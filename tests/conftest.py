@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The C restatement (oracle/libsvc_oracle.so); built on demand with gcc."""
+    import subprocess
+    from oracle import binding
+    if not os.path.exists(binding.ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    return binding.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The unmodified reference motion.cpp (oracle/_ref); skipped where it was never built."""
+    from oracle import binding
+    if not binding.Reference.available():
+        pytest.skip("oracle/_ref/libsvc_ref.so not built (needs /root/reference)")
+    return binding.Reference()
+
+
+@pytest.fixture(scope="session")
+def native():
+    """The product library; GPU tests must go through it (no fallback)."""
+    import torch
+    from scalable_video_codec_amd import native as n
+    n.load()
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return n

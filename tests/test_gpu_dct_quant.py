@@ -1,0 +1,111 @@
+"""GPU parity of the transform path.
+
+DCT: within 1e-4 * max(1, |ref|) of the float64 orthonormal DCT-II (the oracle of
+record; cv::dct itself is unavailable offline -- parity with OpenCV is unpinned).
+Quant: bit-exact against libs/decoder.cpp:140-144 restated."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: float DCT within 1e-4 (relative to max(1, |ref|))
+
+
+def _dct_close(got, ref64):
+    err = np.abs(got.astype(np.float64) - ref64)
+    lim = TOL * np.maximum(1.0, np.abs(ref64))
+    worst = float((err / lim).max())
+    assert worst <= 1.0, f"worst error / tolerance = {worst}"
+    return float(err.max())
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_dct_host_random(native, oracle, block):
+    rng = np.random.default_rng(block)
+    bgr = rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)
+    ref = oracle.dct_frame_f64(bgr, block, block)
+    got = native.dct_host(bgr, block)
+    _dct_close(got, ref)
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_dct_known_answers(native, block):
+    """Constant tile v -> DC = v * block, all AC = 0; extremes 0 and 255."""
+    for v in (0, 1, 128, 255):
+        bgr = np.full((32, 48, 3), v, np.uint8)
+        got = native.dct_host(bgr, block)
+        dc = got[:, ::block, ::block]
+        assert np.allclose(dc, v * block, rtol=1e-6, atol=1e-4), (v, dc.ravel()[:4])
+        ac = got.copy()
+        ac[:, ::block, ::block] = 0
+        assert np.abs(ac).max() <= 1e-4, (v, np.abs(ac).max())
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_dct_parseval_and_planes(native, oracle, block):
+    """Orthonormal transform preserves energy per tile; plane order is B, G, R (cv::split)."""
+    rng = np.random.default_rng(3)
+    bgr = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    got = native.dct_host(bgr, block).astype(np.float64)
+    for c in range(3):
+        e_in = (bgr[..., c].astype(np.float64) ** 2).sum()
+        assert abs(e_in - (got[c] ** 2).sum()) <= 1e-6 * e_in
+    one = np.zeros((16, 16, 3), np.uint8)
+    one[..., 1] = 200  # G only
+    g = native.dct_host(one, block)
+    assert g[0].max() == 0 and g[2].max() == 0 and g[1, 0, 0] > 0
+
+
+def test_dct_frames_batched_synthetic(native, oracle):
+    frames, _, (pw, ph) = util.clip_frames(320, 200, 3, 0xD0, 3)
+    assert ph == 208  # zero padding rows are part of the transform input (encoder.cpp:459-461, :638)
+    bgr = torch.stack(frames).cuda()
+    got = native.dct_frames(bgr, 8).cpu().numpy()
+    for i, f in enumerate(frames):
+        _dct_close(got[i], oracle.dct_frame_f64(f.numpy(), 8, 8))
+
+
+def test_quant_hand_vectors(native):
+    """round half away from zero, step 640 and step 1."""
+    v = np.array([319.9, 320.0, -320.0, 959.9, 0.0, -319.9, 1e6], np.float32)
+    assert native.quant_host(v, 640).tolist() == [0.0, 640.0, -640.0, 640.0, 0.0, -0.0, 999680.0]
+    w = np.array([2.5, -2.5, 7.0, -0.4, 0.5], np.float32)
+    assert native.quant_host(w, 1).tolist() == [3.0, -3.0, 7.0, -0.0, 1.0]
+
+
+@pytest.mark.parametrize("step", [1, 3, 7, 640, 65535])
+def test_quant_bit_exact(native, oracle, step):
+    rng = np.random.default_rng(step)
+    c = (rng.standard_normal(100003) * 900).astype(np.float32)
+    c[:7] = [0.0, -0.0, 0.5 * step, -0.5 * step, 1.5 * step, 4080.0, -4080.0]
+    got, exp = native.quant_host(c, step), oracle.quant(c, step)
+    assert got.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_dct_quant_fused(native, oracle, block):
+    """Fused DCT+quant == oracle quant applied to the device DCT (bit-exact), and the
+    device DCT itself is within tolerance of the f64 oracle."""
+    rng = np.random.default_rng(11)
+    h, w = 64, 96
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    types = rng.integers(0, 3, (h // 16) * (w // 16)).astype(np.uint32)
+    dct = native.dct_host(bgr, block)
+    exp = oracle.quant_frame(dct, 16, 16, types, 2, 640)
+    got = native.dct_quant_host(bgr, block, types, 16, 2, 640)
+    assert got.tobytes() == exp.tobytes()
+    planes = torch.from_numpy(dct).cuda().unsqueeze(0).contiguous()
+    native.quant_frames_(planes, torch.from_numpy(types.astype(np.int32)).cuda().unsqueeze(0).contiguous(), 16, 2, 640)
+    assert planes[0].cpu().numpy().tobytes() == exp.tobytes()
+
+
+def test_dct_unsupported(native):
+    with pytest.raises(native.SvcError) as e:
+        native.dct_host(np.zeros((32, 32, 3), np.uint8), 4)
+    assert e.value.status == native.SVC_ERR_UNSUPPORTED
+    with pytest.raises(native.SvcError) as e:
+        native.dct_host(np.zeros((30, 32, 3), np.uint8), 8)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG

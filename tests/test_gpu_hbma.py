@@ -1,0 +1,117 @@
+"""GPU parity of the motion search against the oracle (bit-exact MVs and min-MADs).
+
+Reference behaviour under test: libs/motion.cpp:268-340 (EBMA), :342-410
+(refinement), :412-465 (HBMA), :691-749 (the fixed 4-level 16x16 entry)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(got_mv, got_mad, exp_mv, exp_mad, what):
+    got_mv, got_mad = np.asarray(got_mv), np.asarray(got_mad)
+    bad = np.flatnonzero((got_mv != exp_mv).any(axis=-1) | (got_mad != exp_mad))
+    assert bad.size == 0, (f"{what}: {bad.size}/{len(exp_mad)} blocks differ; first {bad[:5]}: "
+                           f"got {got_mv[bad[:5]].tolist()} {got_mad[bad[:5]].tolist()} "
+                           f"want {exp_mv[bad[:5]].tolist()} {exp_mad[bad[:5]].tolist()}")
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 4])
+@pytest.mark.parametrize("flags", ["auto", "wave"])
+def test_hbma_host_cif(native, oracle, levels, flags):
+    """C1-shaped clip through the host-pointer entry (what motion.hpp's wrapper calls)."""
+    _, pyrs, _ = util.clip_frames(352, 288, 2, 0x5C0DEC01, levels)
+    t, a = util.np_pyr(pyrs[0]), util.np_pyr(pyrs[1])
+    exp_mv, exp_mad = oracle.hbma(t, a, 8, 16, 16)
+    f = native.HBMA_AUTO if flags == "auto" else native.HBMA_FORCE_WAVE_PER_BLOCK
+    mv, mad = native.hbma_host(t, a, 8, 16, 16, flags=f)
+    _assert_same(mv, mad, exp_mv, exp_mad, f"L={levels} {flags}")
+
+
+@pytest.mark.parametrize("levels,rng_range", [(3, 8), (3, 4), (4, 8), (4, 16)])
+def test_hbma_fused_vs_oracle_noise(native, oracle, levels, rng_range):
+    """Uncorrelated noise planes: every window clamp and carried-MAD path gets exercised."""
+    rng = np.random.default_rng(levels * 100 + rng_range)
+    w, h = 256, 192
+    t, a = util.random_planes(rng, w, h, levels), util.random_planes(rng, w, h, levels)
+    exp_mv, exp_mad = oracle.hbma(t, a, rng_range, 16, 16)
+    mv, mad = native.hbma_host(t, a, rng_range, 16, 16, flags=native.HBMA_FORCE_FUSED)
+    _assert_same(mv, mad, exp_mv, exp_mad, f"fused L={levels} R={rng_range}")
+    mv, mad = native.hbma_host(t, a, rng_range, 16, 16, flags=native.HBMA_FORCE_WAVE_PER_BLOCK)
+    _assert_same(mv, mad, exp_mv, exp_mad, f"wave L={levels} R={rng_range}")
+
+
+@pytest.mark.parametrize("bw,bh,r,levels", [(8, 8, 4, 1), (16, 8, 8, 2), (4, 4, 2, 1), (32, 16, 8, 3), (6, 10, 3, 1)])
+def test_hbma_wave_generic_shapes(native, oracle, bw, bh, r, levels):
+    """Block shapes outside the fused kernel, including a non-multiple-of-4 width (byte path)."""
+    rng = np.random.default_rng(bw * 1000 + bh)
+    w, h = bw * 12, bh * 9
+    f = 1 << (levels - 1)
+    w, h = w * f, h * f
+    t, a = util.random_planes(rng, w, h, levels), util.random_planes(rng, w, h, levels)
+    exp_mv, exp_mad = oracle.hbma(t, a, r, bw, bh)
+    mv, mad = native.hbma_host(t, a, r, bw, bh)
+    _assert_same(mv, mad, exp_mv, exp_mad, f"{bw}x{bh} R={r} L={levels}")
+
+
+def test_ebma_host(native, oracle):
+    rng = np.random.default_rng(7)
+    t = rng.integers(0, 256, (96, 160), dtype=np.uint8)
+    a = np.roll(t, (2, -3), axis=(0, 1))
+    exp_mv, exp_mad = oracle.ebma(t, a, 8, 16, 16)
+    mv, mad = native.ebma_host(t, a, 8, 16, 16)
+    _assert_same(mv, mad, exp_mv, exp_mad, "ebma")
+
+
+def test_flat_frames_zero_reset(native, oracle):
+    """Flat frames: every candidate ties, the top level zero-resets the MV (motion.cpp:333-337)."""
+    t = [np.full((128 >> l, 192 >> l), 77, np.uint8) for l in range(3)]
+    a = [np.full((128 >> l, 192 >> l), 77, np.uint8) for l in range(3)]
+    exp_mv, exp_mad = oracle.hbma(t, a, 8, 16, 16)
+    assert not exp_mv.any() and not exp_mad.any()
+    for f in (native.HBMA_FORCE_FUSED, native.HBMA_FORCE_WAVE_PER_BLOCK):
+        mv, mad = native.hbma_host(t, a, 8, 16, 16, flags=f)
+        _assert_same(mv, mad, exp_mv, exp_mad, "flat")
+
+
+def test_periodic_ties(native, oracle):
+    """Exactly periodic texture: many exact ties; top picks the LAST raster minimum, refinement the FIRST."""
+    yy, xx = np.mgrid[0:256, 0:384]
+    base = (((xx // 2) % 2) * 120 + ((yy // 2) % 2) * 60 + 20).astype(np.uint8)
+    for levels in (3, 4):
+        t = [np.ascontiguousarray(base[:: 1 << l, :: 1 << l]) for l in range(levels)]
+        a = [np.ascontiguousarray(np.roll(base, (1, 1), (0, 1))[:: 1 << l, :: 1 << l]) for l in range(levels)]
+        exp_mv, exp_mad = oracle.hbma(t, a, 8, 16, 16)
+        for f in (native.HBMA_FORCE_FUSED, native.HBMA_FORCE_WAVE_PER_BLOCK):
+            mv, mad = native.hbma_host(t, a, 8, 16, 16, flags=f)
+            _assert_same(mv, mad, exp_mv, exp_mad, f"periodic L={levels}")
+
+
+@pytest.mark.parametrize("levels", [3, 4])
+def test_hbma_pairs_batched_clip(native, oracle, levels):
+    """Device-resident clip layout: pair p = (frame p, frame p+1) of one packed buffer."""
+    n = 5
+    _, pyrs, (pw, ph) = util.clip_frames(320, 240, n, 0xABC + levels, levels)
+    stride = native.pyramid_stride(pw, ph, levels)
+    buf = util.pack_clip(pyrs, stride, "cuda")
+    mv, mad = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, 8)
+    mvw, madw = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, 8,
+                                  flags=native.HBMA_FORCE_WAVE_PER_BLOCK)
+    torch.cuda.synchronize()
+    for p in range(n - 1):
+        exp_mv, exp_mad = oracle.hbma(util.np_pyr(pyrs[p]), util.np_pyr(pyrs[p + 1]), 8, 16, 16)
+        _assert_same(mv[p].cpu().numpy(), mad[p].cpu().numpy(), exp_mv, exp_mad, f"fused pair {p}")
+        _assert_same(mvw[p].cpu().numpy(), madw[p].cpu().numpy(), exp_mv, exp_mad, f"wave pair {p}")
+
+
+def test_invalid_args(native):
+    t = [np.zeros((64, 64), np.uint8)]
+    with pytest.raises(native.SvcError) as e:
+        native.hbma_host(t, t, 8, 16, 24)  # 64 % 24 != 0 (motion.cpp:428-429)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG
+    with pytest.raises(native.SvcError) as e:
+        native.hbma_host(t * 3, t * 3, 2, 16, 16)  # search_range < 2^(L-1) (motion.cpp:433)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG
