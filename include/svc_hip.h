@@ -106,6 +106,14 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
                           uint8_t* d_inlier_mask, uint32_t* d_inlier_count,
                           void* stream);
 
+/* In-repo part of the segmentation glue, libs/encoder.cpp:507-513 + :549-551:
+ * foreground = not a RANSAC inlier; d_block_types [n_frames][blocks] gets 0
+ * (BLOCK_TYPE_BACKGROUND, libs/codec.hpp:6) for inliers and region id 1 for the
+ * foreground (the OpenCV-side clustering into several regions is SURVEY 8f-2). */
+int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks,
+                               uint32_t n_frames, uint32_t* d_block_types,
+                               void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Transform.  d_bgr: n_frames frames of H x W x 3 u8, interleaved B,G,R (the
  * padded frame the reference converts to f32 at libs/encoder.cpp:638), frame f at

@@ -150,6 +150,13 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
                        d_inlier_mask, d_inlier_count, static_cast<hipStream_t>(stream));
 }
 
+int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks, uint32_t n_frames,
+                                uint32_t* d_block_types, void* stream) {
+  SVC_REQUIRE(d_inlier_mask && d_block_types, "block_types: null pointer");
+  return launch_block_types(d_inlier_mask, (uint64_t)blocks * n_frames, d_block_types,
+                            static_cast<hipStream_t>(stream));
+}
+
 static int validate_dct(const void* in, const void* out, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh) {
   SVC_REQUIRE(in && out, "dct: null pointer");
   SVC_REQUIRE(bw > 0 && bh > 0, "dct: block must be positive (encoder.cpp:325-326)");

@@ -125,6 +125,24 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
   }
 }
 
+// libs/encoder.cpp:507-513 + :549-551 (the in-repo part of the segmentation glue):
+// the foreground mask is the complement of the RANSAC inliers and every block starts
+// as BLOCK_TYPE_BACKGROUND (0, libs/codec.hpp:6).  Until the OpenCV-side clustering
+//  exists, all foreground blocks form one region with id 1.
+__global__ __launch_bounds__(256) void block_types_kernel(const uint8_t* mask, uint32_t* types, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    types[i] = mask[i] ? 0u : 1u;
+}
+
+int launch_block_types(const uint8_t* d_mask, uint64_t n, uint32_t* d_types, hipStream_t stream) {
+  if (n == 0) return SVC_OK;
+  const uint64_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(block_types_kernel, dim3((uint32_t)(want < 2048 ? want : 2048)), dim3(256), 0, stream,
+                     d_mask, d_types, n);
+  return check_launch("block_types_kernel");
+}
+
 int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
                   const uint32_t* d_samples, uint32_t iters, float* d_gm, float* d_rmse,
                   uint8_t* d_mask, uint32_t* d_count, hipStream_t stream) {

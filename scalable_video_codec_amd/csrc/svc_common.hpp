@@ -72,6 +72,7 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames,
                   svc_ransac_params params, const uint32_t* d_samples, uint32_t iters,
                   float* d_gm, float* d_rmse, uint8_t* d_mask, uint32_t* d_count,
                   hipStream_t stream);
+int launch_block_types(const uint8_t* d_mask, uint64_t n, uint32_t* d_types, hipStream_t stream);
 int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames,
                         uint32_t w, uint32_t h, uint32_t levels, uint8_t* d_pyr,
                         uint64_t pyr_stride, hipStream_t stream);

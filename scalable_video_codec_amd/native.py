@@ -44,6 +44,7 @@ SIGNATURES = {
     "svc_hip_ebma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
     "svc_hip_dct_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_dct_quant_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
@@ -149,6 +150,15 @@ def ransac_frames(mv: torch.Tensor, samples: torch.Tensor, gm_in: Optional[torch
                                         iters, _dev(gm, torch.float32), _dev(rmse, torch.float32),
                                         _dev(mask, torch.uint8), _dev(count, torch.int32), _stream()))
     return gm, rmse, mask, count
+
+
+def block_types_frames(mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mask: (frames, blocks) u8 inlier mask -> (frames, blocks) i32 block types (0 = background)."""
+    frames, blocks = mask.shape
+    if out is None:
+        out = torch.empty((frames, blocks), dtype=torch.int32, device=mask.device)
+    _check(load().svc_hip_block_types_frames(_dev(mask, torch.uint8), blocks, frames, _dev(out, torch.int32), _stream()))
+    return out
 
 
 def dct_frames(bgr: torch.Tensor, block: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

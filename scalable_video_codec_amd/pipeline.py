@@ -1,0 +1,163 @@
+"""Clip-level driver of the hot path: the part of the reference's per-frame loop
+(Encoder::operator(), libs/encoder.cpp:453-664) that touches motion search, global
+motion, block types and the transform, batched over a clip that lives in HBM.
+
+Frame order follows the reference: the tracked frame of encoded frame t is the
+previous SOURCE frame (libs/encoder.cpp:661-663 swaps source pyramids; there is no
+decoded-frame feedback), and frame 0 of a clip is tracked-only (:361-367).
+
+Multi-GPU: a long clip is cut into consecutive chunks, one per rank.
+The only cross-rank dependency is the pyramid of the frame just before a chunk, so
+each step rank r sends the pyramid of its last frame to rank r+1 (one RCCL
+send/recv of ~2.7 MB at 1080p over one xGMI link) and rank r+1 parks it in a halo
+slot in front of its own pyramids.  No other data crosses ranks; outputs stay
+sharded.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import native
+from .configs import CodecConfig
+
+_PMC_JSON = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+
+
+def load_pmc_traffic() -> Dict[str, float]:
+    """HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/), if recorded."""
+    try:
+        with open(_PMC_JSON) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def plan_shards(total_frames: int, world: int) -> List[Tuple[int, int, bool]]:
+    """Cuts a clip of `total_frames` into `world` consecutive chunks.  Returns, per rank,
+    (first_frame, n_frames, needs_halo): every rank but the first needs the pyramid of
+    frame first_frame - 1 from its predecessor.  Encoded frames: total_frames - 1."""
+    base, extra = divmod(total_frames, world)
+    out, start = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((start, n, r > 0 and n > 0))
+        start += n
+    return out
+
+
+def ransac_samples(n_frames: int, iters: int, subset: int, blocks: int, seed: int, device) -> torch.Tensor:
+    """Deterministic, distinct-within-an-iteration sample indices (the explicit draws of
+    include/svc_hip.h): a counter hash, then offsets that keep a subset distinct."""
+    from .synth import hash32
+    idx = torch.arange(n_frames * iters, dtype=torch.int64, device=device)
+    first = hash32(idx * 0x9E3779B1 + seed) % blocks
+    step = 1 + hash32(idx * 0x85EBCA6B + seed + 1) % max(1, (blocks - 1) // max(1, subset))
+    k = torch.arange(subset, dtype=torch.int64, device=device)
+    s = (first.unsqueeze(1) + step.unsqueeze(1) * k) % blocks
+    return s.reshape(n_frames, iters, subset).to(torch.int32).contiguous()
+
+
+class ClipEncoder:
+    """Owns the device buffers of one rank's chunk and runs one hot-path pass per step()."""
+
+    def __init__(self, cfg: CodecConfig, n_frames: int, device, rank: int = 0, world: int = 1,
+                 ransac: Optional[dict] = None):
+        self.cfg, self.n, self.dev, self.rank, self.world = cfg, n_frames, device, rank, world
+        self.pw, self.ph = cfg.padded
+        self.levels = cfg.levels
+        self.blocks = cfg.blocks
+        self.has_halo = world > 1 and rank > 0
+        self.pairs_per_step = n_frames - 1 + (1 if self.has_halo else 0)
+        self.encoded_per_step = self.pairs_per_step
+        self.first_encoded = 0 if self.has_halo else 1
+        self.stride = native.pyramid_stride(self.pw, self.ph, self.levels)
+        self.ransac = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+        if ransac:
+            self.ransac.update(ransac)
+        p = self.pairs_per_step
+        # slot 0 = halo (previous rank's last frame), slots 1..n = own frames
+        self.pyr = torch.zeros((n_frames + 1) * self.stride, dtype=torch.uint8, device=device)
+        self.bgr = torch.empty((n_frames, self.ph, self.pw, 3), dtype=torch.uint8, device=device)
+        self.mv = torch.empty((p, self.blocks, 2), dtype=torch.float32, device=device)
+        self.mad = torch.empty((p, self.blocks), dtype=torch.float32, device=device)
+        self.gm = torch.zeros((p, 2), dtype=torch.float32, device=device)
+        self.rmse = torch.empty(p, dtype=torch.float32, device=device)
+        self.mask = torch.empty((p, self.blocks), dtype=torch.uint8, device=device)
+        self.count = torch.empty(p, dtype=torch.int32, device=device)
+        self.types = torch.empty((p, self.blocks), dtype=torch.int32, device=device)
+        self.coeffs = (torch.empty((p, 3, self.ph, self.pw), dtype=torch.float32, device=device)
+                       if cfg.dct_block else None)
+        self.iters = native.ransac_iter_count(**self.ransac)
+        self.samples = ransac_samples(p, self.iters, self.ransac["subset_sz"], self.blocks,
+                                      cfg.seed + 7919 * rank, device)
+        self._ev: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
+
+    def load_frames(self, frames: List[torch.Tensor]) -> None:
+        assert len(frames) == self.n
+        for i, f in enumerate(frames):
+            self.bgr[i].copy_(f)
+
+    # -- timing: HIP events on the stream the kernels are launched on ----------------
+    def reset_kernel_timers(self) -> None:
+        self._ev = {}
+
+    def _timed(self, name: str, timed: bool):
+        enc = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                if timed:
+                    self_inner.a = torch.cuda.Event(enable_timing=True)
+                    self_inner.b = torch.cuda.Event(enable_timing=True)
+                    self_inner.a.record()
+
+            def __exit__(self_inner, *exc):
+                if timed:
+                    self_inner.b.record()
+                    enc._ev.setdefault(name, []).append((self_inner.a, self_inner.b))
+        return _Ctx()
+
+    def kernel_times_ms(self) -> Dict[str, float]:
+        """Average duration per launch (per step) of each stage, from the recorded events."""
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self._ev.items()}
+
+    # -- one pass of the hot path -----------------------------------------------------
+    def exchange_halo(self) -> None:
+        """Ring-less neighbour shift: my last pyramid -> rank+1's halo slot (RCCL over xGMI)."""
+        if self.world <= 1:
+            return
+        ops = []
+        own_last = self.pyr[self.n * self.stride:(self.n + 1) * self.stride]
+        if self.rank + 1 < self.world:
+            ops.append(dist.P2POp(dist.isend, own_last, self.rank + 1))
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.irecv, self.pyr[:self.stride], self.rank - 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def step(self, timed: bool = False) -> None:
+        c = self.cfg
+        with self._timed("luma_pyramid", timed):
+            native.luma_pyramid_frames(self.bgr, self.levels, out=self.pyr[self.stride:], stride=self.stride)
+        with self._timed("halo_exchange", timed and self.world > 1):
+            self.exchange_halo()
+        t0 = 0 if self.has_halo else 1
+        with self._timed("hbma", timed):
+            native.hbma_pairs(self.pyr[t0 * self.stride:], self.pyr[(t0 + 1) * self.stride:], self.stride,
+                              self.pairs_per_step, self.levels, self.pw, self.ph, c.search_range,
+                              c.mv_block, c.mv_block, out=(self.mv, self.mad))
+        with self._timed("ransac", timed):
+            native.ransac_frames(self.mv, self.samples, out=(self.gm, self.rmse, self.mask, self.count),
+                                 **self.ransac)
+        with self._timed("block_types", timed):
+            native.block_types_frames(self.mask, out=self.types)
+        if c.dct_block:
+            with self._timed("dct_quant", timed):
+                native.dct_quant_frames(self.bgr[self.first_encoded:], c.dct_block, self.types, c.mv_block,
+                                        c.fg_step, c.bg_step, out=self.coeffs)
