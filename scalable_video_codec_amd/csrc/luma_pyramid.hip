@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void luma_kernel(LumaArgs a) {
   *dst = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
 struct PyrDownArgs {
   uint8_t* pyr;
   uint64_t pyr_stride;
@@ -60,40 +62,61 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i >= n ? 2 * (n - 1) - i : i;
 }
 
-// one lane: 4 destination pixels (one dword store) from a 5 x 11 source patch
+// One lane: 4 destination pixels (one dword store) from a 5 x 11 source patch.
+// Two launches per level keep every wave convergent: BORDER = false covers the quads
+// whose patch lies inside the row (one unaligned dwordx4 per source row, all five in
+// flight together); BORDER = true covers the first and last quad of each row with
+// reflected byte loads (2 quads per row: noise).
+template <bool BORDER>
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
   if (q >= a.total) return;
-  const uint32_t per_frame = a.dh * a.quads_per_row;
+  const uint32_t lanes_per_row = BORDER ? 2u : a.quads_per_row - 2u;
+  const uint32_t per_frame = a.dh * lanes_per_row;
   const uint32_t frame = q / per_frame, rem = q - frame * per_frame;
-  const uint32_t dy = rem / a.quads_per_row, dq = rem - dy * a.quads_per_row;
+  const uint32_t dy = rem / lanes_per_row, k = rem - dy * lanes_per_row;
+  const uint32_t dq = BORDER ? (k == 0 ? 0u : a.quads_per_row - 1u) : k + 1u;
   const uint8_t* src = a.pyr + (size_t)frame * a.pyr_stride + a.src_off;
   const int sx0 = (int)dq * 8;  // source column of the first output's centre
-  const bool interior = sx0 >= 4 && sx0 + 12 <= (int)a.sw;
+  constexpr bool interior = !BORDER;
 
   uint32_t acc[4] = {0, 0, 0, 0};
   const int taps[5] = {1, 4, 6, 4, 1};
+  const uint8_t* rows[5];
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int sy = reflect101((int)dy * 2 + r - 2, (int)a.sh);
-    const uint8_t* row = src + (size_t)sy * a.sw;
-    uint32_t px[11];  // source columns sx0 - 2 .. sx0 + 8
-    if (interior) {
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(row + sx0 - 4);
-      const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
-      px[0] = (w0 >> 16) & 0xFF; px[1] = w0 >> 24;
-      px[2] = w1 & 0xFF; px[3] = (w1 >> 8) & 0xFF; px[4] = (w1 >> 16) & 0xFF; px[5] = w1 >> 24;
-      px[6] = w2 & 0xFF; px[7] = (w2 >> 8) & 0xFF; px[8] = (w2 >> 16) & 0xFF; px[9] = w2 >> 24;
-      px[10] = w3 & 0xFF;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 11; ++i) px[i] = row[reflect101(sx0 - 2 + i, (int)a.sw)];
-    }
+  for (int r = 0; r < 5; ++r)
+    rows[r] = src + (size_t)reflect101((int)dy * 2 + r - 2, (int)a.sh) * a.sw;
+
+  auto accumulate = [&](int r, const uint32_t (&px)[11]) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const uint32_t hsum = px[2 * o] + 4 * px[2 * o + 1] + 6 * px[2 * o + 2] + 4 * px[2 * o + 3] + px[2 * o + 4];
       acc[o] += (uint32_t)taps[r] * hsum;
     }
+  };
+
+  if (interior) {
+    // all five row loads are issued before the first use: one memory round trip, not five
+    u32x4_a4 w[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) w[r] = *reinterpret_cast<const u32x4_a4*>(rows[r] + sx0 - 4);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const uint32_t w0 = w[r].x, w1 = w[r].y, w2 = w[r].z, w3 = w[r].w;
+      const uint32_t px[11] = {(w0 >> 16) & 0xFF, w0 >> 24,
+                               w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
+                               w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24,
+                               w3 & 0xFF};  // source columns sx0 - 2 .. sx0 + 8
+      accumulate(r, px);
+    }
+  } else {
+    uint32_t pb[5][11];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int i = 0; i < 11; ++i) pb[r][i] = rows[r][reflect101(sx0 - 2 + i, (int)a.sw)];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) accumulate(r, pb[r]);
   }
   uint32_t out = 0;
 #pragma unroll
@@ -134,10 +157,13 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     off += (uint64_t)pa.sw * pa.sh;
     pa.dst_off = off;
     pa.quads_per_row = pa.dw / 4;
-    const uint64_t tot = (uint64_t)n_frames * pa.dh * pa.quads_per_row;
+    if (pa.quads_per_row < 2) return fail(SVC_ERR_UNSUPPORTED, "pyramid: level %u is narrower than 16 pixels", l);
+    const uint64_t tot = (uint64_t)n_frames * pa.dh * (pa.quads_per_row - 2);
     if (tot > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many pixels for one launch");
     pa.total = (uint32_t)tot;
-    hipLaunchKernelGGL(pyr_down_kernel, dim3(div_up(pa.total, 256)), dim3(256), 0, stream, pa);
+    if (pa.total) hipLaunchKernelGGL(pyr_down_kernel<false>, dim3(div_up(pa.total, 256)), dim3(256), 0, stream, pa);
+    pa.total = n_frames * pa.dh * 2;
+    hipLaunchKernelGGL(pyr_down_kernel<true>, dim3(div_up(pa.total, 256)), dim3(256), 0, stream, pa);
     rc = check_launch("pyr_down_kernel");
     if (rc) return rc;
   }

@@ -37,9 +37,41 @@ __device__ __forceinline__ bool is_inlier(float gx, float gy, float mx, float my
   return dx * dx + dy * dy < t2;
 }
 
+constexpr uint32_t kChunk = 4096;  // LDS staging: 4096 float2 = 32 KiB
+
+// Sequential f32 sums over an LDS-staged chunk, in index order, by ONE lane: the
+// reference's accumulation order (motion.cpp:156-159, :172-175) is part of the result.
+// Entries that are not inliers were staged as +0.0f, which leaves a sum unchanged.
+__device__ __forceinline__ void serial_sum2(const float2* st, uint32_t n, float& sx, float& sy) {
+  uint32_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(st + i);
+    const float4 b = *reinterpret_cast<const float4*>(st + i + 2);
+    sx = sx + a.x; sy = sy + a.y;
+    sx = sx + a.z; sy = sy + a.w;
+    sx = sx + b.x; sy = sy + b.y;
+    sx = sx + b.z; sy = sy + b.w;
+  }
+  for (; i < n; ++i) { sx = sx + st[i].x; sy = sy + st[i].y; }
+}
+
+__device__ __forceinline__ void serial_sum1(const float* st, uint32_t n, float& acc) {
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(st + i);
+    const float4 b = *reinterpret_cast<const float4*>(st + i + 4);
+    acc += a.x; acc += a.y; acc += a.z; acc += a.w;
+    acc += b.x; acc += b.y; acc += b.z; acc += b.w;
+  }
+  for (; i < n; ++i) acc += st[i];
+}
+
 __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
+  __shared__ __attribute__((aligned(16))) float2 s_stage[kChunk];
   __shared__ float s_gm[2];
   __shared__ uint32_t s_cnt[4];
+  __shared__ int s_isum[2];
+  __shared__ uint32_t s_flag;
   const uint32_t tid = threadIdx.x, frame = blockIdx.x;
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * a.blocks;
   const uint32_t* samples = a.samples + (size_t)frame * a.iters * a.subset;
@@ -80,47 +112,100 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
     }
     __syncthreads();  // s_gm / s_cnt are rewritten next iteration
   }
+  const bool any_iter = a.iters > 0;
 
   // mask of the winning model's inliers (== best_inliers, motion.cpp:236 / :244-253)
   for (uint32_t i = tid; i < a.blocks; i += 256) {
     const float2 m = mv[i];
-    mask[i] = (a.iters > 0 && is_inlier(bgx, bgy, m.x, m.y, t2)) ? 1 : 0;
+    mask[i] = (any_iter && is_inlier(bgx, bgy, m.x, m.y, t2)) ? 1 : 0;
   }
-  __syncthreads();
 
-  if (tid == 0) {
-    float out_gx = bgx, out_gy = bgy, acc = 0.f, r;
-    if (best_n < a.subset) {
-      // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
+  if (best_n < a.subset) {
+    // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
+    if (tid == 0) {
       const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
+      float acc = 0.f;
       for (uint32_t i = 0; i < a.subset; ++i) {
         const float2 m = mv[samples[(size_t)best_it * a.subset + i]];
         const float dx = m.x - ix, dy = m.y - iy;
         acc += dx * dx + dy * dy;
       }
-      r = sqrtf(acc / (float)a.subset);
-    } else {
-      float sx = 0.f, sy = 0.f;
-      for (uint32_t i = 0; i < a.blocks; ++i)
-        if (mask[i]) {
-          const float2 m = mv[i];
-          sx = sx + m.x;
-          sy = sy + m.y;
-        }
-      const float inv = 1.0f / (float)best_n;
-      out_gx = sx * inv;
-      out_gy = sy * inv;
-      for (uint32_t i = 0; i < a.blocks; ++i)
-        if (mask[i]) {
-          const float2 m = mv[i];
-          const float dx = m.x - out_gx, dy = m.y - out_gy;
-          acc += dx * dx + dy * dy;
-        }
-      r = sqrtf(acc / (float)best_n);
+      a.gm[2 * frame] = bgx;
+      a.gm[2 * frame + 1] = bgy;
+      a.rmse[frame] = sqrtf(acc / (float)a.subset);
+      a.count[frame] = best_n;
     }
+    return;
+  }
+
+  // ---- final model = mean of the inliers (motion.cpp:255-256) -------------------
+  // Fast path: when every MV component is an integer and the sum of magnitudes stays
+  // below 2^24 (always true for block-matching output), every partial sum of the
+  // reference's sequential f32 accumulation is exactly representable, so an integer
+  // reduction in any order gives the identical float.  Otherwise: the serial walk.
+  if (tid == 0) { s_flag = 1u; s_isum[0] = 0; s_isum[1] = 0; s_cnt[0] = 0; }
+  __syncthreads();
+  {
+    bool ok = true;
+    int ix = 0, iy = 0;
+    uint32_t mag = 0;
+    for (uint32_t i = tid; i < a.blocks; i += 256) {
+      const float2 m = mv[i];
+      if (!is_inlier(bgx, bgy, m.x, m.y, t2)) continue;
+      ok = ok && m.x == truncf(m.x) && m.y == truncf(m.y) && fabsf(m.x) <= 32768.f && fabsf(m.y) <= 32768.f;
+      if (ok) {
+        ix += (int)m.x; iy += (int)m.y;
+        mag += (uint32_t)fabsf(m.x) + (uint32_t)fabsf(m.y);
+      }
+    }
+    if (!ok || mag >= (1u << 24)) s_flag = 0u;  // 256 addends below 2^24 cannot wrap s_cnt
+    atomicAdd(&s_isum[0], ix);
+    atomicAdd(&s_isum[1], iy);
+    atomicAdd(&s_cnt[0], mag & 0xFFFFFFu);
+  }
+  __syncthreads();
+  const bool exact_int = s_flag != 0u && s_cnt[0] < (1u << 24);
+  float sx = 0.f, sy = 0.f;
+  if (exact_int) {
+    sx = (float)s_isum[0];
+    sy = (float)s_isum[1];
+  } else {
+    for (uint32_t base = 0; base < a.blocks; base += kChunk) {
+      const uint32_t n = min(kChunk, a.blocks - base);
+      for (uint32_t i = tid; i < n; i += 256) {
+        const float2 m = mv[base + i];
+        s_stage[i] = is_inlier(bgx, bgy, m.x, m.y, t2) ? m : make_float2(0.f, 0.f);
+      }
+      __syncthreads();
+      if (tid == 0) serial_sum2(s_stage, n, sx, sy);
+      __syncthreads();
+    }
+    if (tid == 0) { s_gm[0] = sx; s_gm[1] = sy; }
+    __syncthreads();
+    sx = s_gm[0];
+    sy = s_gm[1];
+  }
+  const float inv = 1.0f / (float)best_n;
+  const float out_gx = sx * inv, out_gy = sy * inv;
+
+  // ---- RMSE (motion.cpp:258-259, :165-180): terms in parallel, the sum in order -----
+  float acc = 0.f;
+  float* terms = reinterpret_cast<float*>(s_stage);
+  for (uint32_t base = 0; base < a.blocks; base += 2 * kChunk) {
+    const uint32_t n = min(2 * kChunk, a.blocks - base);
+    for (uint32_t i = tid; i < n; i += 256) {
+      const float2 m = mv[base + i];
+      const float dx = m.x - out_gx, dy = m.y - out_gy;
+      terms[i] = is_inlier(bgx, bgy, m.x, m.y, t2) ? dx * dx + dy * dy : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) serial_sum1(terms, n, acc);
+    __syncthreads();
+  }
+  if (tid == 0) {
     a.gm[2 * frame] = out_gx;
     a.gm[2 * frame + 1] = out_gy;
-    a.rmse[frame] = r;
+    a.rmse[frame] = sqrtf(acc / (float)best_n);
     a.count[frame] = best_n;
   }
 }

@@ -21,10 +21,15 @@ def _field(rng, n, outlier_frac):
 
 @pytest.mark.parametrize("subset", [1, 2, 5])
 @pytest.mark.parametrize("outliers", [0.0, 0.3, 0.9])
-def test_ransac_host_vs_oracle(native, oracle, subset, outliers):
+@pytest.mark.parametrize("fractional", [False, True])
+def test_ransac_host_vs_oracle(native, oracle, subset, outliers, fractional):
+    """Integral MVs take the exact integer-sum path, fractional ones the in-order f32 walk
+    (order-dependent rounding, motion.cpp:156-159); both must be bit-identical."""
     rng = np.random.default_rng(subset * 10 + int(outliers * 10))
-    n = 8160
+    n = 8160 if not fractional else 9001  # 9001 > 2 LDS chunks
     mv = _field(rng, n, outliers)
+    if fractional:
+        mv += (rng.random((n, 2)) * 0.37).astype(np.float32)
     p = dict(DEFAULT_RANSAC, subset_sz=subset)
     k = oracle.ransac_iter_count(**p)
     assert k == native.ransac_iter_count(**p)
