@@ -41,6 +41,7 @@ struct DctArgs {
   const uint32_t* types;
   uint32_t mv_bw, mv_bh, mfw, mv_blocks;
   float fg_step, bg_step;
+  float fg_inv, bg_inv;  // RN(1 / step), computed on the host
 };
 
 template <int N> struct Basis;
@@ -53,15 +54,17 @@ template <> struct Basis<16> {
   static __device__ __forceinline__ double odd(int k, int i) { return kDctOdd16[k][i]; }
 };
 
-// N-point orthonormal DCT-II via the even/odd split of the basis.
-template <int N>
-__device__ __forceinline__ void dct1d(const double* __restrict__ x, double* __restrict__ y) {
+// N-point orthonormal DCT-II via the even/odd split of the basis.  T = float for the
+// row pass: the inputs are integers <= 255, so the butterflies x[i] +- x[N-1-i] are
+// exact in f32 (half the cost of f64 on this chip) and only their results are widened.
+template <int N, typename T>
+__device__ __forceinline__ void dct1d(const T* __restrict__ x, double* __restrict__ y) {
   constexpr int H = N / 2;
   double s[H], d[H];
 #pragma unroll
   for (int i = 0; i < H; ++i) {
-    s[i] = x[i] + x[N - 1 - i];
-    d[i] = x[i] - x[N - 1 - i];
+    s[i] = (double)(x[i] + x[N - 1 - i]);
+    d[i] = (double)(x[i] - x[N - 1 - i]);
   }
 #pragma unroll
   for (int k = 0; k < H; ++k) {
@@ -84,13 +87,28 @@ __device__ __forceinline__ float quant1(float c, float step) {
   return q * step;
 }
 
+// The same three lines at a fraction of the cost (the IEEE divide expansion + roundf are
+// ~60 issue cycles per coefficient on gfx950 and made the fused kernel VALU-bound):
+//  - division: q0 = c * inv, r = fma(-q0, step, c), q = fma(r, inv, q0) with inv = RN(1/step)
+//    from the host is the correctly rounded quotient (Markstein's correction step) as long
+//    as nothing under/overflows -- coefficients here are 0 or 1e-16 < |c| < 4100;
+//  - std::round (half away from zero) == trunc(q + copysign(0.5 - 2^-25, q)) for every float.
+// Both identities are checked bit-for-bit against the oracle by tests/test_gpu_dct_quant.py.
+__device__ __forceinline__ float quant1_fast(float c, float step, float inv) {
+  const float q0 = c * inv;
+  const float r = __builtin_fmaf(-q0, step, c);
+  float q = __builtin_fmaf(r, inv, q0);
+  q = __builtin_truncf(q + __builtin_copysignf(0.49999997f, q));
+  return q * step;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ double byte_at(const uint32_t* w, int b) {
-  return (double)(float)((w[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+__device__ __forceinline__ float byte_at(const uint32_t* w, int b) {
+  return (float)((w[b >> 2] >> (8 * (b & 3))) & 0xFFu);  // v_cvt_f32_ubyteN
 }
 
 constexpr int kRowPitch = 144;                  // 16 f64 + 16 B pad
@@ -126,25 +144,27 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   uint8_t* slab = lds + sc_local * kSlab;
   float* out_frame = a.planes + (size_t)frame * 3 * a.w * a.h;
 
-  float step = 1.f;
+  float step = 1.f, inv_step = 1.f;
   if (QUANT) {
     // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249);
     // background (0, libs/codec.hpp:6) takes bg_step (libs/decoder.cpp:130-135)
     const uint32_t col = N == 8 ? x_pix + 2 * j : x_pix + j;
     const uint32_t t = a.types[(size_t)frame * a.mv_blocks + (y_pix / a.mv_bh) * a.mfw + col / a.mv_bw];
     step = t == 0 ? a.bg_step : a.fg_step;
+    inv_step = t == 0 ? a.bg_inv : a.fg_inv;
   }
 
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    double x[16], r[16];
+    float x[16];
+    double r[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) x[p] = byte_at(wds, 3 * p + c);
     if (N == 8) {
-      dct1d<8>(x, r);
-      dct1d<8>(x + 8, r + 8);
+      dct1d<8, float>(x, r);
+      dct1d<8, float>(x + 8, r + 8);
     } else {
-      dct1d<16>(x, r);
+      dct1d<16, float>(x, r);
     }
     double2* row = reinterpret_cast<double2*>(slab + j * kRowPitch);
 #pragma unroll
@@ -161,13 +181,13 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
         ca[y] = t.x;
         cb[y] = t.y;
       }
-      dct1d<8>(ca, ya);
-      dct1d<8>(cb, yb);
+      dct1d<8, double>(ca, ya);
+      dct1d<8, double>(cb, yb);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + 2 * j;
 #pragma unroll
       for (int v = 0; v < 8; ++v) {
         float fa = (float)ya[v], fb = (float)yb[v];
-        if (QUANT) { fa = quant1(fa, step); fb = quant1(fb, step); }
+        if (QUANT) { fa = quant1_fast(fa, step, inv_step); fb = quant1_fast(fb, step, inv_step); }
         *reinterpret_cast<float2*>(dst + (size_t)v * a.w) = make_float2(fa, fb);
       }
     } else {
@@ -175,12 +195,12 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 #pragma unroll
       for (int y = 0; y < 16; ++y)
         cc[y] = *reinterpret_cast<const double*>(slab + y * kRowPitch + j * 8);
-      dct1d<16>(cc, yy);
+      dct1d<16, double>(cc, yy);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + j;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         float f = (float)yy[v];
-        if (QUANT) f = quant1(f, step);
+        if (QUANT) f = quant1_fast(f, step, inv_step);
         dst[(size_t)v * a.w] = f;
       }
     }
@@ -214,6 +234,8 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
     a.mv_blocks = a.mfw * (h / mv_bh);
     a.fg_step = (float)fg_step;  // libs/decoder.cpp:141 divides a float by an unsigned
     a.bg_step = (float)bg_step;
+    a.fg_inv = 1.0f / a.fg_step;
+    a.bg_inv = 1.0f / a.bg_step;
   }
   const uint32_t seg_per_wg = 256 / bw;
   const dim3 grid(div_up(a.total_segcols, seg_per_wg)), block(256);

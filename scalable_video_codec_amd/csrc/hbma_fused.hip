@@ -13,11 +13,14 @@
 //
 // SAD engine.  v_qsad_pk_u16_u8 returns, for one 4-byte anchor word, the four SADs
 // against the tracked bytes at offsets 0..3 of an 8-byte window, accumulated as
-// 4 x u16 (a 16x16 block's SAD <= 65280 fits).  The window origin is ALIGNED DOWN
-// to 4 bytes, so the +-R_top candidates land on columns j = shift .. shift + 2 R_top
-// (shift = origin & 3) of an 8-column grid = exactly two QSADs per anchor word and
-// no realignment of the tracked data at all.  Columns outside the reference's
-// clamped window (libs/motion.cpp:375-385) are masked at selection time.
+// 4 x u16 (a 16x16 block's SAD <= 65280 fits).  Measured on gfx950 (tools/
+// ubench_valu.hip): QSAD issues in 16 cycles per wave, v_sad_u8 / v_alignbyte_b32 /
+// v_min3 in 4, i.e. 4 cycles per 4-byte SAD either way, and rocprof shows this kernel
+// VALU-bound (not HBM-bound), so the instruction count is what is minimised: each
+// tracked row is funnel-shifted ONCE to the window origin (shared by every vertical
+// offset), then one QSAD covers dx = 0..3 and one v_sad_u8 the fifth column.
+// Candidates outside the reference's clamped window (libs/motion.cpp:375-385) are
+// masked at selection time.
 //
 // Arithmetic.  All block areas are powers of two, so MAD = sad / area is an exact
 // dyadic rational; the MAD carried across levels (libs/motion.cpp:401 compares a
@@ -86,7 +89,7 @@ __device__ __forceinline__ void load_anchor_row(const uint8_t* p, uint32_t (&a)[
 }
 
 struct Window {
-  int a0, wy;            // origin of the 8-column x (2RT+1)-row candidate grid
+  int wx, wy;              // origin of the (2RT+1) x (2RT+1) candidate grid (always in the plane)
   int jlo, jhi, dlo, dhi;  // the reference's clamped window inside that grid
 };
 
@@ -95,49 +98,64 @@ __device__ __forceinline__ Window make_window(int cx, int cy, int fw, int fh) {
   Window w;
   const int x0 = max(0, cx - RT), x1 = min(fw - B + 1, cx + RT + 1);  // motion.cpp:381-385
   const int y0 = max(0, cy - RT), y1 = min(fh - B + 1, cy + RT + 1);  // :375-379
-  w.a0 = max(0, (cx - RT) & ~3);
+  w.wx = min(max(cx - RT, 0), fw - (B + 2 * RT));
   w.wy = min(max(cy - RT, 0), fh - (B + 2 * RT));
-  w.jlo = x0 - w.a0; w.jhi = x1 - w.a0;
+  w.jlo = x0 - w.wx; w.jhi = x1 - w.wx;
   w.dlo = y0 - w.wy; w.dhi = y1 - w.wy;
   return w;
 }
 
-// Picks the winner of a (2RT+1) x 8 grid of SADs in the reference's raster order.
-// TOP: `<=` so the last minimum wins, and the MV is zeroed when every candidate
-// updated (motion.cpp:324-337).  Refinement: strict `<` against the carried,
-// scaled minimum (motion.cpp:401).
+// Picks the winner of the (2RT+1)^2 grid of SADs in the reference's raster order with one
+// unsigned min over packed keys  (scaled_sad << 5) | code :
+//   refinement (motion.cpp:401, strict `<` against the carried minimum): code = raster
+//     index, so equal SADs resolve to the FIRST candidate; the winner replaces the carried
+//     value only if its scaled SAD is strictly smaller;
+//   top level (motion.cpp:324-337, `<=`): code = 31 - index, so equal SADs resolve to the
+//     LAST candidate; and if the valid SADs are non-increasing in raster order every
+//     candidate "updated" and the MV is zeroed (the minimum is kept).
+// Candidates outside the reference's clamped window get the all-ones key.
 template <int RT, bool TOP, int SHIFT, typename GetSad>
 __device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad sad_at, int& mvx,
                                        int& mvy, uint32_t& best) {
-  constexpr int NDY = 2 * RT + 1;
-  uint32_t mn = TOP ? 0xFFFFFFFFu : best;
-  int bj = -1, bd = 0, updates = 0, nvalid = 0;
+  constexpr int N = 2 * RT + 1;
+  static_assert(N * N <= 32, "raster index must fit the 5-bit code");
+  uint32_t kmin = 0xFFFFFFFFu;
+  uint32_t prev = 0xFFFFFFFFu;  // FLT_MAX of motion.cpp:290
+  bool mono = true;
 #pragma unroll
-  for (int d = 0; d < NDY; ++d) {
+  for (int d = 0; d < N; ++d) {
     const bool row_ok = d >= w.dlo && d < w.dhi;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t s = sad_at(d, j) << SHIFT;
+    for (int j = 0; j < N; ++j) {
       const bool valid = row_ok && j >= w.jlo && j < w.jhi;
+      const uint32_t s = sad_at(d, j);
+      const int idx = d * N + j;
+      const uint32_t key = (s << (SHIFT + 5)) | (uint32_t)(TOP ? 31 - idx : idx);
+      kmin = min(kmin, valid ? key : 0xFFFFFFFFu);
       if (TOP) {
-        if (valid) {
-          ++nvalid;
-          if (s <= mn) { mn = s; bj = j; bd = d; ++updates; }
-        }
-      } else {
-        if (valid && s < mn) { mn = s; bj = j; bd = d; }
+        mono = mono && (!valid || s <= prev);
+        prev = valid ? s : prev;
       }
     }
   }
-  if (bj >= 0) {
-    mvx = w.a0 + bj - ax;
+  const uint32_t smin = kmin >> 5;  // scaled SAD of the winner
+  const int idx = TOP ? 31 - (int)(kmin & 31u) : (int)(kmin & 31u);
+  const int bd = idx / N, bj = idx - bd * N;
+  if (TOP) {
+    best = smin;
+    mvx = mono ? 0 : w.wx + bj - ax;
+    mvy = mono ? 0 : w.wy + bd - ay;
+  } else if (smin < best) {
+    best = smin;
+    mvx = w.wx + bj - ax;
     mvy = w.wy + bd - ay;
-    best = mn;
   }
-  if (TOP && updates == nvalid) { mvx = 0; mvy = 0; }
 }
 
-// One level with block size B >= 4.
+// One level with block size B >= 4.  Per tracked row: NW + 2 aligned dwords are loaded
+// and funnel-shifted once (v_alignbyte_b32) so that word k starts at window byte 4k; then
+// for every anchor row that meets it, per anchor word: one v_qsad_pk_u16_u8 (candidates
+// dx = 0..3) and, for RT = 2, one v_sad_u8 (dx = 4).
 template <int B, int RT, bool TOP, int SHIFT>
 __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
                                              const uint8_t* __restrict__ anc, int fw, int fh,
@@ -145,19 +163,24 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
   constexpr int NW = B / 4, ND = NW + 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
   const int ax = bx * B, ay = by * B;
   const Window w = make_window<B, RT>(ax + mvx, ay + mvy, fw, fh);
+  const int a0 = w.wx & ~3;
+  const uint32_t sh = (uint32_t)(w.wx & 3);
 
-  uint64_t acc[NDY][2];
+  uint64_t acc4[NDY];
+  uint32_t acc1[NDY];
 #pragma unroll
-  for (int d = 0; d < NDY; ++d) acc[d][0] = acc[d][1] = 0;
+  for (int d = 0; d < NDY; ++d) { acc4[d] = 0; acc1[d] = 0; }
   uint32_t a[B][NW];
   const uint8_t* tp = trk + (size_t)w.wy * fw;
   const uint8_t* ap = anc + (size_t)ay * fw + ax;
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    uint32_t m[ND];
-    load_row<ND, TOP>(tp + (size_t)t * fw, w.a0, fw, m);
+    uint32_t m[ND], v[NW + 1];
+    load_row<ND, TOP>(tp + (size_t)t * fw, a0, fw, m);
     if (t < B) load_anchor_row<NW>(ap + (size_t)t * fw, a[t < B ? t : 0]);
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
 #pragma unroll
     for (int d = 0; d < NDY; ++d) {
       const int r = t - d;  // anchor row that meets tracked row t at vertical offset d
@@ -165,16 +188,18 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
           const uint32_t av = a[r >= 0 && r < B ? r : 0][k];
-          acc[d][0] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(m[k], m[k + 1]), av, acc[d][0]);
-          acc[d][1] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(m[k + 1], m[k + 2]), av, acc[d][1]);
+          acc4[d] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k], v[k + 1]), av, acc4[d]);
+          if (RT == 2) acc1[d] = __builtin_amdgcn_sad_u8(v[k + 1], av, acc1[d]);
         }
       }
     }
   }
   select<RT, TOP, SHIFT>(
       w, ax, ay,
-      [&](int d, int j) { return (uint32_t)(acc[d][j >> 2] >> (16 * (j & 3))) & 0xFFFFu; }, mvx,
-      mvy, best);
+      [&](int d, int j) {
+        return j < 4 ? (uint32_t)(acc4[d] >> (16 * (j & 3))) & 0xFFFFu : acc1[d];
+      },
+      mvx, mvy, best);
 }
 
 // Top level of a 4-level pyramid: 2x2 blocks (reference motion.cpp:719-720).  Two
@@ -187,11 +212,13 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
   constexpr int B = 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
   const int ax = bx * B, ay = by * B;
   const Window w = make_window<B, RT>(ax, ay, fw, fh);
-  uint32_t s[NDY][8];
+  const int a0 = w.wx & ~3;
+  const uint32_t sh = (uint32_t)(w.wx & 3);
+  uint32_t s[NDY][NDY];
 #pragma unroll
   for (int d = 0; d < NDY; ++d)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[d][j] = 0;
+    for (int j = 0; j < NDY; ++j) s[d][j] = 0;
   uint32_t a[B];
 #pragma unroll
   for (int r = 0; r < B; ++r)
@@ -200,18 +227,20 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     uint32_t m[3];
-    load_row<3, true>(tp + (size_t)t * fw, w.a0, fw, m);
-    uint32_t tj[8];
+    load_row<3, true>(tp + (size_t)t * fw, a0, fw, m);
+    // window bytes 0 .. 2RT+1 (<= 6) as two dwords starting at the window origin
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(m[1], m[0], sh);
+    const uint32_t v1 = __builtin_amdgcn_alignbyte(m[2], m[1], sh);
+    uint32_t tj[NDY];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tj[j] = __builtin_amdgcn_alignbyte(m[1], m[0], j) & 0xFFFFu;
-#pragma unroll
-    for (int j = 4; j < 8; ++j) tj[j] = __builtin_amdgcn_alignbyte(m[2], m[1], j - 4) & 0xFFFFu;
+    for (int j = 0; j < NDY; ++j)
+      tj[j] = (j < 4 ? __builtin_amdgcn_alignbyte(v1, v0, j) : v1 >> (8 * (j - 4))) & 0xFFFFu;
 #pragma unroll
     for (int d = 0; d < NDY; ++d) {
       const int r = t - d;
       if (r >= 0 && r < B) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NDY; ++j)
           s[d][j] = __builtin_amdgcn_sad_u8(tj[j], a[r >= 0 && r < B ? r : 0], s[d][j]);
       }
     }
@@ -257,7 +286,7 @@ bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, ui
   if (rt != 1 && rt != 2) return false;
   const uint32_t tw = w >> (levels - 1), th = h >> (levels - 1), tb = 16u >> (levels - 1);
   // the top plane must hold a whole candidate grid (clamped loads stay in the row)
-  return tw >= tb + 8 && th >= tb + 2 * rt && (w % 16 == 0) && (h % 16 == 0);
+  return tw >= tb + 8 && tw >= 12 && th >= tb + 2 * rt && (w % 16 == 0) && (h % 16 == 0);
 }
 
 int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
