@@ -62,6 +62,23 @@ def ransac_samples(n_frames: int, iters: int, subset: int, blocks: int, seed: in
     return s.reshape(n_frames, iters, subset).to(torch.int32).contiguous()
 
 
+def halo_exchange(pyr: torch.Tensor, stride: int, n_frames: int, rank: int, world: int) -> None:
+    """The one cross-rank step.  `pyr` holds n_frames + 1 packed-pyramid
+    slots: slot 0 is the halo, slots 1..n_frames this rank's frames.  Rank r sends its
+    last pyramid to rank r + 1, which receives it into slot 0; rank 0 has no predecessor
+    (frame 0 of the clip is tracked-only, libs/encoder.cpp:361-367).  Works on any
+    backend: RCCL ("nccl") on device buffers in the product, gloo on CPU in the tests."""
+    if world <= 1:
+        return
+    ops = []
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, pyr[n_frames * stride:(n_frames + 1) * stride], rank + 1))
+    if rank > 0:
+        ops.append(dist.P2POp(dist.irecv, pyr[:stride], rank - 1))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
 class ClipEncoder:
     """Owns the device buffers of one rank's chunk and runs one hot-path pass per step()."""
 
@@ -130,16 +147,7 @@ class ClipEncoder:
     # -- one pass of the hot path -----------------------------------------------------
     def exchange_halo(self) -> None:
         """Ring-less neighbour shift: my last pyramid -> rank+1's halo slot (RCCL over xGMI)."""
-        if self.world <= 1:
-            return
-        ops = []
-        own_last = self.pyr[self.n * self.stride:(self.n + 1) * self.stride]
-        if self.rank + 1 < self.world:
-            ops.append(dist.P2POp(dist.isend, own_last, self.rank + 1))
-        if self.rank > 0:
-            ops.append(dist.P2POp(dist.irecv, self.pyr[:self.stride], self.rank - 1))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        halo_exchange(self.pyr, self.stride, self.n, self.rank, self.world)
 
     def step(self, timed: bool = False) -> None:
         c = self.cfg

@@ -1,0 +1,96 @@
+"""The drop-in boundary, checked without a GPU: the C-ABI library loads and exports
+every symbol include/svc_hip.h declares; the C++ library exports the reference's own
+mangled names (libs/motion.hpp:100-153); argument validation answers before any device
+work; and with no GPU the product fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from scalable_video_codec_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "svc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(svc_hip_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = native.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/svc_hip.h but not exported"
+    assert set(names) == set(native.SIGNATURES), set(names) ^ set(native.SIGNATURES)
+    assert lib.svc_hip_abi_version() == 1
+
+
+def test_motion_library_exports_reference_symbols():
+    """Itanium-mangled names of the reference's public functions (nm -C of the compiled
+    reference object) -- what apps/encoder.cpp links against."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", native.MOTION_LIB_PATH], text=True)
+    for sym in ("_Z26EstimateMotionHierarchicalPKPKhS2_jjjjjjP5Vec2fPf",
+                "_Z35EstimateMotionHierarchical16x16Sse2PKPKhS2_jjjP5Vec2fPf",
+                "_Z30EstimateMotionExhaustiveSearchPKhS0_jjjjjP5Vec2fPf",
+                "_Z26EstimateGlobalMotionRansacPK5Vec2fj12RansacParamsPfPS_PSt6vectorIjSaIjEE"):
+        assert sym in out, sym
+    ctypes.CDLL(native.MOTION_LIB_PATH)  # resolves its libsvc_hip.so dependency via $ORIGIN
+
+
+def test_pyramid_bytes_and_iter_count():
+    assert native.pyramid_bytes(1920, 1088, 3) == 2741760
+    assert native.pyramid_bytes(3840, 2160, 4) == 11016000
+    assert native.pyramid_bytes(352, 288, 1) == 101376
+    assert native.ransac_iter_count() == 7                      # defaults, SURVEY.md 3.3
+    assert native.ransac_iter_count(subset_sz=3) == 35
+
+
+def test_preconditions_are_statuses_not_ub():
+    """The reference only asserts these (libs/motion.cpp:417-433); here they are
+    SVC_ERR_INVALID_ARG, raised before any device call (so this runs without a GPU)."""
+    z = [np.zeros((64, 64), np.uint8)]
+    for args in ((z, z, 8, 16, 24),          # frame % block (motion.cpp:428-429)
+                 (z, z, 8, 0, 16),           # zero block (:423)
+                 (z * 3, z * 3, 2, 16, 16),  # range < 2^(L-1) (:433)
+                 (z * 2, z * 2, 8, 3, 16)):  # block not divisible by 2^(L-1)
+        with pytest.raises(native.SvcError) as e:
+            native.hbma_host(*args)
+        assert e.value.status == native.SVC_ERR_INVALID_ARG, args[2:]
+    with pytest.raises(native.SvcError) as e:
+        native.quant_host(np.ones(4, np.float32), 0)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG
+    with pytest.raises(native.SvcError) as e:
+        native.ransac_host(np.zeros((4, 2), np.float32), np.array([4], np.uint32))  # index == N: the reference's OOB draw
+    assert e.value.status == native.SVC_ERR_INVALID_ARG
+    with pytest.raises(native.SvcError) as e:
+        native.dct_host(np.zeros((30, 32, 3), np.uint8), 8)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    z = [np.zeros((64, 64), np.uint8)]
+    with pytest.raises(native.SvcError) as e:
+        native.hbma_host(z, z, 8, 16, 16)
+    assert e.value.status == native.SVC_ERR_NO_DEVICE
+    with pytest.raises(native.SvcError) as e:
+        native.dct_host(np.zeros((32, 32, 3), np.uint8), 8)
+    assert e.value.status == native.SVC_ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under scalable_video_codec_amd/ or include/ may reference it."""
+    for base in ("scalable_video_codec_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inc")):
+                    text = open(os.path.join(dp, f)).read()
+                    assert "svc_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

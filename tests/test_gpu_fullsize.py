@@ -1,0 +1,93 @@
+"""BASELINE.json's full-size workload (C3: 1080p, 300 frames, 3 levels, 8x8 DCT + quant)
+through size-independent properties, plus sampled pairs against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from scalable_video_codec_amd import configs, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def encoded(native):
+    cfg = configs.C3
+    dev = torch.device("cuda")
+    clip = synth.SynthClip(cfg.width, cfg.height, cfg.frames, cfg.seed, device=dev)
+    pw, ph = cfg.padded
+    frames = [synth.pad_frame(clip.frame_bgr(t), pw, ph) for t in range(cfg.frames)]
+    enc = pipeline.ClipEncoder(cfg, cfg.frames, dev)
+    enc.load_frames(frames)
+    enc.step()
+    torch.cuda.synchronize()
+    return cfg, enc
+
+
+def test_two_kernels_agree_on_every_pair(native, encoded):
+    """The fused lane-per-block kernel and the per-level LDS-staged kernel are independent
+    implementations; on all 299 x 8160 blocks they must give identical MVs and min-MADs."""
+    cfg, enc = encoded
+    t0 = enc.stride
+    mv, mad = native.hbma_pairs(enc.pyr[t0:], enc.pyr[2 * t0:], enc.stride, enc.pairs_per_step, cfg.levels,
+                                enc.pw, enc.ph, cfg.search_range, flags=native.HBMA_FORCE_WAVE_PER_BLOCK)
+    torch.cuda.synchronize()
+    assert torch.equal(mv, enc.mv) and torch.equal(mad, enc.mad)
+    bound = cfg.r_top * ((1 << cfg.levels) - 1)  # |mv| <= R_top (2^L - 1), SURVEY.md 8a row 5
+    assert float(enc.mv.abs().max()) <= bound
+    assert bool((enc.mv == enc.mv.round()).all()) and float(enc.mad.min()) >= 0.0
+
+
+def test_sampled_pairs_against_oracle(oracle, encoded):
+    cfg, enc = encoded
+    offs = synth.level_offsets(enc.pw, enc.ph, cfg.levels)
+
+    def planes(slot):
+        flat = enc.pyr[slot * enc.stride:(slot + 1) * enc.stride].cpu().numpy()
+        return [flat[offs[l]:offs[l] + (enc.pw >> l) * (enc.ph >> l)].reshape(enc.ph >> l, enc.pw >> l)
+                for l in range(cfg.levels)]
+    for p in (0, 150, 298):  # pair p = frames p, p+1 = slots p+1, p+2
+        mv, mad = oracle.hbma(planes(p + 1), planes(p + 2), cfg.search_range, 16, 16)
+        assert np.array_equal(enc.mv[p].cpu().numpy(), mv) and np.array_equal(enc.mad[p].cpu().numpy(), mad)
+    # device pyramids == the torch definitions (frame 7)
+    f = enc.bgr[7]
+    for l, ref in enumerate(synth.build_pyramid(synth.bgr_to_y(f), cfg.levels)):
+        got = enc.pyr[8 * enc.stride + offs[l]: 8 * enc.stride + offs[l] + ref.numel()].reshape(ref.shape)
+        assert torch.equal(got, ref)
+
+
+def test_ransac_and_types_consistent(oracle, encoded):
+    cfg, enc = encoded
+    from oracle.binding import DEFAULT_RANSAC
+    for p in (0, 149, 298):
+        gm, rmse, inl = oracle.ransac(enc.mv[p].cpu().numpy(), enc.samples[p].cpu().numpy().astype(np.uint32).ravel(),
+                                      **DEFAULT_RANSAC)
+        assert enc.gm[p].cpu().numpy().tobytes() == gm.tobytes()
+        assert np.float32(enc.rmse[p].item()).tobytes() == rmse.tobytes()
+        assert np.array_equal(np.flatnonzero(enc.mask[p].cpu().numpy()), inl) and int(enc.count[p]) == len(inl)
+    assert torch.equal(enc.types, (enc.mask == 0).to(torch.int32))
+    assert bool(((enc.count > 0) & (enc.count <= cfg.blocks)).all())
+
+
+def test_dct_energy_dc_and_quant_properties(native, encoded):
+    cfg, enc = encoded
+    n = enc.encoded_per_step
+    raw = native.dct_frames(enc.bgr[1:], cfg.dct_block)           # un-quantised, all 299 frames
+    px = enc.bgr[1:].to(torch.float64)
+    e_in = (px * px).sum(dim=(1, 2, 3))
+    e_out = (raw.to(torch.float64) ** 2).sum(dim=(1, 2, 3))
+    assert float(((e_in - e_out).abs() / e_in).max()) < 1e-6       # Parseval, every frame
+    dc = raw[:, :, ::8, ::8].to(torch.float64)
+    means = px.permute(0, 3, 1, 2).reshape(n, 3, enc.ph // 8, 8, enc.pw // 8, 8).mean(dim=(3, 5))
+    assert float((dc - 8 * means).abs().max()) < 2e-3              # DC = 8 x tile mean
+    # fused DCT+quant == quant applied to the raw DCT, bit for bit, on the whole clip
+    q = raw.clone()
+    native.quant_frames_(q, enc.types, cfg.mv_block, cfg.fg_step, cfg.bg_step)
+    torch.cuda.synchronize()
+    assert torch.equal(q, enc.coeffs)
+    # idempotence and lattice membership
+    q2 = q.clone()
+    native.quant_frames_(q2, enc.types, cfg.mv_block, cfg.fg_step, cfg.bg_step)
+    assert torch.equal(q2, q)
+    bg = (enc.types == 0).reshape(n, 1, enc.ph // 16, 1, enc.pw // 16, 1).expand(n, 3, enc.ph // 16, 16, enc.pw // 16, 16)
+    bgc = q.reshape(n, 3, enc.ph // 16, 16, enc.pw // 16, 16)[bg]
+    assert bool((bgc % cfg.bg_step == 0).all())

@@ -1,0 +1,85 @@
+"""Host-side logic: configs, padding, the synthetic generator, the pre-step definitions,
+frame sharding.  CPU only."""
+import numpy as np
+import torch
+
+from scalable_video_codec_amd import configs, pipeline, synth
+
+
+def test_padded_dims_follow_reference():
+    # libs/encoder.cpp:164-168 + libs/math.hpp:276-283: round up to lcm(block, 2^(L-1))
+    assert synth.padded_dims(1920, 1080, 16, 16, 3) == (1920, 1088)
+    assert synth.padded_dims(1920, 1080, 16, 16, 4) == (1920, 1088)
+    assert synth.padded_dims(3840, 2160, 16, 16, 4) == (3840, 2160)
+    assert synth.padded_dims(352, 288, 16, 16, 1) == (352, 288)
+    assert synth.padded_dims(100, 50, 16, 16, 6) == (128, 64)
+    assert synth.closest_larger_divisible(17, 4, 6) == 24
+
+
+def test_config_table_matches_survey():
+    c = configs
+    assert (c.C3.blocks, c.C3.r_top, c.C3.mv_field) == (8160, 2, (120, 68))
+    assert (c.C2.blocks, c.C5.blocks, c.C1.blocks) == (3600, 32400, 396)
+    assert c.C5.r_top == 1 and c.C1.r_top == 8
+    assert c.C3.hbma_bytes_per_frame() == 5581440 and c.C2.hbma_bytes_per_frame() == 2462400
+    assert c.C5.hbma_bytes_per_frame() == 22420800 and c.C1.hbma_bytes_per_frame() == 207504
+    assert c.C3.dct_bytes_per_frame() == 31334400 + 4 * 8160
+
+
+def test_clip_is_deterministic_and_moves():
+    a = synth.SynthClip(352, 288, 3, 1234)
+    b = synth.SynthClip(352, 288, 3, 1234)
+    f0, f0b, f1 = a.frame_bgr(0), b.frame_bgr(0), a.frame_bgr(1)
+    assert torch.equal(f0, f0b) and not torch.equal(f0, f1)
+    assert f0.dtype == torch.uint8 and f0.shape == (288, 352, 3)
+    # global drift (+3, -2): frame 1 at p shows what frame 0 showed at p + (3, -2), up to +-2 noise
+    y0, y1 = synth.bgr_to_y(f0).int(), synth.bgr_to_y(f1).int()
+    shifted = (y1[20:-20, 20:-20] - y0[18:-22, 23:-17]).abs().float().mean()
+    still = (y1[20:-20, 20:-20] - y0[20:-20, 20:-20]).abs().float().mean()
+    assert shifted < still
+    assert all(abs(x) <= 24 and abs(y) <= 24 for x, y in synth.SynthClip(64, 64, 200, 1).offsets)
+
+
+def test_luma_and_pyramid_definitions():
+    rng = np.random.default_rng(0)
+    bgr = torch.from_numpy(rng.integers(0, 256, (12, 16, 3), dtype=np.uint8))
+    y = synth.bgr_to_y(bgr).numpy()
+    b, g, r = (bgr[..., i].numpy().astype(np.int64) for i in range(3))
+    assert np.array_equal(y, ((1868 * b + 9617 * g + 4899 * r + 8192) >> 14).astype(np.uint8))
+    assert synth.bgr_to_y(torch.full((2, 2, 3), 255, dtype=torch.uint8)).unique().tolist() == [255]
+    # pyr_down against a direct 5x5 reflect-101 loop
+    p = rng.integers(0, 256, (10, 12), dtype=np.uint8)
+    got = synth.pyr_down(torch.from_numpy(p)).numpy()
+    k = np.array([1, 4, 6, 4, 1])
+    refl = lambda i, n: (-i if i < 0 else (2 * (n - 1) - i if i >= n else i))  # noqa: E731
+    for oy in range(5):
+        for ox in range(6):
+            s = sum(int(k[a]) * int(k[c]) * int(p[refl(2 * oy + a - 2, 10), refl(2 * ox + c - 2, 12)])
+                    for a in range(5) for c in range(5))
+            assert got[oy, ox] == (s + 128) >> 8
+    pyr = synth.build_pyramid(torch.from_numpy(rng.integers(0, 256, (32, 48), dtype=np.uint8)), 3)
+    assert [tuple(x.shape) for x in pyr] == [(32, 48), (16, 24), (8, 12)]
+    assert synth.pack_pyramid(pyr).numel() == synth.pyramid_bytes(48, 32, 3) == 48 * 32 * 21 // 16
+    assert synth.level_offsets(48, 32, 3) == [0, 1536, 1920]
+
+
+def test_plan_shards_covers_the_clip_once():
+    for total, world in ((300, 1), (300, 8), (2400, 8), (10, 3), (5, 8)):
+        plan = pipeline.plan_shards(total, world)
+        assert len(plan) == world and sum(n for _, n, _ in plan) == total
+        pos = 0
+        for r, (start, n, halo) in enumerate(plan):
+            assert start == pos and halo == (r > 0 and n > 0)
+            pos += n
+        # encoded frames = frames with a predecessor somewhere in the clip
+        encoded = sum(n - 1 + (1 if halo else 0) for _, n, halo in plan if n > 0)
+        assert encoded == total - 1
+
+
+def test_ransac_samples_are_distinct_and_in_range():
+    s = pipeline.ransac_samples(5, 35, 3, 8160, 99, "cpu")
+    assert s.shape == (5, 35, 3) and s.dtype == torch.int32
+    assert int(s.min()) >= 0 and int(s.max()) < 8160
+    srt = s.sort(dim=-1).values
+    assert bool((srt[..., 1:] != srt[..., :-1]).all())
+    assert torch.equal(s, pipeline.ransac_samples(5, 35, 3, 8160, 99, "cpu"))

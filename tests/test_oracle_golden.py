@@ -1,0 +1,101 @@
+"""Pins the oracle (the C restatement in oracle/svc_oracle.c) to the reference: every
+golden vector below was produced by the unmodified reference libs/motion.cpp
+(tests/golden/make_golden.py), and the restatement must reproduce it bit for bit.
+CPU only."""
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+
+@pytest.mark.parametrize("cfg", G.HBMA_CONFIGS, ids=lambda c: c.name)
+def test_hbma_configs_match_reference(oracle, cfg):
+    z = G.load(f"hbma_{cfg.name}.npz")
+    (_, p0), (f1, p1) = G.config_pair(cfg)
+    # the seeded generator must still produce the bytes the reference was run on
+    assert G.sha(p0) == str(z["sha_tracked"]) and G.sha(p1) == str(z["sha_anchor"])
+    assert G.sha([f1]) == str(z["sha_bgr_anchor"])
+    mv, mad = oracle.hbma(p0, p1, cfg.search_range, cfg.mv_block, cfg.mv_block)
+    assert np.array_equal(mv, z["mv"]) and np.array_equal(mad, z["mad"])
+    if cfg.levels == 4:  # libs/motion.cpp:691-749 == the generic path with 4 levels
+        mv_s, mad_s = oracle.hbma16_sse2(p0, p1, cfg.search_range)
+        assert np.array_equal(mv_s, z["mv_sse2"]) and np.array_equal(mad_s, z["mad_sse2"])
+        assert np.array_equal(z["mv_sse2"], z["mv"]) and np.array_equal(z["mad_sse2"], z["mad"])
+
+
+def test_c1_stored_planes_match_generator():
+    z = G.load("hbma_C1-cif-1L.npz")
+    (_, p0), (_, p1) = G.config_pair(G.HBMA_CONFIGS[0])
+    assert np.array_equal(p0[0], z["tracked"]) and np.array_equal(p1[0], z["anchor"])
+
+
+@pytest.mark.parametrize("case", list(G.micro_cases()), ids=lambda c: c[0])
+def test_hbma_micro_semantics(oracle, case):
+    name, t, a, r, bw, bh, mv_ref, mad_ref = case
+    mv, mad = oracle.hbma(t, a, r, bw, bh)
+    assert np.array_equal(mv, mv_ref) and np.array_equal(mad, mad_ref), name
+
+
+def test_micro_fixtures_hit_their_semantics():
+    cases = {c[0]: c for c in G.micro_cases()}
+    _, _, _, _, _, _, mv, mad = cases["flat"]
+    assert not mv.any() and not mad.any()           # zero-reset on exact ties (motion.cpp:333-337)
+    _, _, _, _, _, _, mv, mad = cases["zero_reset_nonflat"]
+    assert not mv.any() and mad.all()               # ... and min_mad is kept, not reset
+    _, t, a, r, bw, bh, mv, mad = cases["carried"]
+    # level 0 is noise: no level-0 candidate beats the carried MAD, so every MV is even (2 x coarse)
+    assert np.all(mv % 2 == 0) and mad.max() < 64
+
+
+@pytest.mark.parametrize("case", list(G.ransac_cases()), ids=lambda c: c[0])
+def test_ransac_matches_reference(oracle, case):
+    name, mv, params, samples, gm_ref, rmse_ref, inl_ref = case
+    n = len(mv) - 1  # the fixture carries entry n, which the reference's [0, n] draw may read
+    assert oracle.ransac_iter_count(**params) * params["subset_sz"] == samples.size
+    gm, rmse, inl = oracle.ransac(mv, samples, gm_in=(0.25, -0.75), n=n, **params)
+    assert gm.tobytes() == gm_ref.tobytes() and rmse.tobytes() == rmse_ref.tobytes()
+    assert np.array_equal(inl, inl_ref)
+
+
+def test_ransac_fixture_contains_the_off_by_one():
+    """At least one golden case really drew index n (motion.cpp:208) -- the behaviour the
+    product deliberately does not reproduce (include/svc_hip.h)."""
+    assert any(int(c[3].max()) == len(c[1]) - 1 for c in G.ransac_cases())
+
+
+def test_dct_tiles(oracle):
+    z = G.load("dct_tiles.npz")
+    for key in sorted({k.split("/")[0] for k in z.files}):
+        tin, tout = z[f"{key}/in"], z[f"{key}/out"]
+        blk = tin.shape[1]
+        for i in range(len(tin)):
+            got = oracle.dct_frame_f64(np.ascontiguousarray(tin[i]), blk, blk)
+            assert np.abs(got - tout[i]).max() < 1e-10, (key, i)
+    for blk in (8, 16):  # known answers: DC of a constant tile, single-cosine rows/columns
+        out = z[f"known{blk}/out"]
+        assert abs(out[0, 0, 0, 0] - 255 * blk) < 1e-9 and np.abs(out[0, 0].ravel()[1:]).max() < 1e-9
+        assert abs(out[1, 0, 0, 0] - blk) < 1e-9
+        assert np.argmax(np.abs(out[2, 0, 0, 1:])) + 1 == 3 and np.abs(out[2, 0, 1:, :]).max() < 1e-9
+        assert np.argmax(np.abs(out[3, 0, 1:, 0])) + 1 == 2 and np.abs(out[3, 0, :, 1:]).max() < 1e-9
+
+
+def test_dct_inverse_roundtrip(oracle):
+    from scipy.fft import idctn
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    for blk in (8, 16):
+        y = oracle.dct_frame_f64(bgr, blk, blk)
+        for c in range(3):
+            for ty in range(0, 32, blk):
+                for tx in range(0, 32, blk):
+                    back = idctn(y[c, ty:ty + blk, tx:tx + blk], type=2, norm="ortho")
+                    assert np.abs(back - bgr[ty:ty + blk, tx:tx + blk, c]).max() < 1e-9
+
+
+def test_quant_hand_vectors(oracle):
+    z = G.load("quant.npz")
+    assert oracle.quant(z["step640/in"], 640).tobytes() == z["step640/out"].tobytes()
+    assert oracle.quant(z["step1/in"], 1).tobytes() == z["step1/out"].tobytes()
+    planes = np.full((3, 16, 32), 319.9, np.float32)
+    out = oracle.quant_frame(planes, 16, 16, np.array([0, 5], np.uint32), 1, 640)
+    assert (out[:, :, :16] == 0).all() and (out[:, :, 16:] == 320.0).all()  # bg step 640 / fg step 1

@@ -1,0 +1,57 @@
+"""Live comparison of the C restatement with the unmodified reference (oracle/_ref,
+built from /root/reference by oracle/Makefile).  Skipped where _ref was never built."""
+import numpy as np
+import pytest
+
+from oracle.binding import DEFAULT_RANSAC
+from tests import util
+
+
+@pytest.mark.parametrize("levels,r,bw,bh", [(1, 8, 16, 16), (2, 8, 16, 16), (3, 8, 16, 16), (4, 8, 16, 16),
+                                            (3, 5, 8, 8), (2, 7, 16, 8), (1, 3, 6, 10), (3, 12, 32, 16)])
+def test_hbma_random(oracle, reference, levels, r, bw, bh):
+    rng = np.random.default_rng(levels * 31 + r)
+    f = 1 << (levels - 1)
+    w, h = bw * 7 * f // f * f, bh * 5 * f // f * f
+    w, h = (w // (bw * f) + 1) * bw * f, (h // (bh * f) + 1) * bh * f
+    t, a = util.random_planes(rng, w, h, levels), util.random_planes(rng, w, h, levels)
+    mv_o, mad_o = oracle.hbma(t, a, r, bw, bh)
+    mv_r, mad_r = reference.hbma(t, a, r, bw, bh)
+    assert np.array_equal(mv_o, mv_r) and np.array_equal(mad_o, mad_r)
+
+
+def test_hbma_synthetic_clip_and_sse2(oracle, reference):
+    _, pyrs, _ = util.clip_frames(352, 288, 3, 77, 4)
+    for i in range(2):
+        t, a = util.np_pyr(pyrs[i]), util.np_pyr(pyrs[i + 1])
+        mv_r, mad_r = reference.hbma(t, a, 8, 16, 16)
+        mv_s, mad_s = reference.hbma16_sse2(t, a, 8)
+        mv_o, mad_o = oracle.hbma16_sse2(t, a, 8)
+        assert np.array_equal(mv_r, mv_s) and np.array_equal(mad_r, mad_s)  # SSE2 == generic L=4
+        assert np.array_equal(mv_o, mv_s) and np.array_equal(mad_o, mad_s)
+
+
+def test_ebma(oracle, reference):
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, 256, (64, 96), dtype=np.uint8)
+    a = np.roll(t, (1, -2), (0, 1))
+    for r, bw, bh in ((8, 16, 16), (2, 4, 4), (20, 8, 8)):
+        mv_o, mad_o = oracle.ebma(t, a, r, bw, bh)
+        mv_r, mad_r = reference.ebma(t, a, r, bw, bh)
+        assert np.array_equal(mv_o, mv_r) and np.array_equal(mad_o, mad_r)
+
+
+def test_ransac_lockstep(oracle, reference):
+    """Several calls in a row: the mirrored engine stays in step with the reference's static one."""
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        n = 500 + 37 * trial
+        mv = np.tile(np.array([[2.0, 1.0]], np.float32), (n + 1, 1))
+        mv[rng.choice(n, n // 4, replace=False)] += rng.integers(-12, 13, (n // 4, 2)).astype(np.float32)
+        p = dict(DEFAULT_RANSAC, subset_sz=1 + trial % 4)
+        k = oracle.ransac_iter_count(**p)
+        gm_r, rmse_r, inl_r = reference.ransac(mv, n, **p)
+        s = reference.ransac_draw(n, p["subset_sz"], k)
+        gm_o, rmse_o, inl_o = oracle.ransac(mv, s, n=n, **p)
+        assert gm_o.tobytes() == gm_r.tobytes() and rmse_o.tobytes() == rmse_r.tobytes()
+        assert np.array_equal(inl_o, inl_r)
