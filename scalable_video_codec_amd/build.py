@@ -83,9 +83,33 @@ def build_motion(force: bool = False) -> str:
     return LIB_MOTION
 
 
+DROPIN_SRC = os.path.join(ROOT, "tests", "dropin", "dropin_main.cpp")
+REFERENCE_LIBS = os.environ.get("SVC_REFERENCE_DIR", "/root/reference") + "/libs"
+
+
+def build_dropin(force: bool = False) -> List[str]:
+    """A caller written against the reference's motion.hpp only, linked to libsvc_motion.so:
+    once with the reference's OWN header (where /root/reference exists; the binary travels
+    to the GPU box), once with include/svc/motion.hpp."""
+    cxx = shutil.which("g++") or "g++"
+    out = []
+    variants = [("dropin_own_hdr", os.path.join(INCLUDE, "svc"), [])]
+    if os.path.exists(os.path.join(REFERENCE_LIBS, "motion.hpp")):
+        variants.append(("dropin_ref_hdr", REFERENCE_LIBS, []))
+        variants.append(("dropin_ref_hdr_sse2", REFERENCE_LIBS, ["-DDROPIN_USE_SSE2_ENTRY"]))
+    for name, inc, extra in variants:
+        exe = os.path.join(os.path.dirname(DROPIN_SRC), name)
+        if force or not _newer(exe, [DROPIN_SRC, LIB_MOTION]):
+            _run([cxx, "-std=c++17", "-O2", "-msse2", f"-I{inc}", *extra, "-o", exe, DROPIN_SRC, f"-L{PKG}",
+                  "-lsvc_motion", "-lsvc_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd"])
+        out.append(exe)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
     build_motion(force)
+    build_dropin(force)
 
 
 if __name__ == "__main__":
