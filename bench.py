@@ -110,11 +110,19 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # SVC_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (RCCL
+    # refuses two ranks on one device): ranks then share GPUs and the halo goes through gloo.
+    backend = os.environ.get("SVC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     native.load()
 
     cfg = configs.ALL[args.config]
@@ -146,8 +154,9 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    encoded = torch.tensor([enc.encoded_per_step], dtype=torch.float64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    encoded = torch.tensor([enc.encoded_per_step], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(encoded, op=dist.ReduceOp.SUM)
@@ -181,7 +190,7 @@ def main() -> None:
                 "encoded_frames_per_step": total_encoded,
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
-                "parallelism": f"frame-sharded x{world}" + (" + RCCL halo (1 pyramid/rank/step)" if world > 1 else ""),
+                "parallelism": f"frame-sharded x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} halo (1 pyramid/rank/step)" if world > 1 else ""),
             },
             "roofline": {
                 "kernel": "hbma_fused16_kernel (MAD search, all pyramid levels)",

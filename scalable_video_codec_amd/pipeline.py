@@ -70,13 +70,21 @@ def halo_exchange(pyr: torch.Tensor, stride: int, n_frames: int, rank: int, worl
     backend: RCCL ("nccl") on device buffers in the product, gloo on CPU in the tests."""
     if world <= 1:
         return
+    send_buf = pyr[n_frames * stride:(n_frames + 1) * stride]
+    recv_buf = pyr[:stride]
+    staged = pyr.is_cuda and dist.get_backend() == "gloo"  # rehearsal mode only: gloo moves host memory
+    if staged:
+        send_buf = send_buf.cpu()
+        recv_host = torch.empty(stride, dtype=torch.uint8)
     ops = []
     if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, pyr[n_frames * stride:(n_frames + 1) * stride], rank + 1))
+        ops.append(dist.P2POp(dist.isend, send_buf, rank + 1))
     if rank > 0:
-        ops.append(dist.P2POp(dist.irecv, pyr[:stride], rank - 1))
+        ops.append(dist.P2POp(dist.irecv, recv_host if staged else recv_buf, rank - 1))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+    if staged and rank > 0:
+        recv_buf.copy_(recv_host)
 
 
 class ClipEncoder:

@@ -1,18 +1,23 @@
 #!/bin/bash
 # Collects PMC counters for the bench's kernels, one counter group per pass
-# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE cannot share a pass).
-# usage: tools/pmc_passes.sh <outdir> [bench args...]
+# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE cannot share a pass; no trace domains
+# besides --kernel-trace next to --pmc).
+# usage: PMC_GROUPS="1 2 3" tools/pmc_passes.sh <outdir> [bench args...]
 set -u
 out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 -L > "$out/counters_available.txt" 2>&1
-i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" \
-           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" \
-           "SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE" \
-           "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr"; do
-  i=$((i+1))
+groups=(
+  "FETCH_SIZE"
+  "WRITE_SIZE"
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"
+  "SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+  "TCC_HIT_sum TCC_MISS_sum"
+)
+for i in ${PMC_GROUPS:-1 2 3 4 5}; do
+  grp=${groups[$((i-1))]}
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$out/pass$i.log" 2>&1
   echo "pass $i ($grp): exit $?"
 done
+python3 tools/summarize_pmc.py "$out" "$out/summary.csv"
+rm -rf "$out"/pass*/  # raw per-dispatch CSVs are large; the summary is what is kept
