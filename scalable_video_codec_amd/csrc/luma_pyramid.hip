@@ -69,7 +69,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // reflected byte loads (2 quads per row: noise).
 template <bool BORDER>
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
-  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  // consecutive output rows share 3 of their 5 source rows: keep them on one XCD's L2
+  const uint32_t q = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (q >= a.total) return;
   const uint32_t lanes_per_row = BORDER ? 2u : a.quads_per_row - 2u;
   const uint32_t per_frame = a.dh * lanes_per_row;
@@ -125,6 +126,100 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
   *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dw + dq * 4) = out;
 }
 
+// ---- luma + first pyramid level in one pass over the BGR frame -------------------------
+// A workgroup owns a 128 x 32 tile of the luma plane.  Its lanes compute Y for the tile plus
+// a 2-pixel halo (reflect-101 at the frame border, exactly what pyr_down_kernel does) into
+// LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
+// from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
+// whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
+constexpr int kTW = 128, kTH = 32, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
+
+struct LumaPyr1Args {
+  const uint8_t* bgr;
+  uint64_t frame_stride;
+  uint8_t* pyr;
+  uint64_t pyr_stride;
+  uint64_t l1_off;  // = w * h
+  uint32_t w, h;
+  uint32_t tiles_x, tiles_per_frame, total_tiles;
+};
+
+__device__ __forceinline__ uint32_t luma_of(uint32_t b, uint32_t g, uint32_t r) {
+  return (1868u * b + 9617u * g + 4899u * r + 8192u) >> 14;
+}
+
+__global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(kTH + 4) * kPitch];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (t >= a.total_tiles) return;
+  const uint32_t frame = t / a.tiles_per_frame, tr = t - frame * a.tiles_per_frame;
+  const uint32_t ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+  const int x0 = (int)tx * kTW, y0 = (int)ty * kTH;
+  const int w = (int)a.w, h = (int)a.h;
+  const int segs = min(kTW, w - x0) / 16;  // 16-pixel segments of this tile inside the frame
+  const int xe = x0 + segs * 16;           // first column right of the tile's valid part
+  const uint8_t* src = a.bgr + (size_t)frame * a.frame_stride;
+  uint8_t* y_plane = a.pyr + (size_t)frame * a.pyr_stride;
+
+  // (a) segment tasks: 16 pixels of one row -> 4 dwords of LDS (+ the level-0 store)
+  for (int task = (int)tid; task < (kTH + 4) * segs; task += 256) {
+    const int r = task / segs, sgm = task - r * segs;
+    const int y = y0 - 2 + r, yr = reflect101(y, h);
+    const int x = x0 + sgm * 16;
+    const uint4* p = reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3);
+    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int px = 0; px < 16; ++px) {
+      const int b0 = 3 * px, b1 = 3 * px + 1, b2 = 3 * px + 2;
+      const uint32_t yy = luma_of((wd[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu, (wd[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu,
+                                  (wd[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu);
+      out[px >> 2] |= yy << (8 * (px & 3));
+    }
+    const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;  // 16-byte aligned (Guideline 17)
+    if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
+  }
+  // (b) halo pixels: two columns on each side of the valid part, every row
+  for (int task = (int)tid; task < (kTH + 4) * 4; task += 256) {
+    const int r = task >> 2, k = task & 3;
+    const int yr = reflect101(y0 - 2 + r, h);
+    const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
+    const uint8_t* p = src + ((size_t)yr * w + reflect101(x, w)) * 3;
+    tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
+  }
+  __syncthreads();
+
+  // (c) level 1: lane = (output row, quad of 4 output columns)
+  const int oy = (int)tid >> 4, q = (int)tid & 15;
+  const int gx = (x0 >> 1) + 4 * q, gy = (y0 >> 1) + oy;  // level-1 coordinates
+  if (gx >= (w >> 1) || gy >= (h >> 1)) return;
+  const int taps[5] = {1, 4, 6, 4, 1};
+  uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r5 = 0; r5 < 5; ++r5) {
+    // centre of output column 4q + o is LDS column kOff + 8q + 2o; taps span kOff + 8q - 2 .. + 8
+    const uint8_t* rowp = &tile[(2 * oy + r5) * kPitch + kOff + 8 * q];
+    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
+    const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
+    const uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
+    const uint32_t px[11] = {(w0 >> 16) & 0xFF, w0 >> 24,
+                             mid.x & 0xFF, (mid.x >> 8) & 0xFF, (mid.x >> 16) & 0xFF, mid.x >> 24,
+                             mid.y & 0xFF, (mid.y >> 8) & 0xFF, (mid.y >> 16) & 0xFF, mid.y >> 24,
+                             w3 & 0xFF};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      acc[o] += (uint32_t)taps[r5] * (px[2 * o] + 4 * px[2 * o + 1] + 6 * px[2 * o + 2] + 4 * px[2 * o + 3] + px[2 * o + 4]);
+  }
+  uint32_t out = 0;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
+  *reinterpret_cast<uint32_t*>(y_plane + a.l1_off + (size_t)gy * (w >> 1) + gx) = out;
+}
+static_assert(kPitch % 16 == 0 && kOff % 16 == 0, "LDS rows keep 16-byte alignment for the ds_write_b128");
+
 int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                         uint32_t h, uint32_t levels, uint8_t* d_pyr, uint64_t pyr_stride,
                         hipStream_t stream) {
@@ -142,9 +237,29 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
   const uint64_t tg = (uint64_t)la.groups_per_frame * n_frames;
   if (tg > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many pixels for one launch");
   la.total_groups = (uint32_t)tg;
-  hipLaunchKernelGGL(luma_kernel, dim3(div_up(la.total_groups, 256)), dim3(256), 0, stream, la);
-  int rc = check_launch("luma_kernel");
-  if (rc) return rc;
+  int rc;
+  uint32_t first_plain_level = 0;
+  // level-1 width must be a multiple of 4 for the fused kernel's dword stores
+  if (levels >= 2 && (w / 2) % 4 == 0 && h % 2 == 0) {
+    LumaPyr1Args fa;
+    fa.bgr = d_bgr;
+    fa.frame_stride = frame_stride;
+    fa.pyr = d_pyr;
+    fa.pyr_stride = pyr_stride;
+    fa.l1_off = (uint64_t)w * h;
+    fa.w = w; fa.h = h;
+    fa.tiles_x = div_up(w, kTW);
+    fa.tiles_per_frame = fa.tiles_x * div_up(h, kTH);
+    const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
+    if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many tiles for one launch");
+    fa.total_tiles = (uint32_t)tt;
+    hipLaunchKernelGGL(luma_pyr1_kernel, dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+    if ((rc = check_launch("luma_pyr1_kernel"))) return rc;
+    first_plain_level = 1;
+  } else {
+    hipLaunchKernelGGL(luma_kernel, dim3(div_up(la.total_groups, 256)), dim3(256), 0, stream, la);
+    if ((rc = check_launch("luma_kernel"))) return rc;
+  }
 
   uint64_t off = 0;
   for (uint32_t l = 0; l + 1 < levels; ++l) {
@@ -157,6 +272,7 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     off += (uint64_t)pa.sw * pa.sh;
     pa.dst_off = off;
     pa.quads_per_row = pa.dw / 4;
+    if (l < first_plain_level) continue;  // produced by luma_pyr1_kernel
     if (pa.quads_per_row < 2) return fail(SVC_ERR_UNSUPPORTED, "pyramid: level %u is narrower than 16 pixels", l);
     const uint64_t tot = (uint64_t)n_frames * pa.dh * (pa.quads_per_row - 2);
     if (tot > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many pixels for one launch");

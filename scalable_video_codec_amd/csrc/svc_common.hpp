@@ -51,6 +51,15 @@ inline uint64_t pyramid_bytes(uint32_t w, uint32_t h, uint32_t levels) {
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so blocks b and
+// b + 8 share an L2 but b and b + 1 do not.  This bijective remap gives every XCD one
+// CONTIGUOUS range of logical work (rows that overlap stay in one L2).  Speed only: nothing
+// depends on the placement (cdna_hip_programming.md T1).
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
+  const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------
 
 int launch_hbma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,

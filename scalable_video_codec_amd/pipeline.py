@@ -121,6 +121,8 @@ class ClipEncoder:
         self.samples = ransac_samples(p, self.iters, self.ransac["subset_sz"], self.blocks,
                                       cfg.seed + 7919 * rank, device)
         self._ev: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
+        self._steps_timed = 0
+        self._side: Optional[torch.cuda.Stream] = None
 
     def load_frames(self, frames: List[torch.Tensor]) -> None:
         assert len(frames) == self.n
@@ -130,6 +132,7 @@ class ClipEncoder:
     # -- timing: HIP events on the stream the kernels are launched on ----------------
     def reset_kernel_timers(self) -> None:
         self._ev = {}
+        self._steps_timed = 0
 
     def _timed(self, name: str, timed: bool):
         enc = self
@@ -139,41 +142,87 @@ class ClipEncoder:
                 if timed:
                     self_inner.a = torch.cuda.Event(enable_timing=True)
                     self_inner.b = torch.cuda.Event(enable_timing=True)
-                    self_inner.a.record()
+                    self_inner.a.record(torch.cuda.current_stream())
 
             def __exit__(self_inner, *exc):
                 if timed:
-                    self_inner.b.record()
+                    self_inner.b.record(torch.cuda.current_stream())
                     enc._ev.setdefault(name, []).append((self_inner.a, self_inner.b))
         return _Ctx()
 
     def kernel_times_ms(self) -> Dict[str, float]:
-        """Average duration per launch (per step) of each stage, from the recorded events."""
+        """Per-step duration of each stage (summed over its launches when the step is chunked),
+        from HIP events recorded on the stream each stage is launched on."""
         torch.cuda.synchronize()
-        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self._ev.items()}
+        steps = max(1, self._steps_timed)
+        return {k: sum(a.elapsed_time(b) for a, b in v) / steps for k, v in self._ev.items()}
+
+    def launches_per_step(self) -> Dict[str, float]:
+        steps = max(1, self._steps_timed)
+        return {k: len(v) / steps for k, v in self._ev.items()}
 
     # -- one pass of the hot path -----------------------------------------------------
     def exchange_halo(self) -> None:
         """Ring-less neighbour shift: my last pyramid -> rank+1's halo slot (RCCL over xGMI)."""
         halo_exchange(self.pyr, self.stride, self.n, self.rank, self.world)
 
-    def step(self, timed: bool = False) -> None:
+    def step(self, timed: bool = False, chunks: int = 1) -> None:
+        """One pass over the clip.  chunks > 1 cuts the clip into consecutive chunks and runs
+        the transform of chunk k on a second HIP stream while the front (luma, pyramid, motion
+        search, RANSAC, block types) of chunk k + 1 runs on the first: the DCT+quant kernel is
+        HBM-bound, the motion search VALU-bound and RANSAC latency-bound, so they overlap.
+        The dependency DCT+quant(k) <- block types(k) is a HIP event."""
         c = self.cfg
-        with self._timed("luma_pyramid", timed):
-            native.luma_pyramid_frames(self.bgr, self.levels, out=self.pyr[self.stride:], stride=self.stride)
-        with self._timed("halo_exchange", timed and self.world > 1):
-            self.exchange_halo()
-        t0 = 0 if self.has_halo else 1
-        with self._timed("hbma", timed):
-            native.hbma_pairs(self.pyr[t0 * self.stride:], self.pyr[(t0 + 1) * self.stride:], self.stride,
-                              self.pairs_per_step, self.levels, self.pw, self.ph, c.search_range,
-                              c.mv_block, c.mv_block, out=(self.mv, self.mad))
-        with self._timed("ransac", timed):
-            native.ransac_frames(self.mv, self.samples, out=(self.gm, self.rmse, self.mask, self.count),
-                                 **self.ransac)
-        with self._timed("block_types", timed):
-            native.block_types_frames(self.mask, out=self.types)
-        if c.dct_block:
-            with self._timed("dct_quant", timed):
-                native.dct_quant_frames(self.bgr[self.first_encoded:], c.dct_block, self.types, c.mv_block,
-                                        c.fg_step, c.bg_step, out=self.coeffs)
+        chunks = max(1, min(chunks, self.pairs_per_step))
+        if chunks > 1 and self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        t0 = 0 if self.has_halo else 1        # slot of the first tracked pyramid
+        bounds = [self.pairs_per_step * i // chunks for i in range(chunks + 1)]
+        done_frames = 0                        # frames whose pyramid exists (own frames, 0-based)
+        for k in range(chunks):
+            p0, p1 = bounds[k], bounds[k + 1]  # pairs [p0, p1) of this step
+            # pair p uses slots t0 + p (tracked) and t0 + p + 1 (anchor); slot s > 0 is own frame s - 1
+            need = t0 + p1                     # own frames [0, need) must have pyramids
+            if need > done_frames:
+                with self._timed("luma_pyramid", timed):
+                    native.luma_pyramid_frames(self.bgr[done_frames:need], self.levels,
+                                               out=self.pyr[(done_frames + 1) * self.stride:], stride=self.stride)
+                done_frames = need
+            if k == 0:
+                if chunks > 1 and self.world > 1 and done_frames < self.n:
+                    # the halo payload is this rank's LAST pyramid: build it before the exchange
+                    with self._timed("luma_pyramid", timed):
+                        native.luma_pyramid_frames(self.bgr[self.n - 1:self.n], self.levels,
+                                                   out=self.pyr[self.n * self.stride:], stride=self.stride)
+                with self._timed("halo_exchange", timed and self.world > 1):
+                    self.exchange_halo()
+            np_ = p1 - p0
+            with self._timed("hbma", timed):
+                native.hbma_pairs(self.pyr[(t0 + p0) * self.stride:], self.pyr[(t0 + p0 + 1) * self.stride:],
+                                  self.stride, np_, self.levels, self.pw, self.ph, c.search_range,
+                                  c.mv_block, c.mv_block, out=(self.mv[p0:p1], self.mad[p0:p1]))
+            with self._timed("ransac", timed):
+                native.ransac_frames(self.mv[p0:p1], self.samples[p0:p1],
+                                     out=(self.gm[p0:p1], self.rmse[p0:p1], self.mask[p0:p1], self.count[p0:p1]),
+                                     **self.ransac)
+            with self._timed("block_types", timed):
+                native.block_types_frames(self.mask[p0:p1], out=self.types[p0:p1])
+            if not c.dct_block:
+                continue
+            f0 = self.first_encoded + p0       # encoded frame of pair p is own frame first_encoded + p
+            if chunks == 1:
+                with self._timed("dct_quant", timed):
+                    native.dct_quant_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
+                                            c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
+            else:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ready)
+                    with self._timed("dct_quant", timed):
+                        native.dct_quant_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
+                                                c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
+        if chunks > 1 and c.dct_block:
+            main.wait_stream(self._side)
+        self._steps_timed += 1 if timed else 0
