@@ -51,18 +51,29 @@ def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 20.0):
     t_hbma = t_rest = 0.0
     done = 0
     t_start = time.perf_counter()
+    # the reference's default build runs its SSE2 entry, which exists for 4 levels / 16x16 only
+    # (libs/motion.hpp:143-147, libs/encoder.cpp:472-476); other level counts run the generic path
+    use_sse2 = cfg.levels == 4 and cfg.mv_block == 16
+    if ref is not None:
+        search = (lambda t, a: ref.hbma16_sse2(t, a, cfg.search_range)) if use_sse2 else \
+                 (lambda t, a: ref.hbma(t, a, cfg.search_range, cfg.mv_block, cfg.mv_block))
+        search_name = "unmodified reference " + ("EstimateMotionHierarchical16x16Sse2" if use_sse2 else
+                                                "EstimateMotionHierarchical (generic path; the SSE2 path only exists for 4 levels)")
+    else:
+        search = (lambda t, a: orc.hbma16_sse2(t, a, cfg.search_range)) if use_sse2 else \
+                 (lambda t, a: orc.hbma(t, a, cfg.search_range, cfg.mv_block, cfg.mv_block))
+        search_name = "C restatement" + (" (SSE2 path)" if use_sse2 else "")
+    search(pyrs[0], pyrs[1])  # warm-up: page in, let the core clock up
     for i in range(1, n):
         t0 = time.perf_counter()
-        if ref is not None:
-            mv, _ = ref.hbma(pyrs[i - 1], pyrs[i], cfg.search_range, cfg.mv_block, cfg.mv_block)
-        else:
-            mv, _ = orc.hbma(pyrs[i - 1], pyrs[i], cfg.search_range, cfg.mv_block, cfg.mv_block)
+        mv, _ = search(pyrs[i - 1], pyrs[i])
         t1 = time.perf_counter()
         samples = (np.arange(k, dtype=np.uint32) * 2654435761 % len(mv)).astype(np.uint32)
         _, _, inl = orc.ransac(mv, samples, **binding.DEFAULT_RANSAC)
         types = (orc.fg_mask(inl, len(mv)) != 0).astype(np.uint32)
-        planes = orc.dct_frame_f32(host[i].numpy(), cfg.dct_block, cfg.dct_block)
-        orc.quant_frame(planes, cfg.mv_block, cfg.mv_block, types, cfg.fg_step, cfg.bg_step)
+        if cfg.dct_block:
+            planes = orc.dct_frame_f32(host[i].numpy(), cfg.dct_block, cfg.dct_block)
+            orc.quant_frame(planes, cfg.mv_block, cfg.mv_block, types, cfg.fg_step, cfg.bg_step)
         t2 = time.perf_counter()
         t_hbma += t1 - t0
         t_rest += t2 - t1
@@ -71,21 +82,20 @@ def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 20.0):
             break
     # the reference's own fast path (SSE2, fixed 4 levels) on the same frames, for context
     sse2_ms = None
-    if ref is not None and cfg.padded[0] % 8 == 0:
+    if ref is not None and not use_sse2 and cfg.mv_block == 16 and cfg.padded[0] % 8 == 0 and cfg.padded[1] % 8 == 0:
         p4 = [[p.numpy() for p in synth.build_pyramid(synth.bgr_to_y(f), 4)] for f in host[:2]]
-        if p4[0][0].shape[0] % 8 == 0 and p4[0][0].shape[1] % 8 == 0:
-            t0 = time.perf_counter()
-            for _ in range(3):
-                ref.hbma16_sse2(p4[0], p4[1], cfg.search_range)
-            sse2_ms = (time.perf_counter() - t0) / 3 * 1e3
+        ref.hbma16_sse2(p4[0], p4[1], cfg.search_range)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ref.hbma16_sse2(p4[0], p4[1], cfg.search_range)
+        sse2_ms = (time.perf_counter() - t0) / 3 * 1e3
     total = t_hbma + t_rest
     return {
         "value": done / total if total > 0 else None,
         "unit": "frames/s",
         "cores": 1,
         "kind": "reference" if ref is not None else "port",
-        "sample": (f"first {done} encoded frames of the same clip, 1 thread: motion search = "
-                   f"{'unmodified reference EstimateMotionHierarchical (generic path; its SSE2 path only exists for 4 levels)' if ref is not None else 'C restatement'}"
+        "sample": (f"first {done} encoded frames of the same clip, 1 thread: motion search = {search_name}"
                    f", RANSAC/DCT(f64 separable)/quant = C restatement (cv::dct is not buildable offline)"),
         "hbma_ms_per_frame": t_hbma / done * 1e3 if done else None,
         "ransac_dct_quant_ms_per_frame": t_rest / done * 1e3 if done else None,
@@ -126,6 +136,7 @@ def main() -> None:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     native.load()
+    torch.set_num_threads(min(8, torch.get_num_threads()))  # CPU share of a 1-GPU box is small
 
     cfg = configs.ALL[args.config]
     n_frames = args.frames or cfg.frames
@@ -170,7 +181,8 @@ def main() -> None:
         hbma_bytes = cfg.hbma_bytes_per_frame() * enc.pairs_per_step
         dct_bytes = cfg.dct_bytes_per_frame() * enc.encoded_per_step
         hbma_gbps = hbma_bytes / (kt["hbma"] * 1e-3) / 1e9
-        dct_gbps = dct_bytes / (kt["dct_quant"] * 1e-3) / 1e9
+        has_dct = "dct_quant" in kt
+        dct_gbps = dct_bytes / (kt["dct_quant"] * 1e-3) / 1e9 if has_dct else None
         nl = enc.launches_per_step()  # launches per step of each stage (= --chunks)
         pmc = pipeline.load_pmc_traffic()
 
@@ -179,7 +191,8 @@ def main() -> None:
             v = pmc.get(key)
             return v / nl[stage] if v is not None else None
         out = {
-            "metric": "encoded frames/sec (1080p, 16x16 HBMA+DCT)",
+            "metric": "encoded frames/sec (1080p, 16x16 HBMA+DCT)" if cfg.name.startswith("C3") else
+                      f"encoded frames/sec ({cfg.name})",
             "value": total_encoded * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -205,22 +218,26 @@ def main() -> None:
                 "kernel": "hbma_fused16_kernel (MAD search, all pyramid levels)",
                 "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": hbma_gbps / HBM_PEAK_GBPS,
-                "traffic": per_launch_traffic("hbma_bytes_per_launch", "hbma"),
+                "traffic": per_launch_traffic("hbma_bytes_per_launch", "hbma") if cfg.name.startswith("C3-") else None,
                 "algorithmic_bytes_per_launch": hbma_bytes / nl["hbma"],
                 "avg_launch_ms": kt["hbma"] / nl["hbma"],
                 "launches_per_step": nl["hbma"],
             },
             "roofline_dct": {
-                "kernel": "dct_kernel<8, quant> (the step's longest kernel)",
+                "kernel": f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)",
                 "bound": "hbm", "achieved": dct_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": dct_gbps / HBM_PEAK_GBPS,
-                "traffic": per_launch_traffic("dct_bytes_per_launch", "dct_quant"),
+                "traffic": per_launch_traffic("dct_bytes_per_launch", "dct_quant") if cfg.name.startswith("C3-") else None,
                 "algorithmic_bytes_per_launch": dct_bytes / nl["dct_quant"],
                 "avg_launch_ms": kt["dct_quant"] / nl["dct_quant"],
                 "launches_per_step": nl["dct_quant"],
-            },
+            } if has_dct else None,
             "kernel_ms_per_step": kt,
         }
+        if not has_dct:
+            out.pop("roofline_dct")
+        if "hbma_wave" in (enc.hbma_kernel_name or ""):
+            out["roofline"]["kernel"] = "hbma_wave_level_kernel (LDS-staged wave-per-block search)"
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, frames)
             if out["cpu_baseline"]["value"]:

@@ -56,71 +56,103 @@ __device__ __forceinline__ void serial_sum2(const float2* st, uint32_t n, float&
 }
 
 __device__ __forceinline__ void serial_sum1(const float* st, uint32_t n, float& acc) {
+  // One lane, strictly in index order.  The next 32 values are fetched from LDS while the
+  // current 32 are being added, so the chain runs at the dependent-add rate, not at LDS latency.
   uint32_t i = 0;
-  for (; i + 8 <= n; i += 8) {
-    const float4 a = *reinterpret_cast<const float4*>(st + i);
-    const float4 b = *reinterpret_cast<const float4*>(st + i + 4);
-    acc += a.x; acc += a.y; acc += a.z; acc += a.w;
-    acc += b.x; acc += b.y; acc += b.z; acc += b.w;
+  if (n >= 32) {
+    float4 cur[8], nxt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = *reinterpret_cast<const float4*>(st + 4 * k);
+    for (; i + 64 <= n; i += 32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) nxt[k] = *reinterpret_cast<const float4*>(st + i + 32 + 4 * k);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { acc += cur[k].x; acc += cur[k].y; acc += cur[k].z; acc += cur[k].w; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { acc += cur[k].x; acc += cur[k].y; acc += cur[k].z; acc += cur[k].w; }
+    i += 32;
   }
   for (; i < n; ++i) acc += st[i];
 }
 
+constexpr uint32_t kModelsPerPass = 8;  // iteration models scored per pass over the field
+
+// block-wide sum of one counter per thread; result valid in every thread
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red, uint32_t tid) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();  // s_red may still be read from the previous reduction
+  if ((tid & 63) == 0) s_red[tid >> 6] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
 __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
   __shared__ __attribute__((aligned(16))) float2 s_stage[kChunk];
-  __shared__ float s_gm[2];
-  __shared__ uint32_t s_cnt[4];
+  __shared__ float s_model[kModelsPerPass][2];
+  __shared__ uint32_t s_red[4];
   __shared__ int s_isum[2];
-  __shared__ uint32_t s_flag;
+  __shared__ uint32_t s_flag, s_mag;
+  __shared__ float s_gm[2];
   const uint32_t tid = threadIdx.x, frame = blockIdx.x;
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * a.blocks;
   const uint32_t* samples = a.samples + (size_t)frame * a.iters * a.subset;
   uint8_t* mask = a.mask + (size_t)frame * a.blocks;
   const float t2 = a.thresh * a.thresh;
 
+  // ---- iterations (motion.cpp:210-238), kModelsPerPass at a time: the models of a group
+  // are built by separate lanes, then ONE pass over the field counts the inliers of all.
   uint32_t best_n = 0, best_it = 0;
   float bgx = 0.f, bgy = 0.f;
-  for (uint32_t it = 0; it < a.iters; ++it) {
-    if (tid == 0) {
-      float sx = 0.f, sy = 0.f;
+  for (uint32_t it0 = 0; it0 < a.iters; it0 += kModelsPerPass) {
+    const uint32_t nm = min(kModelsPerPass, a.iters - it0);
+    if (tid < nm) {
+      float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 m = mv[samples[(size_t)it * a.subset + i]];
+        const float2 m = mv[samples[(size_t)(it0 + tid) * a.subset + i]];
         sx = sx + m.x;
         sy = sy + m.y;
       }
       const float inv = 1.0f / (float)a.subset;
-      s_gm[0] = sx * inv;
-      s_gm[1] = sy * inv;
+      s_model[tid][0] = sx * inv;
+      s_model[tid][1] = sy * inv;
     }
     __syncthreads();
-    const float gx = s_gm[0], gy = s_gm[1];
-    uint32_t n = 0;
+    float gx[kModelsPerPass], gy[kModelsPerPass];
+    uint32_t cnt[kModelsPerPass];
+#pragma unroll
+    for (uint32_t k = 0; k < kModelsPerPass; ++k) {
+      gx[k] = s_model[k < nm ? k : 0][0];
+      gy[k] = s_model[k < nm ? k : 0][1];
+      cnt[k] = 0;
+    }
     for (uint32_t i = tid; i < a.blocks; i += 256) {
       const float2 m = mv[i];
-      n += is_inlier(gx, gy, m.x, m.y, t2) ? 1u : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < kModelsPerPass; ++k) cnt[k] += is_inlier(gx[k], gy[k], m.x, m.y, t2) ? 1u : 0u;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
-    if ((tid & 63) == 0) s_cnt[tid >> 6] = n;
-    __syncthreads();
-    const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (total >= best_n) {  // motion.cpp:233
-      best_n = total;
-      best_it = it;
-      bgx = gx;
-      bgy = gy;
+    for (uint32_t k = 0; k < kModelsPerPass; ++k) {
+      const uint32_t total = block_sum(cnt[k], s_red, tid);
+      if (k < nm && total >= best_n) {  // motion.cpp:233, in iteration order: ties -> later
+        best_n = total;
+        best_it = it0 + k;
+        bgx = gx[k];
+        bgy = gy[k];
+      }
     }
-    __syncthreads();  // s_gm / s_cnt are rewritten next iteration
+    __syncthreads();  // s_model is rewritten by the next group
   }
   const bool any_iter = a.iters > 0;
 
-  // mask of the winning model's inliers (== best_inliers, motion.cpp:236 / :244-253)
-  for (uint32_t i = tid; i < a.blocks; i += 256) {
-    const float2 m = mv[i];
-    mask[i] = (any_iter && is_inlier(bgx, bgy, m.x, m.y, t2)) ? 1 : 0;
-  }
-
   if (best_n < a.subset) {
+    for (uint32_t i = tid; i < a.blocks; i += 256) {
+      const float2 m = mv[i];
+      mask[i] = (any_iter && is_inlier(bgx, bgy, m.x, m.y, t2)) ? 1 : 0;
+    }
     // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
     if (tid == 0) {
       const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
@@ -138,12 +170,13 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
     return;
   }
 
-  // ---- final model = mean of the inliers (motion.cpp:255-256) -------------------
-  // Fast path: when every MV component is an integer and the sum of magnitudes stays
+  // ---- inlier mask (== best_inliers, motion.cpp:244-253) and, in the same pass, the
+  // final model = mean of the inliers (motion.cpp:255-256).
+  // Fast path: when every inlier MV component is an integer and the sum of magnitudes stays
   // below 2^24 (always true for block-matching output), every partial sum of the
   // reference's sequential f32 accumulation is exactly representable, so an integer
   // reduction in any order gives the identical float.  Otherwise: the serial walk.
-  if (tid == 0) { s_flag = 1u; s_isum[0] = 0; s_isum[1] = 0; s_cnt[0] = 0; }
+  if (tid == 0) { s_flag = 1u; s_isum[0] = 0; s_isum[1] = 0; s_mag = 0; }
   __syncthreads();
   {
     bool ok = true;
@@ -151,20 +184,22 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
     uint32_t mag = 0;
     for (uint32_t i = tid; i < a.blocks; i += 256) {
       const float2 m = mv[i];
-      if (!is_inlier(bgx, bgy, m.x, m.y, t2)) continue;
+      const bool in = is_inlier(bgx, bgy, m.x, m.y, t2);
+      mask[i] = in ? 1 : 0;
+      if (!in) continue;
       ok = ok && m.x == truncf(m.x) && m.y == truncf(m.y) && fabsf(m.x) <= 32768.f && fabsf(m.y) <= 32768.f;
       if (ok) {
         ix += (int)m.x; iy += (int)m.y;
         mag += (uint32_t)fabsf(m.x) + (uint32_t)fabsf(m.y);
       }
     }
-    if (!ok || mag >= (1u << 24)) s_flag = 0u;  // 256 addends below 2^24 cannot wrap s_cnt
+    if (!ok || mag >= (1u << 24)) s_flag = 0u;  // 256 addends below 2^24 cannot wrap s_mag
     atomicAdd(&s_isum[0], ix);
     atomicAdd(&s_isum[1], iy);
-    atomicAdd(&s_cnt[0], mag & 0xFFFFFFu);
+    atomicAdd(&s_mag, mag & 0xFFFFFFu);
   }
   __syncthreads();
-  const bool exact_int = s_flag != 0u && s_cnt[0] < (1u << 24);
+  const bool exact_int = s_flag != 0u && s_mag < (1u << 24);
   float sx = 0.f, sy = 0.f;
   if (exact_int) {
     sx = (float)s_isum[0];
