@@ -6,7 +6,8 @@ blocks, 3-level HBMA + RANSAC + 8x8 DCT + quant (fg 1 / bg 640).
 One "step" = one pass of the hot path over the whole clip resident in HBM:
   luma + pyramid (all frames) -> [N>1: halo exchange of the previous rank's last
   pyramid, RCCL send/recv] -> fused HBMA (all frame pairs) -> RANSAC (per frame) ->
-  inlier mask -> block types -> fused DCT + quant (per encoded frame).
+  segmentation (mask, close/open, k-means, connected components -> region ids) ->
+  fused DCT + quant (per encoded frame).
 `value` = encoded frames of all ranks / max-over-ranks time, BGR frames already
 resident in HBM when the timed region starts (PCIe excluded).
 
@@ -70,7 +71,10 @@ def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 20.0):
         t1 = time.perf_counter()
         samples = (np.arange(k, dtype=np.uint32) * 2654435761 % len(mv)).astype(np.uint32)
         _, _, inl = orc.ransac(mv, samples, **binding.DEFAULT_RANSAC)
-        types = (orc.fg_mask(inl, len(mv)) != 0).astype(np.uint32)
+        inl_mask = np.zeros(len(mv), np.uint8)
+        inl_mask[inl] = 1
+        mfw, mfh = cfg.mv_field
+        types = orc.segment(inl_mask, mv, mfw, mfh, cfg.mv_block, cfg.mv_block, seed=i)
         if cfg.dct_block:
             planes = orc.dct_frame_f32(host[i].numpy(), cfg.dct_block, cfg.dct_block)
             orc.quant_frame(planes, cfg.mv_block, cfg.mv_block, types, cfg.fg_step, cfg.bg_step)
@@ -96,7 +100,7 @@ def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 20.0):
         "cores": 1,
         "kind": "reference" if ref is not None else "port",
         "sample": (f"first {done} encoded frames of the same clip, 1 thread: motion search = {search_name}"
-                   f", RANSAC/DCT(f64 separable)/quant = C restatement (cv::dct is not buildable offline)"),
+                   f", RANSAC/segmentation/DCT(f64 separable)/quant = C restatement (cv::dct is not buildable offline)"),
         "hbma_ms_per_frame": t_hbma / done * 1e3 if done else None,
         "ransac_dct_quant_ms_per_frame": t_rest / done * 1e3 if done else None,
         "reference_sse2_4level_hbma_ms_per_frame": sse2_ms,
@@ -112,6 +116,8 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=0, help="override the clip length (0 = the config's)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="cut the clip into this many chunks; the transform of chunk k overlaps the front of chunk k+1 on a second stream")
+    ap.add_argument("--no-segmentation", action="store_true",
+                    help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -146,7 +152,7 @@ def main() -> None:
     clip = synth.SynthClip(cfg.width, cfg.height, world * n_frames, cfg.seed, device=dev)
     pw, ph = cfg.padded
     frames = [synth.pad_frame(clip.frame_bgr(rank * n_frames + t), pw, ph) for t in range(n_frames)]
-    enc = pipeline.ClipEncoder(cfg, n_frames, dev, rank=rank, world=world)
+    enc = pipeline.ClipEncoder(cfg, n_frames, dev, rank=rank, world=world, segmentation=not args.no_segmentation)
     enc.load_frames(frames)
     del clip
     torch.cuda.synchronize()

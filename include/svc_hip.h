@@ -50,6 +50,19 @@ typedef struct svc_ransac_params {
   float inlier_ratio;
 } svc_ransac_params;
 
+/* The segmentation knobs of EncoderConfig / KMeansParams (libs/encoder.hpp:17-36);
+ * defaults in apps/encoder.cpp:47-56: 3x3 rect, 10 clusters, 3 attempts, 10 iterations,
+ * epsilon 1, 4-connectivity. */
+typedef struct svc_segment_params {
+  uint32_t morph_rect_w;
+  uint32_t morph_rect_h;
+  uint32_t cluster_count;
+  uint32_t attempt_count;
+  uint32_t max_iter_count;
+  float epsilon;
+  uint32_t connectivity; /* 4 or 8 */
+} svc_segment_params;
+
 /* flags for svc_hip_hbma_pairs / svc_hip_hbma_host */
 #define SVC_HBMA_AUTO 0u
 #define SVC_HBMA_FORCE_WAVE_PER_BLOCK 1u /* per-level LDS-staged kernel (any shape) */
@@ -113,6 +126,22 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
 int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks,
                                uint32_t n_frames, uint32_t* d_block_types,
                                void* stream);
+
+/* The whole segmentation glue of libs/encoder.cpp:507-623: foreground mask, morphological
+ * close + open, k-means on (0, mv.x, x_px, y_px), per-cluster connected components, region
+ * ids numbered as the reference numbers them (0 = background).  The in-repo steps are the
+ * reference's; the OpenCV steps follow this repo's deterministic definitions (DESIGN.md
+ * section 4.6; parity with OpenCV 3.4's kmeans RNG cannot be pinned offline).  Frame f uses
+ * seed + f.  d_workspace: svc_hip_segment_workspace_bytes() bytes of scratch. */
+uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h,
+                                         uint32_t n_frames);
+
+int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy,
+                           uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames,
+                           uint32_t mv_block_w, uint32_t mv_block_h,
+                           svc_segment_params params, uint64_t seed,
+                           uint8_t* d_workspace, uint64_t workspace_bytes,
+                           uint32_t* d_block_types, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Transform.  d_bgr: n_frames frames of H x W x 3 u8, interleaved B,G,R (the

@@ -68,6 +68,8 @@ class Oracle:
                                         _f32p, _f32p, _u32p, _u32p]
         L.svc_oracle_fg_mask.restype = None
         L.svc_oracle_fg_mask.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_segment.restype = C.c_int
+        L.svc_oracle_segment.argtypes = [_u8p, _f32p] + [C.c_uint32] * 9 + [C.c_float, C.c_uint32, C.c_uint64, _u32p]
         L.svc_oracle_quant.restype = None
         L.svc_oracle_quant.argtypes = [_f32p, C.c_uint64, C.c_uint32]
         L.svc_oracle_quant_frame.restype = None
@@ -143,6 +145,19 @@ class Oracle:
         mask = np.empty(n, np.uint8)
         self.lib.svc_oracle_fg_mask(_ptr(inliers, _u32p), inliers.size, n, _ptr(mask, _u8p))
         return mask
+
+    def segment(self, inlier_mask, mv, mfw, mfh, mv_bw=16, mv_bh=16, morph_w=3, morph_h=3, cluster_count=10,
+                attempts=3, max_iter=10, epsilon=1.0, connectivity=4, seed=0):
+        """Region ids per MV block (defaults: apps/encoder.cpp:47-56)."""
+        m = np.ascontiguousarray(inlier_mask, np.uint8)
+        v = np.ascontiguousarray(mv, np.float32)
+        out = np.empty(mfw * mfh, np.uint32)
+        rc = self.lib.svc_oracle_segment(_ptr(m, _u8p), _ptr(v, _f32p), mfw, mfh, mv_bw, mv_bh, morph_w, morph_h,
+                                         cluster_count, attempts, max_iter, epsilon, connectivity, seed,
+                                         _ptr(out, _u32p))
+        if rc:
+            raise ValueError("svc_oracle_segment: invalid parameter")
+        return out
 
     # -- quant / DCT --
     def quant(self, coeffs, step):

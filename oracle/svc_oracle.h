@@ -97,6 +97,16 @@ void svc_oracle_ransac(const svc_oracle_vec2f* motion_field, uint32_t n,
 void svc_oracle_fg_mask(const uint32_t* inliers, uint32_t inlier_count,
                         uint32_t n, uint8_t* mask);
 
+/* libs/encoder.cpp:507-623: RANSAC inliers + motion field -> region id per MV block
+ * (0 = background).  In-repo steps restated exactly; the OpenCV steps (morphology,
+ * k-means, connected components) follow this repo's deterministic definitions --
+ * see oracle/svc_segment.c.  inlier_mask[i] != 0 marks a RANSAC inlier. */
+int svc_oracle_segment(const uint8_t* inlier_mask, const svc_oracle_vec2f* mv,
+                       uint32_t mfw, uint32_t mfh, uint32_t mv_bw, uint32_t mv_bh,
+                       uint32_t morph_w, uint32_t morph_h, uint32_t cluster_count,
+                       uint32_t attempts, uint32_t max_iter, float epsilon,
+                       uint32_t connectivity, uint64_t seed, uint32_t* block_types);
+
 /* libs/decoder.cpp:130-144 (quant lines of DecodeBlock), one coefficient run. */
 void svc_oracle_quant(float* coeffs, uint64_t n, uint32_t step);
 

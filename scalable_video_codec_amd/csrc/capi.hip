@@ -157,6 +157,32 @@ int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks, ui
                             static_cast<hipStream_t>(stream));
 }
 
+uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames) {
+  return segment_workspace_per_frame(mv_field_w * mv_field_h) * n_frames;
+}
+
+int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, uint32_t mv_field_w,
+                           uint32_t mv_field_h, uint32_t n_frames, uint32_t mv_block_w, uint32_t mv_block_h,
+                           svc_segment_params params, uint64_t seed, uint8_t* d_workspace,
+                           uint64_t workspace_bytes, uint32_t* d_block_types, void* stream) {
+  SVC_REQUIRE(d_inlier_mask && d_mv_xy && d_block_types && d_workspace, "segment: null pointer");
+  SVC_REQUIRE(mv_field_w > 0 && mv_field_h > 0 && mv_block_w > 0 && mv_block_h > 0, "segment: empty motion field");
+  // libs/encoder.cpp:39-61 (Validate(KMeansParams)), :92-97 (connectivity)
+  SVC_REQUIRE(params.cluster_count > 0, "segment: invalid cluster count: must be > 0");
+  SVC_REQUIRE(params.attempt_count > 0, "segment: invalid attempt count: must be > 0");
+  SVC_REQUIRE(params.max_iter_count > 0, "segment: invalid maximum iteration count: must be > 0");
+  SVC_REQUIRE(params.epsilon > 0, "segment: invalid epsilon: must be > 0");
+  SVC_REQUIRE(params.connectivity == 4 || params.connectivity == 8,
+              "segment: invalid connected components connectivity: must be either 4 or 8");
+  SVC_REQUIRE(params.morph_rect_w > 0 && params.morph_rect_h > 0, "segment: morphology rectangle must be positive");
+  SVC_REQUIRE(workspace_bytes >= svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames),
+              "segment: workspace of %llu B is smaller than the %llu B needed", (unsigned long long)workspace_bytes,
+              (unsigned long long)svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames));
+  SVC_REQUIRE(aligned(d_workspace, 16) && aligned(d_mv_xy, 8), "segment: workspace must be 16-byte, motion field 8-byte aligned");
+  return launch_segment(d_inlier_mask, d_mv_xy, mv_field_w, mv_field_h, n_frames, mv_block_w, mv_block_h, params,
+                        seed, d_workspace, d_block_types, static_cast<hipStream_t>(stream));
+}
+
 static int validate_dct(const void* in, const void* out, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh) {
   SVC_REQUIRE(in && out, "dct: null pointer");
   SVC_REQUIRE(bw > 0 && bh > 0, "dct: block must be positive (encoder.cpp:325-326)");

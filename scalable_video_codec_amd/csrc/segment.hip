@@ -1,0 +1,427 @@
+// segment.hip -- RANSAC inliers + motion field -> region id per MV block, batched:
+// one wavefront per frame.  Reference: libs/encoder.cpp:507-623.
+//
+// The in-repo steps are the reference's (foreground = complement of the inliers :507-513,
+// raster-order foreground list :538-546, BuildMvFeatures' (0, mv.x, x_px, y_px) with its
+// mv.y overwrite :316-319, cluster_count = min(K, #foreground) :555, per-cluster
+// connected components numbered with `offset += count including label 0` :597-623).
+// The OpenCV steps (morphologyEx close/open, kmeans, connectedComponents) cannot be pinned
+// offline; they follow this repo's deterministic definitions, stated in
+// oracle/svc_segment.c, which this kernel reproduces bit for bit.  Everything that could
+// depend on a summation order is exact integer arithmetic (k-means++ weights, centre sums,
+// fixed-point compactness), so the parallel reductions here are order-free; the remaining
+// floating point is per-element f64 in a fixed operation order (FP contraction is off).
+//
+// The field is small (8 160 blocks at 1080p): the byte masks and the union-find parents of a
+// frame sit in LDS when they fit (7 B per block), the point lists in a caller-provided global
+// workspace (L2-resident); phases are separated by workgroup barriers; frames run on
+// separate CUs.  Connected components are a lock-free union-find (one merge sweep + one
+// flatten sweep), not iterative label propagation.
+#include "svc_common.hpp"
+
+namespace svc {
+
+struct SegArgs {
+  const uint8_t* mask;  // [frames][n], 1 = RANSAC inlier
+  const float* mv;      // [frames][n][2]
+  uint32_t* types;      // [frames][n]
+  uint8_t* ws;
+  uint64_t ws_stride;
+  uint64_t seed;
+  double eps2;
+  uint32_t mfw, mfh, n, mv_bw, mv_bh;
+  uint32_t morph_w, morph_h, k, attempts, max_iter, conn;
+};
+
+constexpr uint32_t kMaxK = 64;
+// Lanes per frame are a template parameter T: 256 when the per-block arrays fit in LDS (measured at
+// 1080p: 64 lanes 0.86 ms, 256 lanes 0.39 ms per 64 frames -- the field-sized sweeps need the
+// lanes), 1024 when they live in global memory (4K), where sweep throughput is what counts.
+
+__device__ __forceinline__ uint64_t seg_hash(uint64_t x) {  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+struct Pt { int f[3]; };
+
+__device__ __forceinline__ Pt make_pt(const float2* mv, uint32_t b, uint32_t mfw, uint32_t bw, uint32_t bh) {
+  Pt p;
+  const float mx = mv[b].x;
+  p.f[0] = (int)(mx < 0 ? mx - 0.5f : mx + 0.5f);
+  p.f[1] = (int)((b % mfw) * bw);
+  p.f[2] = (int)((b / mfw) * bh);
+  return p;
+}
+
+__device__ __forceinline__ uint64_t dist2_int(const Pt& a, const int* c) {
+  uint64_t s = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int64_t t = (int64_t)a.f[d] - c[d];
+    s += (uint64_t)(t * t);
+  }
+  return s;
+}
+
+__device__ __forceinline__ double dist2_dbl(const Pt& p, const double* c) {
+  const double dx = (double)p.f[0] - c[0], dy = (double)p.f[1] - c[1], dz = (double)p.f[2] - c[2];
+  double s = dx * dx;
+  s = s + dy * dy;
+  s = s + dz * dz;
+  return s;
+}
+
+// exclusive block scan of one u64 per thread (wave scan by shuffles + 4 wave totals in LDS:
+// two barriers); returns this thread's prefix, *total = sum over the block
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int off) {
+  const uint32_t lo = __shfl_up((uint32_t)v, off, 64), hi = __shfl_up((uint32_t)(v >> 32), off, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <uint32_t T>
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* s_scan, uint32_t tid, uint64_t* total) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint64_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t y = shfl_up_u64(x, off);
+    if (lane >= (uint32_t)off) x += y;
+  }
+  __syncthreads();  // s_scan may still be read from the previous scan
+  if (lane == 63) s_scan[wave] = x;
+  __syncthreads();
+  uint64_t woff = 0, tot = 0;
+#pragma unroll
+  for (uint32_t wv = 0; wv < T / 64; ++wv) {
+    const uint64_t t = s_scan[wv];
+    woff += wv < wave ? t : 0;
+    tot += t;
+  }
+  *total = tot;
+  return woff + x - v;
+}
+
+// Lock-free union-find on `parent` (LDS or global): a set's root is its smallest block index
+// (= its first block in raster order); links always go from the larger root to the smaller
+// with atomicMin, so concurrent unions commute.
+__device__ __forceinline__ uint32_t uf_find(const uint32_t* parent, uint32_t x) {
+  uint32_t p = parent[x];
+  while (p != x) { x = p; p = parent[x]; }
+  return x;
+}
+
+__device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const uint32_t t = a; a = b; b = t; }
+    const uint32_t old = atomicMin(&parent[a], b);
+    if (old == a) return;  // a was still a root and now points at b
+    a = old;               // someone linked a first: carry on from where it points
+  }
+}
+
+template <uint32_t T>
+__device__ __forceinline__ void morph_pass(const uint8_t* src, uint8_t* dst, const SegArgs& a, bool dilate,
+                                           uint32_t tid) {
+  const int ax = (int)a.morph_w / 2, ay = (int)a.morph_h / 2;
+  if (a.morph_w == 3 && a.morph_h == 3) {  // the default element: branch-free, loads in flight together
+    const int W = (int)a.mfw, H = (int)a.mfh;
+    const int pad = dilate ? 0 : 255;
+    for (uint32_t i = tid; i < a.n; i += T) {
+      const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
+      int v = pad;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int sx = x + dx, sy = y + dy;
+          const bool in = sx >= 0 && sy >= 0 && sx < W && sy < H;
+          const int p = src[in ? sy * W + sx : (int)i];
+          const int q = in ? p : pad;
+          v = dilate ? max(v, q) : min(v, q);
+        }
+      dst[i] = (uint8_t)v;
+    }
+    __syncthreads();
+    return;
+  }
+  for (uint32_t i = tid; i < a.n; i += T) {
+    const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
+    int v = dilate ? 0 : 255;
+    for (int ky = 0; ky < (int)a.morph_h; ++ky)
+      for (int kx = 0; kx < (int)a.morph_w; ++kx) {
+        const int sx = x + kx - ax, sy = y + ky - ay;
+        if (sx < 0 || sy < 0 || sx >= (int)a.mfw || sy >= (int)a.mfh) continue;
+        const int p = src[sy * (int)a.mfw + sx];
+        v = dilate ? max(v, p) : min(v, p);
+      }
+    dst[i] = (uint8_t)v;
+  }
+  __syncthreads();
+}
+
+// LDS_ARRAYS: the per-block byte masks and the union-find parents live in dynamic LDS
+// (7 bytes per MV block: 57 KB at 1080p); otherwise in the global workspace.
+template <bool LDS_ARRAYS, uint32_t T>
+__global__ __launch_bounds__(T) void segment_kernel(SegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+  __shared__ uint64_t s_scan[T / 64];
+  __shared__ int s_cint[kMaxK][3];
+  __shared__ double s_c[kMaxK][3];
+  __shared__ unsigned long long s_sum[kMaxK][3];
+  __shared__ uint32_t s_cnt[kMaxK];
+  __shared__ double s_shift[kMaxK];
+  __shared__ unsigned long long s_compact;
+  __shared__ uint32_t s_pick, s_changed;
+
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, n = a.n;
+  const uint8_t* mask = a.mask + (size_t)frame * n;
+  const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
+  uint32_t* types = a.types + (size_t)frame * n;
+  uint8_t* w = a.ws + (size_t)frame * a.ws_stride;
+  uint8_t* lab = w + 2 * (size_t)n;
+  uint8_t* best_lab = w + 3 * (size_t)n;
+  uint32_t* idx = reinterpret_cast<uint32_t*>(w + ((5 * (size_t)n + 15) & ~(size_t)15));
+  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+  uint8_t* fg = LDS_ARRAYS ? dyn_lds + 4 * n4 : w;
+  uint8_t* tmp = LDS_ARRAYS ? dyn_lds + 5 * n4 : w + n;
+  uint8_t* cl = LDS_ARRAYS ? dyn_lds + 6 * n4 : w + 4 * (size_t)n;
+  uint32_t* label = LDS_ARRAYS ? reinterpret_cast<uint32_t*>(dyn_lds) : idx + n;  // union-find parents
+  Pt* pts_global = reinterpret_cast<Pt*>(idx + 2 * (size_t)n);
+  const uint64_t seed = a.seed + frame;
+
+  // ---- foreground mask, close, open (encoder.cpp:507-527) ---------------------------------
+  for (uint32_t i = tid; i < n; i += T) {
+    fg[i] = mask[i] ? 0 : 255;
+    types[i] = 0;  // :549-551
+  }
+  __syncthreads();
+  morph_pass<T>(fg, tmp, a, true, tid);
+  morph_pass<T>(tmp, fg, a, false, tid);
+  morph_pass<T>(fg, tmp, a, false, tid);
+  morph_pass<T>(tmp, fg, a, true, tid);
+
+  // ---- foreground list in raster order (:538-546) -----------------------------------------
+  const uint32_t per = (n + T - 1) / T;
+  const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
+  uint32_t local = 0;
+  for (uint32_t i = c0; i < c1; ++i) local += fg[i] == 255 ? 1u : 0u;
+  uint64_t tot64;
+  uint32_t pos = (uint32_t)block_excl_scan<T>(local, s_scan, tid, &tot64);
+  const uint32_t nf = (uint32_t)tot64;
+  for (uint32_t i = c0; i < c1; ++i)
+    if (fg[i] == 255) idx[pos++] = i;
+  __syncthreads();
+  if (nf == 0) return;
+  const uint32_t k = min(a.k, nf);  // :555
+
+  // feature points (:300-321) computed once; during k-means they borrow the LDS space of the
+  // union-find parents (not needed before the connected-components step) when they fit
+  Pt* pts = (LDS_ARRAYS && (size_t)nf * sizeof(Pt) <= 4 * n4) ? reinterpret_cast<Pt*>(dyn_lds) : pts_global;
+  for (uint32_t i = tid; i < nf; i += T) pts[i] = make_pt(mv, idx[i], a.mfw, a.mv_bw, a.mv_bh);
+  __syncthreads();
+
+  // ---- k-means on (mv.x, x_px, y_px) (:557-578), `attempts` restarts ------------------------
+  const uint32_t pper = (nf + T - 1) / T;
+  const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
+  uint64_t best_compact = ~0ull;
+  for (uint32_t att = 0; att < a.attempts; ++att) {
+    const uint64_t aseed = seed ^ ((uint64_t)att << 32);
+    if (tid == 0) {
+      const uint32_t first = (uint32_t)(seg_hash(aseed) % nf);
+      const Pt p = pts[first];
+      s_cint[0][0] = p.f[0]; s_cint[0][1] = p.f[1]; s_cint[0][2] = p.f[2];
+    }
+    __syncthreads();
+    for (uint32_t j = 1; j < k; ++j) {  // k-means++: next centre with probability ~ min dist^2
+      uint64_t lsum = 0;
+      for (uint32_t i = p0; i < p1; ++i) {
+        const Pt p = pts[i];
+        uint64_t m = ~0ull;
+        for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+        lsum += m;
+      }
+      uint64_t total;
+      const uint64_t excl = block_excl_scan<T>(lsum, s_scan, tid, &total);
+      if (total == 0) {
+        if (tid == 0) s_pick = j < nf ? j : 0;
+      } else {
+        const uint64_t r = seg_hash(aseed ^ j) % total;
+        if (r >= excl && r < excl + lsum) {  // exactly one lane owns the crossing
+          uint64_t acc = excl;
+          for (uint32_t i = p0; i < p1; ++i) {
+            const Pt p = pts[i];
+            uint64_t m = ~0ull;
+            for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+            acc += m;
+            if (acc > r) { s_pick = i; break; }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const Pt p = pts[s_pick];
+        s_cint[j][0] = p.f[0]; s_cint[j][1] = p.f[1]; s_cint[j][2] = p.f[2];
+      }
+      __syncthreads();
+    }
+    if (tid < k) {
+      s_c[tid][0] = (double)s_cint[tid][0];
+      s_c[tid][1] = (double)s_cint[tid][1];
+      s_c[tid][2] = (double)s_cint[tid][2];
+    }
+    __syncthreads();
+
+    uint64_t compact = 0;
+    for (uint32_t it = 0;; ++it) {  // Lloyd
+      if (tid < k) { s_sum[tid][0] = 0; s_sum[tid][1] = 0; s_sum[tid][2] = 0; s_cnt[tid] = 0; }
+      if (tid == 0) s_compact = 0;
+      __syncthreads();
+      unsigned long long lc = 0;
+      const uint32_t lane = tid & 63u;
+      for (uint32_t i0 = 0; i0 < nf; i0 += T) {  // wave-uniform trip count
+        const uint32_t i = i0 + tid;
+        const bool active = i < nf;
+        Pt p = {{0, 0, 0}};
+        uint32_t bj = 0xFFFFFFFFu;
+        if (active) {
+          p = pts[i];
+          double best = dist2_dbl(p, s_c[0]);
+          bj = 0;
+          for (uint32_t j = 1; j < k; ++j) {
+            const double d = dist2_dbl(p, s_c[j]);
+            if (d < best) { best = d; bj = j; }
+          }
+          lab[i] = (uint8_t)bj;
+          lc += (unsigned long long)(best * 256.0);
+        }
+        // per-cluster sums: reduce inside the wave first, then ONE LDS atomic per wave and
+        // cluster (256 lanes adding to ~10 addresses serialise badly); 64 lanes x |coord| fits int32
+        for (uint32_t j = 0; j < k; ++j) {
+          const bool mine = bj == j;
+          const unsigned long long bal = __ballot(mine);
+          if (bal == 0) continue;
+          int sx = mine ? p.f[0] : 0, sy = mine ? p.f[1] : 0, sz = mine ? p.f[2] : 0;
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            sx += __shfl_xor(sx, off, 64);
+            sy += __shfl_xor(sy, off, 64);
+            sz += __shfl_xor(sz, off, 64);
+          }
+          if (lane == 0) {
+            atomicAdd(&s_cnt[j], (uint32_t)__popcll(bal));
+            atomicAdd(&s_sum[j][0], (unsigned long long)(long long)sx);
+            atomicAdd(&s_sum[j][1], (unsigned long long)(long long)sy);
+            atomicAdd(&s_sum[j][2], (unsigned long long)(long long)sz);
+          }
+        }
+      }
+      atomicAdd(&s_compact, lc);
+      __syncthreads();
+      compact = s_compact;
+      if (it + 1 >= a.max_iter) break;
+      if (tid < k) {
+        double s = 0.0;
+        if (s_cnt[tid]) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const double nc = (double)(long long)s_sum[tid][d] / (double)s_cnt[tid];
+            const double t = nc - s_c[tid][d];
+            s = s + t * t;
+            s_c[tid][d] = nc;
+          }
+        }
+        s_shift[tid] = s;
+      }
+      __syncthreads();
+      double shift = 0.0;
+      for (uint32_t j = 0; j < k; ++j) shift = s_shift[j] > shift ? s_shift[j] : shift;
+      if (shift <= a.eps2) break;
+    }
+    if (compact < best_compact) {  // uniform; ties keep the earlier attempt
+      best_compact = compact;
+      for (uint32_t i = tid; i < nf; i += T) best_lab[i] = lab[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- connected components per cluster, numbered as the reference (:597-623) ------------
+  for (uint32_t i = tid; i < n; i += T) { cl[i] = 255; label[i] = i; }
+  __syncthreads();
+  for (uint32_t i = tid; i < nf; i += T) cl[idx[i]] = best_lab[i];
+  __syncthreads();
+  // merge every block with its already-visited neighbours of the same cluster, then flatten
+  for (uint32_t i = tid; i < n; i += T) {
+    const uint8_t c = cl[i];
+    if (c == 255) continue;
+    const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
+    if (x > 0 && cl[i - 1] == c) uf_unite(label, i, i - 1);
+    if (y > 0) {
+      if (cl[i - a.mfw] == c) uf_unite(label, i, i - a.mfw);
+      if (a.conn == 8) {
+        if (x > 0 && cl[i - a.mfw - 1] == c) uf_unite(label, i, i - a.mfw - 1);
+        if (x + 1 < (int)a.mfw && cl[i - a.mfw + 1] == c) uf_unite(label, i, i - a.mfw + 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += T)
+    if (cl[i] != 255) {
+      const uint32_t r = uf_find(label, i);
+      if (r != i) label[i] = r;  // still an ancestor for any concurrent walker; roots are never rewritten
+    }
+  __syncthreads();
+  uint32_t offset = 0;  // BLOCK_TYPE_BACKGROUND, libs/codec.hpp:6
+  for (uint32_t cid = 0; cid < k; ++cid) {
+    uint32_t roots = 0;
+    for (uint32_t i = c0; i < c1; ++i) roots += (cl[i] == cid && label[i] == i) ? 1u : 0u;
+    uint64_t total;
+    uint32_t rank = (uint32_t)block_excl_scan<T>(roots, s_scan, tid, &total);
+    for (uint32_t i = c0; i < c1; ++i)
+      if (cl[i] == cid && label[i] == i) idx[i] = ++rank;  // idx is free now: component number of a root
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += T)
+      if (cl[i] == cid) types[i] = idx[label[i]] + offset;  // :617
+    offset += (uint32_t)total + 1;  // :620, the count includes label 0
+    __syncthreads();
+  }
+}
+
+uint64_t segment_workspace_per_frame(uint32_t n) {
+  // 5 byte arrays, then idx + label (u32 each), then the feature points (3 x i32)
+  return ((((5ull * n + 15) & ~15ull) + 8ull * n + 12ull * n) + 255) & ~255ull;
+}
+
+int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
+                   uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,
+                   uint32_t* d_types, hipStream_t stream) {
+  if (n_frames == 0) return SVC_OK;
+  if (p.cluster_count > kMaxK)
+    return fail(SVC_ERR_UNSUPPORTED, "segment: cluster_count %u exceeds %u", p.cluster_count, kMaxK);
+  SegArgs a;
+  a.mask = d_mask;
+  a.mv = d_mv;
+  a.types = d_types;
+  a.ws = d_ws;
+  a.mfw = mfw; a.mfh = mfh; a.n = mfw * mfh;
+  a.ws_stride = segment_workspace_per_frame(a.n);
+  a.seed = seed;
+  a.eps2 = (double)p.epsilon * (double)p.epsilon;
+  a.mv_bw = mv_bw; a.mv_bh = mv_bh;
+  a.morph_w = p.morph_rect_w; a.morph_h = p.morph_rect_h;
+  a.k = p.cluster_count; a.attempts = p.attempt_count; a.max_iter = p.max_iter_count;
+  a.conn = p.connectivity;
+  const size_t lds_bytes = 7 * (((size_t)a.n + 3) & ~(size_t)3);
+  if (lds_bytes <= 120 * 1024)
+    hipLaunchKernelGGL((segment_kernel<true, 256>), dim3(n_frames), dim3(256), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL((segment_kernel<false, 1024>), dim3(n_frames), dim3(1024), 0, stream, a);
+  return check_launch("segment_kernel");
+}
+
+}  // namespace svc

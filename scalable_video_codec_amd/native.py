@@ -31,6 +31,16 @@ class RansacParams(C.Structure):
                 ("success_prob", C.c_float), ("inlier_ratio", C.c_float)]
 
 
+class SegmentParams(C.Structure):
+    _fields_ = [("morph_rect_w", C.c_uint32), ("morph_rect_h", C.c_uint32), ("cluster_count", C.c_uint32),
+                ("attempt_count", C.c_uint32), ("max_iter_count", C.c_uint32), ("epsilon", C.c_float),
+                ("connectivity", C.c_uint32)]
+
+
+# apps/encoder.cpp:47-56
+DEFAULT_SEGMENT = dict(morph_rect_w=3, morph_rect_h=3, cluster_count=10, attempt_count=3, max_iter_count=10,
+                       epsilon=1.0, connectivity=4)
+
 _vp = C.c_void_p
 _u32, _u64 = C.c_uint32, C.c_uint64
 
@@ -45,6 +55,8 @@ SIGNATURES = {
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
+    "svc_hip_segment_workspace_bytes": (_u64, [_u32, _u32, _u32]),
+    "svc_hip_segment_frames": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, SegmentParams, _u64, _vp, _u64, _vp, _vp]),
     "svc_hip_dct_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_dct_quant_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
@@ -158,6 +170,27 @@ def block_types_frames(mask: torch.Tensor, out: Optional[torch.Tensor] = None) -
     if out is None:
         out = torch.empty((frames, blocks), dtype=torch.int32, device=mask.device)
     _check(load().svc_hip_block_types_frames(_dev(mask, torch.uint8), blocks, frames, _dev(out, torch.int32), _stream()))
+    return out
+
+
+def segment_workspace_bytes(mfw: int, mfh: int, frames: int) -> int:
+    return int(load().svc_hip_segment_workspace_bytes(mfw, mfh, frames))
+
+
+def segment_frames(mask: torch.Tensor, mv: torch.Tensor, mfw: int, mfh: int, mv_block: int = 16, seed: int = 0,
+                   out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, **params) -> torch.Tensor:
+    """mask (frames, blocks) u8 inlier mask + mv (frames, blocks, 2) f32 -> (frames, blocks) i32 region ids."""
+    frames, blocks = mask.shape
+    assert blocks == mfw * mfh
+    p = SegmentParams(**{**DEFAULT_SEGMENT, **params})
+    need = int(load().svc_hip_segment_workspace_bytes(mfw, mfh, frames))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=mask.device)
+    if out is None:
+        out = torch.empty((frames, blocks), dtype=torch.int32, device=mask.device)
+    _check(load().svc_hip_segment_frames(_dev(mask, torch.uint8), _dev(mv, torch.float32), mfw, mfh, frames,
+                                         mv_block, mv_block, p, seed, _dev(workspace, torch.uint8),
+                                         workspace.numel(), _dev(out, torch.int32), _stream()))
     return out
 
 

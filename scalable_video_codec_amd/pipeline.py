@@ -91,7 +91,7 @@ class ClipEncoder:
     """Owns the device buffers of one rank's chunk and runs one hot-path pass per step()."""
 
     def __init__(self, cfg: CodecConfig, n_frames: int, device, rank: int = 0, world: int = 1,
-                 ransac: Optional[dict] = None):
+                 ransac: Optional[dict] = None, segment: Optional[dict] = None, segmentation: bool = True):
         self.cfg, self.n, self.dev, self.rank, self.world = cfg, n_frames, device, rank, world
         self.pw, self.ph = cfg.padded
         self.levels = cfg.levels
@@ -117,6 +117,16 @@ class ClipEncoder:
         self.types = torch.empty((p, self.blocks), dtype=torch.int32, device=device)
         self.coeffs = (torch.empty((p, 3, self.ph, self.pw), dtype=torch.float32, device=device)
                        if cfg.dct_block else None)
+        # region ids: the full segmentation glue (libs/encoder.cpp:507-623) or, with
+        # segmentation=False, only its in-repo part (foreground = one region)
+        self.segmentation = segmentation
+        self.segment = dict(native.DEFAULT_SEGMENT)
+        if segment:
+            self.segment.update(segment)
+        self.mfw, self.mfh = cfg.mv_field
+        self.seg_ws = (torch.empty(native.segment_workspace_bytes(self.mfw, self.mfh, p), dtype=torch.uint8, device=device)
+                       if segmentation else None)
+        self.seg_seed = cfg.seed * 1000003 + rank * 100003
         self.iters = native.ransac_iter_count(**self.ransac)
         self.samples = ransac_samples(p, self.iters, self.ransac["subset_sz"], self.blocks,
                                       cfg.seed + 7919 * rank, device)
@@ -208,8 +218,14 @@ class ClipEncoder:
                 native.ransac_frames(self.mv[p0:p1], self.samples[p0:p1],
                                      out=(self.gm[p0:p1], self.rmse[p0:p1], self.mask[p0:p1], self.count[p0:p1]),
                                      **self.ransac)
-            with self._timed("block_types", timed):
-                native.block_types_frames(self.mask[p0:p1], out=self.types[p0:p1])
+            if self.segmentation:
+                with self._timed("segment", timed):
+                    native.segment_frames(self.mask[p0:p1], self.mv[p0:p1], self.mfw, self.mfh, c.mv_block,
+                                          seed=self.seg_seed + p0, out=self.types[p0:p1], workspace=self.seg_ws,
+                                          **self.segment)
+            else:
+                with self._timed("block_types", timed):
+                    native.block_types_frames(self.mask[p0:p1], out=self.types[p0:p1])
             if not c.dct_block:
                 continue
             f0 = self.first_encoded + p0       # encoded frame of pair p is own frame first_encoded + p

@@ -64,8 +64,14 @@ def test_ransac_and_types_consistent(oracle, encoded):
         assert enc.gm[p].cpu().numpy().tobytes() == gm.tobytes()
         assert np.float32(enc.rmse[p].item()).tobytes() == rmse.tobytes()
         assert np.array_equal(np.flatnonzero(enc.mask[p].cpu().numpy()), inl) and int(enc.count[p]) == len(inl)
-    assert torch.equal(enc.types, (enc.mask == 0).to(torch.int32))
     assert bool(((enc.count > 0) & (enc.count <= cfg.blocks)).all())
+    # region ids: the oracle's statement of libs/encoder.cpp:507-623 on the same masks / MVs
+    for p in (0, 149, 298):
+        want = oracle.segment(enc.mask[p].cpu().numpy(), enc.mv[p].cpu().numpy(), enc.mfw, enc.mfh,
+                              seed=enc.seg_seed + p)
+        assert np.array_equal(enc.types[p].cpu().numpy().astype(np.uint32), want)
+    # inliers are always background; a region id > 0 implies "not an inlier" before the morphology only
+    assert int(enc.types.min()) == 0
 
 
 def test_dct_energy_dc_and_quant_properties(native, encoded):

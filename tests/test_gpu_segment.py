@@ -1,0 +1,67 @@
+"""GPU segmentation (libs/encoder.cpp:507-623) against the oracle's statement of it
+(oracle/svc_segment.c): region ids must be identical for every block."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rng, mfw, mfh, n_rects, salt):
+    mask = np.ones((mfh, mfw), np.uint8)
+    mv = np.tile(np.array([3.0, -2.0], np.float32), (mfh, mfw, 1))
+    for _ in range(n_rects):
+        h, w = rng.integers(3, max(4, mfh // 3)), rng.integers(3, max(4, mfw // 3))
+        y, x = rng.integers(0, mfh - h), rng.integers(0, mfw - w)
+        mask[y:y + h, x:x + w] = 0
+        mv[y:y + h, x:x + w] = rng.integers(-14, 15, 2)
+    s = rng.random((mfh, mfw)) < salt
+    mask[s] = 0
+    mv[s] = rng.integers(-14, 15, (int(s.sum()), 2))
+    return mask.reshape(-1), mv.reshape(-1, 2)
+
+
+@pytest.mark.parametrize("mfw,mfh", [(120, 68), (80, 45), (22, 18), (240, 135)])
+@pytest.mark.parametrize("conn", [4, 8])
+def test_segment_matches_oracle(native, oracle, mfw, mfh, conn):
+    rng = np.random.default_rng(mfw * 7 + conn)
+    frames = 5
+    masks, mvs = zip(*[_scene(rng, mfw, mfh, 1 + f, 0.01 * f) for f in range(frames)])
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh,
+                                seed=1234, connectivity=conn).cpu().numpy()
+    for f in range(frames):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, connectivity=conn, seed=1234 + f)
+        assert np.array_equal(got[f].astype(np.uint32), want), f"frame {f}: {(got[f] != want).sum()} blocks differ"
+
+
+@pytest.mark.parametrize("kw", [dict(cluster_count=1), dict(cluster_count=3, attempt_count=1, max_iter_count=2),
+                                dict(morph_rect_w=5, morph_rect_h=2), dict(epsilon=50.0), dict(cluster_count=40)])
+def test_segment_parameters(native, oracle, kw):
+    rng = np.random.default_rng(5)
+    mfw, mfh = 60, 34
+    mask, mv = _scene(rng, mfw, mfh, 4, 0.03)
+    got = native.segment_frames(torch.from_numpy(mask[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh,
+                                seed=9, **kw).cpu().numpy()[0]
+    okw = {"attempts" if k == "attempt_count" else "max_iter" if k == "max_iter_count" else
+           "morph_w" if k == "morph_rect_w" else "morph_h" if k == "morph_rect_h" else k: v for k, v in kw.items()}
+    want = oracle.segment(mask, mv, mfw, mfh, seed=9, **okw)
+    assert np.array_equal(got.astype(np.uint32), want)
+
+
+def test_segment_edge_cases(native, oracle):
+    mfw, mfh = 30, 20
+    n = mfw * mfh
+    mv = np.zeros((n, 2), np.float32)
+    for mask in (np.ones(n, np.uint8), np.zeros(n, np.uint8)):  # nothing / everything is foreground
+        got = native.segment_frames(torch.from_numpy(mask[None]).cuda(), torch.from_numpy(mv[None]).cuda(),
+                                    mfw, mfh, seed=3).cpu().numpy()[0]
+        assert np.array_equal(got.astype(np.uint32), oracle.segment(mask, mv, mfw, mfh, seed=3))
+    one = np.ones(n, np.uint8)
+    one[5 * mfw + 7: 5 * mfw + 10] = 0  # a 1x3 sliver is removed by the 3x3 open
+    one[6 * mfw + 7: 6 * mfw + 10] = 0
+    got = native.segment_frames(torch.from_numpy(one[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh).cpu().numpy()[0]
+    assert np.array_equal(got.astype(np.uint32), oracle.segment(one, mv, mfw, mfh)) and not got.any()
+    with pytest.raises(native.SvcError) as e:
+        native.segment_frames(torch.from_numpy(one[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh, connectivity=6)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG

@@ -1,0 +1,25 @@
+"""Times segment_frames on a real clip's masks/MVs under different parameter settings (diagnostic)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scalable_video_codec_amd import configs, native, pipeline, synth
+name = sys.argv[1] if len(sys.argv) > 1 else "C3-1080p-3L-dct8-quant"
+cfg = configs.ALL[name]
+n = min(cfg.frames, 64)
+dev = torch.device("cuda")
+clip = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
+pw, ph = cfg.padded
+enc = pipeline.ClipEncoder(cfg, n, dev)
+enc.load_frames([synth.pad_frame(clip.frame_bgr(t), pw, ph) for t in range(n)])
+enc.step(); torch.cuda.synchronize()
+print(name, "frames", n, "blocks", cfg.blocks, "inliers/frame", enc.count.float().mean().item(), "fg after morph", (enc.types != 0).sum(1).float().mean().item())
+def t(**kw):
+    native.segment_frames(enc.mask, enc.mv, enc.mfw, enc.mfh, seed=1, **kw); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(3): native.segment_frames(enc.mask, enc.mv, enc.mfw, enc.mfh, seed=1, **kw)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / 3
+for kw in (dict(), dict(attempt_count=1), dict(attempt_count=1, max_iter_count=1), dict(cluster_count=1),
+           dict(cluster_count=2), dict(cluster_count=5), dict(cluster_count=20), dict(attempt_count=1, cluster_count=1, max_iter_count=1)):
+    print(kw, round(t(**kw), 3), "ms")
