@@ -118,6 +118,7 @@ def main() -> None:
                     help="cut the clip into this many chunks; the transform of chunk k overlaps the front of chunk k+1 on a second stream")
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
+    ap.add_argument("--wire", action="store_true", help="also serialise the records of libs/encoder.cpp:222-269 each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,7 +153,8 @@ def main() -> None:
     clip = synth.SynthClip(cfg.width, cfg.height, world * n_frames, cfg.seed, device=dev)
     pw, ph = cfg.padded
     frames = [synth.pad_frame(clip.frame_bgr(rank * n_frames + t), pw, ph) for t in range(n_frames)]
-    enc = pipeline.ClipEncoder(cfg, n_frames, dev, rank=rank, world=world, segmentation=not args.no_segmentation)
+    enc = pipeline.ClipEncoder(cfg, n_frames, dev, rank=rank, world=world, segmentation=not args.no_segmentation,
+                               wire=args.wire)
     enc.load_frames(frames)
     del clip
     torch.cuda.synchronize()

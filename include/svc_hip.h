@@ -178,6 +178,47 @@ int svc_hip_quant_frames(float* d_planes, uint32_t n_frames, uint32_t frame_w,
                          uint32_t bg_step, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Wire format.
+ * ------------------------------------------------------------------------- */
+
+/* libs/codec.hpp:8-17 (Header), the first 32 bytes of the encoder's output. */
+typedef struct svc_wire_header {
+  uint32_t frame_count;
+  uint32_t frame_w;
+  uint32_t frame_h;
+  uint32_t frame_excess_w;
+  uint32_t frame_excess_h;
+  uint32_t transform_block_w;
+  uint32_t transform_block_h;
+  uint32_t channel_count;
+} svc_wire_header;
+
+/* Fills the header as libs/encoder.cpp:360-381 does: frame_count = clip frames - 1 (the first
+ * frame is tracked-only), the UNPADDED size, excess = padded - unpadded with the padding rule
+ * of libs/encoder.cpp:164-168, 3 channels.  Host-only. */
+int svc_hip_wire_header(uint32_t clip_frame_count, uint32_t frame_w, uint32_t frame_h,
+                        uint32_t mv_block_w, uint32_t mv_block_h, uint32_t level_count,
+                        uint32_t transform_block_w, uint32_t transform_block_h,
+                        svc_wire_header* out);
+
+/* Bytes SerializeEncodedFrame emits for one frame with these arguments. */
+uint64_t svc_hip_serialized_frame_bytes(uint32_t frame_w, uint32_t frame_h,
+                                        uint32_t transform_block_w, uint32_t transform_block_h);
+
+/* replaces SerializeEncodedFrame, libs/encoder.cpp:222-269, argument for argument (3 channels).
+ * d_planes: [n_frames][3][plane_elems] f32 (plane_elems = padded W * H, what the Dct entry
+ * points write); frame_w / frame_h: the tile-loop bounds AND row stride exactly as the
+ * reference uses them (the encoder passes the unpadded size, :647-650; pass the padded size
+ * for a stream the reference's decoder can parse).  Frame f is written at
+ * d_out + f * out_stride_bytes (>= svc_hip_serialized_frame_bytes, multiple of 4). */
+int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32_t n_frames,
+                             const uint32_t* d_block_types, uint32_t frame_w, uint32_t frame_h,
+                             uint32_t transform_block_w, uint32_t transform_block_h,
+                             uint32_t mv_field_w, uint32_t mv_field_h, uint32_t mv_block_w,
+                             uint32_t mv_block_h, uint8_t* d_out, uint64_t out_stride_bytes,
+                             void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Pre-step: luma + pyramid on the device, so the pyramid never
  * crosses PCIe.  Stands in for cv::cvtColor(BGR2YUV) + cv::extractChannel +
  * cv::buildPyramid (libs/encoder.cpp:468-470) with this repo's fixed-point

@@ -70,6 +70,8 @@ class Oracle:
         L.svc_oracle_fg_mask.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u8p]
         L.svc_oracle_segment.restype = C.c_int
         L.svc_oracle_segment.argtypes = [_u8p, _f32p] + [C.c_uint32] * 9 + [C.c_float, C.c_uint32, C.c_uint64, _u32p]
+        L.svc_oracle_serialize_frame.restype = C.c_uint64
+        L.svc_oracle_serialize_frame.argtypes = [_f32p, C.c_uint64, C.c_uint32, _u32p] + [C.c_uint32] * 7 + [_u8p]
         L.svc_oracle_quant.restype = None
         L.svc_oracle_quant.argtypes = [_f32p, C.c_uint64, C.c_uint32]
         L.svc_oracle_quant_frame.restype = None
@@ -158,6 +160,17 @@ class Oracle:
         if rc:
             raise ValueError("svc_oracle_segment: invalid parameter")
         return out
+
+    def serialize_frame(self, planes, block_types, frame_w, frame_h, tbw, tbh, mv_field_w, mv_bw=16, mv_bh=16):
+        """planes (C, H, W) f32 -> bytes exactly as libs/encoder.cpp:222-269 emits them for these arguments."""
+        pl = np.ascontiguousarray(planes, np.float32)
+        bt = np.ascontiguousarray(block_types, np.uint32)
+        ch = pl.shape[0]
+        cap = ((frame_h + tbh - 1) // tbh) * ((frame_w + tbw - 1) // tbw) * (4 + 4 * ch * tbw * tbh)
+        out = np.empty(cap, np.uint8)
+        n = self.lib.svc_oracle_serialize_frame(_ptr(pl, _f32p), pl.shape[1] * pl.shape[2], ch, _ptr(bt, _u32p),
+                                                frame_w, frame_h, tbw, tbh, mv_field_w, mv_bw, mv_bh, _ptr(out, _u8p))
+        return out[:n].copy()
 
     # -- quant / DCT --
     def quant(self, coeffs, step):

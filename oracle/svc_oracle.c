@@ -372,6 +372,37 @@ void svc_oracle_quant_frame(float* planes, uint32_t w, uint32_t h,
   }
 }
 
+/* ---- wire format ------------------------------------------------------- */
+
+/* libs/encoder.cpp:222-269 (SerializeEncodedFrame), literally: tiles are visited over
+ * frame_w x frame_h AS PASSED (the encoder passes the UNPADDED size, :647-650), each tile is
+ * the u32 type of its MV block followed, per channel, by `transform_block_w` rows of
+ * `transform_block_h` floats read at ch[y * frame_w + tb_x] -- the passed width is also the
+ * row stride, and the w/h of the transform block are swapped (:257-262).  Returns the number
+ * of bytes written. */
+uint64_t svc_oracle_serialize_frame(const float* planes, uint64_t plane_elems, uint32_t channels,
+                                    const uint32_t* block_types, uint32_t frame_w, uint32_t frame_h,
+                                    uint32_t transform_block_w, uint32_t transform_block_h,
+                                    uint32_t mv_field_w, uint32_t mv_block_w, uint32_t mv_block_h,
+                                    uint8_t* out) {
+  uint8_t* o = out;
+  for (uint32_t tb_y = 0; tb_y < frame_h; tb_y += transform_block_h) {
+    for (uint32_t tb_x = 0; tb_x < frame_w; tb_x += transform_block_w) {
+      uint32_t type = block_types[(tb_y / mv_block_h) * mv_field_w + tb_x / mv_block_w]; /* :243-247 */
+      memcpy(o, &type, 4);
+      o += 4;
+      for (uint32_t c = 0; c < channels; ++c) {
+        const float* ch = planes + (size_t)c * plane_elems;
+        for (uint32_t y = tb_y; y < tb_y + transform_block_w; ++y) { /* :257 */
+          memcpy(o, ch + (size_t)y * frame_w + tb_x, sizeof(float) * transform_block_h); /* :258-262 */
+          o += sizeof(float) * transform_block_h;
+        }
+      }
+    }
+  }
+  return (uint64_t)(o - out);
+}
+
 /* ---- DCT --------------------------------------------------------------- */
 
 #ifndef M_PI

@@ -119,6 +119,14 @@ void svc_oracle_quant_frame(float* planes, uint32_t w, uint32_t h,
                             const uint32_t* block_types, uint32_t fg_step,
                             uint32_t bg_step);
 
+/* libs/encoder.cpp:222-269 (SerializeEncodedFrame), argument for argument; `planes` holds
+ * `channels` planes of `plane_elems` floats each.  Returns bytes written. */
+uint64_t svc_oracle_serialize_frame(const float* planes, uint64_t plane_elems, uint32_t channels,
+                                    const uint32_t* block_types, uint32_t frame_w, uint32_t frame_h,
+                                    uint32_t transform_block_w, uint32_t transform_block_h,
+                                    uint32_t mv_field_w, uint32_t mv_block_w, uint32_t mv_block_h,
+                                    uint8_t* out);
+
 /* libs/encoder.cpp:323-339 (Dct) with cv::dct restated as the float64
  * orthonormal DCT-II.  `bgr` is H x W x 3 u8 interleaved (what :638 converts
  * to f32); `planes64` receives 3 planar H x W doubles in B, G, R order. */

@@ -157,6 +157,62 @@ int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks, ui
                             static_cast<hipStream_t>(stream));
 }
 
+static uint32_t lcm_u32(uint32_t a, uint32_t b) {
+  uint32_t x = a, y = b;
+  while (y) { const uint32_t t = x % y; x = y; y = t; }
+  return a / x * b;
+}
+
+int svc_hip_wire_header(uint32_t clip_frame_count, uint32_t frame_w, uint32_t frame_h, uint32_t mv_block_w,
+                        uint32_t mv_block_h, uint32_t level_count, uint32_t transform_block_w,
+                        uint32_t transform_block_h, svc_wire_header* out) {
+  SVC_REQUIRE(out, "wire_header: null output");
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && level_count > 0 && level_count <= 16, "wire_header: invalid block / level count");
+  const uint32_t f = 1u << (level_count - 1);
+  // libs/math.hpp:276-283 (ClosestLargerDivisible) as used at libs/encoder.cpp:164-168
+  const uint32_t lw = lcm_u32(mv_block_w, f), lh = lcm_u32(mv_block_h, f);
+  const uint32_t pw = (frame_w + lw - 1) / lw * lw, ph = (frame_h + lh - 1) / lh * lh;
+  out->frame_count = clip_frame_count > 0 ? clip_frame_count - 1 : 0;  // encoder.cpp:361-367
+  out->frame_w = frame_w;
+  out->frame_h = frame_h;
+  out->frame_excess_w = pw - frame_w;
+  out->frame_excess_h = ph - frame_h;
+  out->transform_block_w = transform_block_w;
+  out->transform_block_h = transform_block_h;
+  out->channel_count = 3;
+  return SVC_OK;
+}
+
+uint64_t svc_hip_serialized_frame_bytes(uint32_t frame_w, uint32_t frame_h, uint32_t tbw, uint32_t tbh) {
+  if (!tbw || !tbh) return 0;
+  return (uint64_t)div_up(frame_w, tbw) * div_up(frame_h, tbh) * (4ull + 12ull * tbw * tbh);
+}
+
+int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32_t n_frames,
+                             const uint32_t* d_block_types, uint32_t frame_w, uint32_t frame_h, uint32_t tbw,
+                             uint32_t tbh, uint32_t mv_field_w, uint32_t mv_field_h, uint32_t mv_block_w,
+                             uint32_t mv_block_h, uint8_t* d_out, uint64_t out_stride_bytes, void* stream) {
+  SVC_REQUIRE(d_planes && d_block_types && d_out, "serialize: null pointer");
+  SVC_REQUIRE(tbw > 0 && tbh > 0, "serialize: transform block must be positive (encoder.cpp:227-228)");
+  SVC_REQUIRE(frame_w > 0 && frame_h > 0 && mv_block_w > 0 && mv_block_h > 0, "serialize: empty frame");
+  // the reference's asserts (encoder.cpp:230-239), with its swapped w/h kept
+  SVC_REQUIRE(frame_w % tbh == 0 && frame_h % tbw == 0, "serialize: frame %ux%u not divisible by transform block (encoder.cpp:230-231)", frame_w, frame_h);
+  SVC_REQUIRE(tbh <= mv_block_w && tbw <= mv_block_h && mv_block_h % tbw == 0 && mv_block_w % tbh == 0,
+              "serialize: transform block %ux%u must divide the MV block %ux%u (encoder.cpp:235-239)", tbw, tbh, mv_block_w, mv_block_h);
+  // every block type and coefficient the loops touch must exist (the reference would read out of bounds)
+  const uint32_t last_x = (div_up(frame_w, tbw) - 1) * tbw, last_y = (div_up(frame_h, tbh) - 1) * tbh;
+  SVC_REQUIRE(last_x / mv_block_w < mv_field_w && last_y / mv_block_h < mv_field_h,
+              "serialize: motion field %ux%u does not cover the frame", mv_field_w, mv_field_h);
+  SVC_REQUIRE((uint64_t)(last_y + tbw - 1) * frame_w + last_x + tbh <= plane_elems,
+              "serialize: planes of %llu floats are too small for %ux%u", (unsigned long long)plane_elems, frame_w, frame_h);
+  SVC_REQUIRE(out_stride_bytes % 4 == 0 && aligned(d_out, 4) &&
+                  (n_frames <= 1 || out_stride_bytes >= svc_hip_serialized_frame_bytes(frame_w, frame_h, tbw, tbh)),
+              "serialize: output stride %llu too small or unaligned", (unsigned long long)out_stride_bytes);
+  return launch_serialize(d_planes, plane_elems, n_frames, d_block_types, mv_field_w * mv_field_h, frame_w, frame_h,
+                          tbw, tbh, mv_field_w, mv_block_w, mv_block_h, d_out, out_stride_bytes,
+                          static_cast<hipStream_t>(stream));
+}
+
 uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames) {
   return segment_workspace_per_frame(mv_field_w * mv_field_h) * n_frames;
 }

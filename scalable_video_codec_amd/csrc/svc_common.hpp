@@ -82,6 +82,10 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames,
                   float* d_gm, float* d_rmse, uint8_t* d_mask, uint32_t* d_count,
                   hipStream_t stream);
 int launch_block_types(const uint8_t* d_mask, uint64_t n, uint32_t* d_types, hipStream_t stream);
+int launch_serialize(const float* d_planes, uint64_t plane_elems, uint32_t n_frames, const uint32_t* d_types,
+                     uint32_t mv_blocks, uint32_t frame_w, uint32_t frame_h, uint32_t tbw, uint32_t tbh,
+                     uint32_t mfw, uint32_t mv_bw, uint32_t mv_bh, uint8_t* d_out, uint64_t out_stride,
+                     hipStream_t stream);
 uint64_t segment_workspace_per_frame(uint32_t n);
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
                    uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,

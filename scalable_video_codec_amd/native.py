@@ -37,6 +37,11 @@ class SegmentParams(C.Structure):
                 ("connectivity", C.c_uint32)]
 
 
+class WireHeader(C.Structure):  # libs/codec.hpp:8-17
+    _fields_ = [(n, C.c_uint32) for n in ("frame_count", "frame_w", "frame_h", "frame_excess_w", "frame_excess_h",
+                                          "transform_block_w", "transform_block_h", "channel_count")]
+
+
 # apps/encoder.cpp:47-56
 DEFAULT_SEGMENT = dict(morph_rect_w=3, morph_rect_h=3, cluster_count=10, attempt_count=3, max_iter_count=10,
                        epsilon=1.0, connectivity=4)
@@ -57,6 +62,9 @@ SIGNATURES = {
     "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
     "svc_hip_segment_workspace_bytes": (_u64, [_u32, _u32, _u32]),
     "svc_hip_segment_frames": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, SegmentParams, _u64, _vp, _u64, _vp, _vp]),
+    "svc_hip_wire_header": (C.c_int, [_u32] * 8 + [C.POINTER(WireHeader)]),
+    "svc_hip_serialized_frame_bytes": (_u64, [_u32, _u32, _u32, _u32]),
+    "svc_hip_serialize_frames": (C.c_int, [_vp, _u64, _u32, _vp] + [_u32] * 8 + [_vp, _u64, _vp]),
     "svc_hip_dct_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_dct_quant_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
@@ -191,6 +199,30 @@ def segment_frames(mask: torch.Tensor, mv: torch.Tensor, mfw: int, mfh: int, mv_
     _check(load().svc_hip_segment_frames(_dev(mask, torch.uint8), _dev(mv, torch.float32), mfw, mfh, frames,
                                          mv_block, mv_block, p, seed, _dev(workspace, torch.uint8),
                                          workspace.numel(), _dev(out, torch.int32), _stream()))
+    return out
+
+
+def wire_header(clip_frames: int, w: int, h: int, mv_block: int, levels: int, tb: int) -> bytes:
+    hdr = WireHeader()
+    _check(load().svc_hip_wire_header(clip_frames, w, h, mv_block, mv_block, levels, tb, tb, C.byref(hdr)))
+    return bytes(hdr)
+
+
+def serialized_frame_bytes(frame_w: int, frame_h: int, tbw: int, tbh: int) -> int:
+    return int(load().svc_hip_serialized_frame_bytes(frame_w, frame_h, tbw, tbh))
+
+
+def serialize_frames(planes: torch.Tensor, block_types: torch.Tensor, frame_w: int, frame_h: int, tbw: int,
+                     tbh: int, mfw: int, mfh: int, mv_block: int = 16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """planes (frames, 3, H, W) f32 + types (frames, blocks) i32 -> (frames, bytes) u8, the records of
+    libs/encoder.cpp:222-269 for tile loops over frame_w x frame_h (also the row stride, as in the reference)."""
+    n, _, ph, pw = planes.shape
+    per = serialized_frame_bytes(frame_w, frame_h, tbw, tbh)
+    if out is None:
+        out = torch.empty((n, per), dtype=torch.uint8, device=planes.device)
+    _check(load().svc_hip_serialize_frames(_dev(planes, torch.float32), ph * pw, n, _dev(block_types, torch.int32),
+                                           frame_w, frame_h, tbw, tbh, mfw, mfh, mv_block, mv_block,
+                                           _dev(out, torch.uint8), out.stride(0), _stream()))
     return out
 
 

@@ -91,7 +91,8 @@ class ClipEncoder:
     """Owns the device buffers of one rank's chunk and runs one hot-path pass per step()."""
 
     def __init__(self, cfg: CodecConfig, n_frames: int, device, rank: int = 0, world: int = 1,
-                 ransac: Optional[dict] = None, segment: Optional[dict] = None, segmentation: bool = True):
+                 ransac: Optional[dict] = None, segment: Optional[dict] = None, segmentation: bool = True,
+                 wire: bool = False):
         self.cfg, self.n, self.dev, self.rank, self.world = cfg, n_frames, device, rank, world
         self.pw, self.ph = cfg.padded
         self.levels = cfg.levels
@@ -117,6 +118,11 @@ class ClipEncoder:
         self.types = torch.empty((p, self.blocks), dtype=torch.int32, device=device)
         self.coeffs = (torch.empty((p, 3, self.ph, self.pw), dtype=torch.float32, device=device)
                        if cfg.dct_block else None)
+        # optional last stage: the serialised records of libs/encoder.cpp:222-269 (padded tile
+        # counts, i.e. the layout the reference's decoder parses)
+        self.wire = wire and bool(cfg.dct_block)
+        self.records = (torch.empty((p, native.serialized_frame_bytes(self.pw, self.ph, cfg.dct_block, cfg.dct_block)),
+                                    dtype=torch.uint8, device=device) if self.wire else None)
         # region ids: the full segmentation glue (libs/encoder.cpp:507-623) or, with
         # segmentation=False, only its in-repo part (foreground = one region)
         self.segmentation = segmentation
@@ -243,4 +249,8 @@ class ClipEncoder:
                                                 c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
         if chunks > 1 and c.dct_block:
             main.wait_stream(self._side)
+        if self.wire:
+            with self._timed("serialize", timed):
+                native.serialize_frames(self.coeffs, self.types, self.pw, self.ph, c.dct_block, c.dct_block,
+                                        self.mfw, self.mfh, c.mv_block, out=self.records)
         self._steps_timed += 1 if timed else 0

@@ -1,0 +1,89 @@
+"""The encoder's output stream (libs/codec.hpp Header + SerializeEncodedFrame,
+libs/encoder.cpp:222-269, :360-381): device bytes == the oracle's literal restatement."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(native, oracle, pw, ph, fw, fh, tbw, tbh, mvb=16, frames=2, seed=0):
+    rng = np.random.default_rng(seed)
+    mfw, mfh = pw // mvb, ph // mvb
+    planes = rng.standard_normal((frames, 3, ph, pw)).astype(np.float32) * 100
+    types = rng.integers(0, 7, (frames, mfw * mfh)).astype(np.int32)
+    got = native.serialize_frames(torch.from_numpy(planes).cuda(), torch.from_numpy(types).cuda(), fw, fh, tbw, tbh,
+                                  mfw, mfh, mvb).cpu().numpy()
+    for f in range(frames):
+        want = oracle.serialize_frame(planes[f], types[f].astype(np.uint32), fw, fh, tbw, tbh, mfw, mvb, mvb)
+        assert got[f].tobytes() == want.tobytes(), (pw, ph, fw, fh, tbw, tbh, f)
+    return got
+
+
+def test_reference_call_1080p(native, oracle):
+    """What the encoder really passes: the UNPADDED 1920x1080 with planes padded to 1088 rows
+    (libs/encoder.cpp:647-650): 135 tile rows, not the 136 the decoder expects."""
+    got = _case(native, oracle, 1920, 1088, 1920, 1080, 8, 8, frames=1)
+    assert got.shape[1] == 240 * 135 * (4 + 3 * 64 * 4)
+
+
+def test_decodable_padded_call(native, oracle):
+    got = _case(native, oracle, 640, 368, 640, 368, 8, 8)
+    assert got.shape[1] == native.serialized_frame_bytes(640, 368, 8, 8) == 80 * 46 * 772
+    _case(native, oracle, 256, 160, 256, 160, 16, 16)
+
+
+def test_width_padding_stride_quirk(native, oracle):
+    """1000 -> padded 1008: the reference uses the unpadded width as the row stride of the padded
+    planes (libs/encoder.cpp:258); bug-compatible bytes, checked against the literal restatement."""
+    _case(native, oracle, 1008, 576, 1000, 560, 8, 8, frames=1, seed=3)
+
+
+def test_non_square_tiles_swap(native, oracle):
+    """transform_block_w/h are swapped inside the reference's loops (:257-262): an 8-wide, 4-tall
+    tile is read as 8 rows of 4 floats, so the last tile row reaches 4 rows past frame_h -- the
+    planes need that slack (a tight plane is rejected, not read out of bounds)."""
+    _case(native, oracle, 128, 80, 128, 64, 8, 4, mvb=16, frames=1, seed=5)
+    _case(native, oracle, 128, 80, 128, 64, 4, 8, mvb=16, frames=1, seed=6)
+    planes = torch.zeros((1, 3, 64, 128), device="cuda")
+    types = torch.zeros((1, 32), dtype=torch.int32, device="cuda")
+    with pytest.raises(native.SvcError):
+        native.serialize_frames(planes, types, 128, 64, 8, 4, 8, 4)
+
+
+def test_header(native):
+    h = native.wire_header(300, 1920, 1080, 16, 3, 8)
+    assert struct.unpack("<8I", h) == (299, 1920, 1080, 0, 8, 8, 8, 3)  # libs/encoder.cpp:360-381
+    assert struct.unpack("<8I", native.wire_header(0, 1000, 562, 16, 4, 16)) == (0, 1000, 562, 8, 14, 16, 16, 3)
+
+
+def test_serialize_rejects_out_of_bounds(native):
+    planes = torch.zeros((1, 3, 64, 64), device="cuda")
+    types = torch.zeros((1, 16), dtype=torch.int32, device="cuda")
+    with pytest.raises(native.SvcError) as e:  # tile loops would run past the planes
+        native.serialize_frames(planes, types, 64, 72, 8, 8, 4, 4)
+    assert e.value.status == native.SVC_ERR_INVALID_ARG
+
+
+def test_pipeline_stream_roundtrip(native, oracle):
+    """DCT+quant output of a real clip -> records -> parsed back as apps/decoder.cpp:55-86 would."""
+    from scalable_video_codec_amd import configs, pipeline, synth
+    cfg = configs.C2
+    dev = torch.device("cuda")
+    clip = synth.SynthClip(cfg.width, cfg.height, 3, cfg.seed, device=dev)
+    pw, ph = cfg.padded
+    enc = pipeline.ClipEncoder(cfg, 3, dev)
+    enc.load_frames([synth.pad_frame(clip.frame_bgr(t), pw, ph) for t in range(3)])
+    enc.step()
+    rec = native.serialize_frames(enc.coeffs, enc.types, pw, ph, 8, 8, enc.mfw, enc.mfh).cpu().numpy()
+    coeffs, types = enc.coeffs.cpu().numpy(), enc.types.cpu().numpy()
+    per_tile = 4 + 3 * 64 * 4
+    for f in range(2):
+        for tile in (0, 1, 159, 160, 14399):
+            ty, tx = divmod(tile, pw // 8)
+            raw = rec[f, tile * per_tile:(tile + 1) * per_tile].tobytes()
+            assert struct.unpack("<I", raw[:4])[0] == types[f, (ty // 2) * enc.mfw + tx // 2]
+            blk = np.frombuffer(raw, np.float32, 192, 4).reshape(3, 8, 8)
+            assert np.array_equal(blk, coeffs[f, :, ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8])

@@ -99,3 +99,14 @@ def test_quant_hand_vectors(oracle):
     planes = np.full((3, 16, 32), 319.9, np.float32)
     out = oracle.quant_frame(planes, 16, 16, np.array([0, 5], np.uint32), 1, 640)
     assert (out[:, :, :16] == 0).all() and (out[:, :, 16:] == 320.0).all()  # bg step 640 / fg step 1
+
+
+def test_serialize_frame_layout(oracle):
+    """libs/encoder.cpp:222-269 on a hand-checkable case: 2 tiles of 2x2, 3 channels."""
+    planes = np.arange(3 * 2 * 4, dtype=np.float32).reshape(3, 2, 4)
+    types = np.array([7], np.uint32)
+    raw = oracle.serialize_frame(planes, types, 4, 2, 2, 2, 1, 4, 2)
+    rec = np.frombuffer(raw.tobytes(), np.uint32).reshape(2, 13)
+    assert rec[0, 0] == 7 and rec[1, 0] == 7
+    f = rec[:, 1:].view(np.float32).reshape(2, 3, 2, 2)
+    assert np.array_equal(f[0], planes[:, :, 0:2]) and np.array_equal(f[1], planes[:, :, 2:4])
