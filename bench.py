@@ -118,7 +118,7 @@ def main() -> None:
                     help="cut the clip into this many chunks; the transform of chunk k overlaps the front of chunk k+1 on a second stream")
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
-    ap.add_argument("--wire", action="store_true", help="also serialise the records of libs/encoder.cpp:222-269 each step")
+    ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -218,6 +218,22 @@ int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32
                              uint32_t mv_block_h, uint8_t* d_out, uint64_t out_stride_bytes,
                              void* stream);
 
+/* Dct (+ optional quant) that emits the serialised records DIRECTLY instead of coefficient
+ * planes: one kernel = libs/encoder.cpp:638-650 (convertTo, Dct, SerializeEncodedFrame) with
+ * no extra pass over HBM.  Same bytes as svc_hip_dct[_quant]_frames followed by
+ * svc_hip_serialize_frames(frame_w, emit_frame_h, ...).  Square transform block (8 or 16);
+ * frame_w must already be the padded width (the fused path does not reproduce the reference's
+ * unpadded-width row stride, libs/encoder.cpp:258 -- use svc_hip_serialize_frames for that);
+ * emit_frame_h = the height SerializeEncodedFrame is given (the encoder passes the unpadded
+ * one; pass frame_h for a stream the reference's decoder parses).  fg_step = bg_step = 0
+ * skips the quantiser (the reference's encoder emits raw coefficients). */
+int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes,
+                               uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                               uint32_t block, const uint32_t* d_block_types,
+                               uint32_t mv_block_w, uint32_t mv_block_h, uint32_t fg_step,
+                               uint32_t bg_step, uint32_t emit_frame_h, uint8_t* d_records,
+                               uint64_t records_stride_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Pre-step: luma + pyramid on the device, so the pyramid never
  * crosses PCIe.  Stands in for cv::cvtColor(BGR2YUV) + cv::extractChannel +

@@ -275,6 +275,29 @@ int svc_hip_dct_quant_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, 
                     mv_block_w, mv_block_h, fg_step, bg_step, true, d_planes, static_cast<hipStream_t>(stream));
 }
 
+int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames,
+                               uint32_t frame_w, uint32_t frame_h, uint32_t block, const uint32_t* d_block_types,
+                               uint32_t mv_block_w, uint32_t mv_block_h, uint32_t fg_step, uint32_t bg_step,
+                               uint32_t emit_frame_h, uint8_t* d_records, uint64_t records_stride_bytes,
+                               void* stream) {
+  int rc = validate_dct(d_bgr, d_records, frame_w, frame_h, block, block);
+  if (rc) return rc;
+  SVC_REQUIRE(d_block_types, "dct_records: null block types");
+  SVC_REQUIRE((fg_step == 0) == (bg_step == 0), "dct_records: give both quant steps or neither (0, 0 = no quant)");
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && mv_block_w % block == 0 && mv_block_h % block == 0 &&
+                  frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "dct_records: MV block %ux%u must be a multiple of the transform block %u and divide the frame",
+              mv_block_w, mv_block_h, block);
+  SVC_REQUIRE(emit_frame_h > 0 && emit_frame_h <= frame_h, "dct_records: emit_frame_h %u outside (0, %u]", emit_frame_h, frame_h);
+  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_records, 4) && records_stride_bytes % 4 == 0 &&
+                  records_stride_bytes >= svc_hip_serialized_frame_bytes(frame_w, emit_frame_h, block, block),
+              "dct_records: frames must be 16-byte aligned; records 4-byte aligned with a stride of at least one frame");
+  const bool quant = fg_step != 0;
+  return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block, block, d_block_types, mv_block_w,
+                    mv_block_h, quant ? fg_step : 1, quant ? bg_step : 1, quant, nullptr,
+                    static_cast<hipStream_t>(stream), d_records, records_stride_bytes, emit_frame_h);
+}
+
 int svc_hip_quant(float* d_coeffs, uint64_t n, uint32_t step, void* stream) {
   SVC_REQUIRE(d_coeffs || n == 0, "quant: null pointer");
   SVC_REQUIRE(step > 0, "quant: step must be positive (decoder.cpp:35-47)");

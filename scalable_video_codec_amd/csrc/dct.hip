@@ -42,6 +42,10 @@ struct DctArgs {
   uint32_t mv_bw, mv_bh, mfw, mv_blocks;
   float fg_step, bg_step;
   float fg_inv, bg_inv;  // RN(1 / step), computed on the host
+  // wire output (records of libs/encoder.cpp:222-269 instead of planes)
+  uint8_t* records;
+  uint64_t records_stride;  // bytes per frame
+  uint32_t emit_bands;      // tile rows emitted per frame (frame_h as passed / N)
 };
 
 template <int N> struct Basis;
@@ -115,7 +119,14 @@ constexpr int kRowPitch = 144;                  // 16 f64 + 16 B pad
 constexpr int kSlab8 = 8 * kRowPitch;           // 1152 B  (= 128 mod 256)
 constexpr int kSlab16 = 16 * kRowPitch + 128;   // 2432 B  (= 128 mod 256)
 
-template <int N, bool QUANT>
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// WIRE: instead of three coefficient planes the kernel emits the reference's serialised
+// records (libs/encoder.cpp:222-269: u32 block type, then per channel N rows of N floats) --
+// the column-pass results take one more trip through the (now free) LDS slab as f32 so that
+// every lane stores 16-byte runs that are contiguous across lanes (128 B per segment column
+// and instruction for N = 8, 256 B for N = 16).  No extra HBM traffic versus planar output.
+template <int N, bool QUANT, bool WIRE>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   constexpr int kSegPerWg = 256 / N;
   constexpr int kSlab = N == 8 ? kSlab8 : kSlab16;
@@ -145,13 +156,26 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   float* out_frame = a.planes + (size_t)frame * 3 * a.w * a.h;
 
   float step = 1.f, inv_step = 1.f;
-  if (QUANT) {
+  uint32_t t = 0;
+  if (QUANT || WIRE) {
     // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249);
     // background (0, libs/codec.hpp:6) takes bg_step (libs/decoder.cpp:130-135)
     const uint32_t col = N == 8 ? x_pix + 2 * j : x_pix + j;
-    const uint32_t t = a.types[(size_t)frame * a.mv_blocks + (y_pix / a.mv_bh) * a.mfw + col / a.mv_bw];
+    t = a.types[(size_t)frame * a.mv_blocks + (y_pix / a.mv_bh) * a.mfw + col / a.mv_bw];
+  }
+  if (QUANT) {
     step = t == 0 ? a.bg_step : a.fg_step;
     inv_step = t == 0 ? a.bg_inv : a.fg_inv;
+  }
+  // records of this segment column: tile (band, 2 seg + q) for N = 8, (band, seg) for N = 16
+  constexpr uint32_t kRec = 4 + 12 * N * N;
+  const bool emit = WIRE && band < a.emit_bands;
+  uint8_t* rec0 = nullptr;
+  if (WIRE) {
+    const uint32_t tiles_x = a.w / N, tile0 = band * tiles_x + (N == 8 ? 2 * seg : seg);
+    rec0 = a.records + (size_t)frame * a.records_stride + (size_t)tile0 * kRec;
+    if (emit && (N == 8 ? (j & 3) == 0 : j == 0))
+      *reinterpret_cast<uint32_t*>(rec0 + (N == 8 ? (j >> 2) * kRec : 0)) = t;
   }
 
 #pragma unroll
@@ -184,11 +208,25 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
       dct1d<8, double>(ca, ya);
       dct1d<8, double>(cb, yb);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + 2 * j;
+      if (WIRE) wave_lds_sync();  // every lane has read its columns: the slab becomes the f32 tile
 #pragma unroll
       for (int v = 0; v < 8; ++v) {
         float fa = (float)ya[v], fb = (float)yb[v];
         if (QUANT) { fa = quant1_fast(fa, step, inv_step); fb = quant1_fast(fb, step, inv_step); }
-        *reinterpret_cast<float2*>(dst + (size_t)v * a.w) = make_float2(fa, fb);
+        if (WIRE) *reinterpret_cast<float2*>(slab + v * 64 + j * 8) = make_float2(fa, fb);
+        else *reinterpret_cast<float2*>(dst + (size_t)v * a.w) = make_float2(fa, fb);
+      }
+      if (WIRE) {
+        wave_lds_sync();
+        // 32 chunks of 16 B (2 tiles x 8 rows x 2 halves), 4 per lane, lane-contiguous in the record
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = i * 8 + (int)j, q = m >> 4, tt = m & 15;
+          const float4 v4 = *reinterpret_cast<const float4*>(slab + (tt >> 1) * 64 + q * 32 + (tt & 1) * 16);
+          if (emit)
+            *reinterpret_cast<u32x4_a4*>(rec0 + q * kRec + 4 + c * 256 + tt * 16) =
+                u32x4_a4{__float_as_uint(v4.x), __float_as_uint(v4.y), __float_as_uint(v4.z), __float_as_uint(v4.w)};
+        }
       }
     } else {
       double cc[16], yy[16];
@@ -197,11 +235,24 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
         cc[y] = *reinterpret_cast<const double*>(slab + y * kRowPitch + j * 8);
       dct1d<16, double>(cc, yy);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + j;
+      if (WIRE) wave_lds_sync();
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         float f = (float)yy[v];
         if (QUANT) f = quant1_fast(f, step, inv_step);
-        dst[(size_t)v * a.w] = f;
+        if (WIRE) *reinterpret_cast<float*>(slab + v * 64 + j * 4) = f;
+        else dst[(size_t)v * a.w] = f;
+      }
+      if (WIRE) {
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // 64 chunks of 16 B per tile-channel, 4 per lane
+          const int m = i * 16 + (int)j;
+          const float4 v4 = *reinterpret_cast<const float4*>(slab + m * 16);
+          if (emit)
+            *reinterpret_cast<u32x4_a4*>(rec0 + 4 + c * 1024 + m * 16) =
+                u32x4_a4{__float_as_uint(v4.x), __float_as_uint(v4.y), __float_as_uint(v4.z), __float_as_uint(v4.w)};
+        }
       }
     }
     wave_lds_sync();  // the slab is rewritten by the next channel
@@ -211,7 +262,7 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
-               hipStream_t stream) {
+               hipStream_t stream, uint8_t* d_records, uint64_t records_stride, uint32_t emit_h) {
   if (bw != bh || (bw != 8 && bw != 16))
     return fail(SVC_ERR_UNSUPPORTED, "dct: transform block %ux%u (supported: 8x8, 16x16)", bw, bh);
   if (w % 16 != 0 || h % bh != 0)
@@ -227,11 +278,17 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   if (total > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "dct: %llu segment columns exceed one launch", (unsigned long long)total);
   a.total_segcols = (uint32_t)total;
   a.planes = d_planes;
-  if (quant) {
+  const bool wire = d_records != nullptr;
+  a.records = d_records;
+  a.records_stride = records_stride;
+  a.emit_bands = wire ? div_up(emit_h, bh) : 0;
+  if (quant || wire) {
     a.types = d_types;
     a.mv_bw = mv_bw; a.mv_bh = mv_bh;
     a.mfw = w / mv_bw;
     a.mv_blocks = a.mfw * (h / mv_bh);
+  }
+  if (quant) {
     a.fg_step = (float)fg_step;  // libs/decoder.cpp:141 divides a float by an unsigned
     a.bg_step = (float)bg_step;
     a.fg_inv = 1.0f / a.fg_step;
@@ -239,13 +296,15 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   }
   const uint32_t seg_per_wg = 256 / bw;
   const dim3 grid(div_up(a.total_segcols, seg_per_wg)), block(256);
+#define SVC_DCT_LAUNCH(N_, Q_, W_) hipLaunchKernelGGL((dct_kernel<N_, Q_, W_>), grid, block, 0, stream, a)
   if (bw == 8) {
-    if (quant) hipLaunchKernelGGL((dct_kernel<8, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((dct_kernel<8, false>), grid, block, 0, stream, a);
+    if (wire) { if (quant) SVC_DCT_LAUNCH(8, true, true); else SVC_DCT_LAUNCH(8, false, true); }
+    else { if (quant) SVC_DCT_LAUNCH(8, true, false); else SVC_DCT_LAUNCH(8, false, false); }
   } else {
-    if (quant) hipLaunchKernelGGL((dct_kernel<16, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((dct_kernel<16, false>), grid, block, 0, stream, a);
+    if (wire) { if (quant) SVC_DCT_LAUNCH(16, true, true); else SVC_DCT_LAUNCH(16, false, true); }
+    else { if (quant) SVC_DCT_LAUNCH(16, true, false); else SVC_DCT_LAUNCH(16, false, false); }
   }
+#undef SVC_DCT_LAUNCH
   return check_launch("dct_kernel");
 }
 

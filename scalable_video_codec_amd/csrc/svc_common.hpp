@@ -72,7 +72,8 @@ int launch_ebma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair
 int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
-               hipStream_t stream);
+               hipStream_t stream, uint8_t* d_records = nullptr, uint64_t records_stride = 0,
+               uint32_t emit_h = 0);
 int launch_quant(float* d_coeffs, uint64_t n, uint32_t step, hipStream_t stream);
 int launch_quant_frames(float* d_planes, uint32_t n_frames, uint32_t w, uint32_t h,
                         uint32_t mv_bw, uint32_t mv_bh, const uint32_t* d_types,

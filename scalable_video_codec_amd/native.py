@@ -65,6 +65,7 @@ SIGNATURES = {
     "svc_hip_wire_header": (C.c_int, [_u32] * 8 + [C.POINTER(WireHeader)]),
     "svc_hip_serialized_frame_bytes": (_u64, [_u32, _u32, _u32, _u32]),
     "svc_hip_serialize_frames": (C.c_int, [_vp, _u64, _u32, _vp] + [_u32] * 8 + [_vp, _u64, _vp]),
+    "svc_hip_dct_records_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
     "svc_hip_dct_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_dct_quant_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
@@ -223,6 +224,22 @@ def serialize_frames(planes: torch.Tensor, block_types: torch.Tensor, frame_w: i
     _check(load().svc_hip_serialize_frames(_dev(planes, torch.float32), ph * pw, n, _dev(block_types, torch.int32),
                                            frame_w, frame_h, tbw, tbh, mfw, mfh, mv_block, mv_block,
                                            _dev(out, torch.uint8), out.stride(0), _stream()))
+    return out
+
+
+def dct_records_frames(bgr: torch.Tensor, block: int, block_types: torch.Tensor, mv_block: int = 16,
+                       fg_step: int = 0, bg_step: int = 0, emit_h: Optional[int] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bgr (frames, H, W, 3) u8 -> (frames, bytes) u8 serialised records, DCT (+quant) and
+    SerializeEncodedFrame in one kernel."""
+    n, h, w, _ = bgr.shape
+    emit_h = h if emit_h is None else emit_h
+    per = serialized_frame_bytes(w, emit_h, block, block)
+    if out is None:
+        out = torch.empty((n, per), dtype=torch.uint8, device=bgr.device)
+    _check(load().svc_hip_dct_records_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block,
+                                             _dev(block_types, torch.int32), mv_block, mv_block, fg_step, bg_step,
+                                             emit_h, _dev(out, torch.uint8), out.stride(0), _stream()))
     return out
 
 

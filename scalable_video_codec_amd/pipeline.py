@@ -116,11 +116,11 @@ class ClipEncoder:
         self.mask = torch.empty((p, self.blocks), dtype=torch.uint8, device=device)
         self.count = torch.empty(p, dtype=torch.int32, device=device)
         self.types = torch.empty((p, self.blocks), dtype=torch.int32, device=device)
-        self.coeffs = (torch.empty((p, 3, self.ph, self.pw), dtype=torch.float32, device=device)
-                       if cfg.dct_block else None)
-        # optional last stage: the serialised records of libs/encoder.cpp:222-269 (padded tile
-        # counts, i.e. the layout the reference's decoder parses)
+        # wire=True: the transform emits the serialised records of libs/encoder.cpp:222-269 directly
+        # (padded tile counts: the layout the reference's decoder parses) instead of planes
         self.wire = wire and bool(cfg.dct_block)
+        self.coeffs = (torch.empty((p, 3, self.ph, self.pw), dtype=torch.float32, device=device)
+                       if cfg.dct_block and not self.wire else None)
         self.records = (torch.empty((p, native.serialized_frame_bytes(self.pw, self.ph, cfg.dct_block, cfg.dct_block)),
                                     dtype=torch.uint8, device=device) if self.wire else None)
         # region ids: the full segmentation glue (libs/encoder.cpp:507-623) or, with
@@ -235,11 +235,15 @@ class ClipEncoder:
             if not c.dct_block:
                 continue
             f0 = self.first_encoded + p0       # encoded frame of pair p is own frame first_encoded + p
-            if chunks == 1:
+            if self.wire:
+                with self._timed("dct_quant", timed):
+                    native.dct_records_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
+                                              c.fg_step, c.bg_step, out=self.records[p0:p1])
+            elif chunks == 1:
                 with self._timed("dct_quant", timed):
                     native.dct_quant_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
                                             c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
-            else:
+            elif not self.wire:
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(self._side):
@@ -247,10 +251,6 @@ class ClipEncoder:
                     with self._timed("dct_quant", timed):
                         native.dct_quant_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
                                                 c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
-        if chunks > 1 and c.dct_block:
+        if chunks > 1 and c.dct_block and not self.wire:
             main.wait_stream(self._side)
-        if self.wire:
-            with self._timed("serialize", timed):
-                native.serialize_frames(self.coeffs, self.types, self.pw, self.ph, c.dct_block, c.dct_block,
-                                        self.mfw, self.mfh, c.mv_block, out=self.records)
         self._steps_timed += 1 if timed else 0

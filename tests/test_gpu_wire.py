@@ -87,3 +87,37 @@ def test_pipeline_stream_roundtrip(native, oracle):
             assert struct.unpack("<I", raw[:4])[0] == types[f, (ty // 2) * enc.mfw + tx // 2]
             blk = np.frombuffer(raw, np.float32, 192, 4).reshape(3, 8, 8)
             assert np.array_equal(blk, coeffs[f, :, ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8])
+
+
+@pytest.mark.parametrize("block", [8, 16])
+@pytest.mark.parametrize("quant", [False, True])
+def test_fused_dct_records_equal_dct_then_serialize(native, block, quant):
+    """One kernel (DCT [+quant] -> records) must emit exactly the bytes of the two-step path."""
+    rng = np.random.default_rng(block + quant)
+    n, h, w = 3, 96, 160
+    bgr = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+    mfw, mfh = w // 16, h // 16
+    types = torch.from_numpy(rng.integers(0, 4, (n, mfw * mfh)).astype(np.int32)).cuda()
+    fg, bg = (2, 640) if quant else (0, 0)
+    planes = native.dct_quant_frames(bgr, block, types, 16, fg, bg) if quant else native.dct_frames(bgr, block)
+    for emit_h in (h, h - 16):  # the decodable layout, and the encoder's "unpadded height" call
+        want = native.serialize_frames(planes, types, w, emit_h, block, block, mfw, mfh)
+        got = native.dct_records_frames(bgr, block, types, 16, fg, bg, emit_h=emit_h)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and torch.equal(got, want), (block, quant, emit_h)
+
+
+def test_fused_records_full_clip_c3(native):
+    from scalable_video_codec_amd import configs, pipeline, synth
+    cfg = configs.C3
+    dev = torch.device("cuda")
+    n = 12
+    clip = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
+    pw, ph = cfg.padded
+    enc = pipeline.ClipEncoder(cfg, n, dev)
+    enc.load_frames([synth.pad_frame(clip.frame_bgr(t), pw, ph) for t in range(n)])
+    enc.step()
+    want = native.serialize_frames(enc.coeffs, enc.types, pw, cfg.height, 8, 8, enc.mfw, enc.mfh)  # 135 tile rows
+    got = native.dct_records_frames(enc.bgr[1:], 8, enc.types, 16, cfg.fg_step, cfg.bg_step, emit_h=cfg.height)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
