@@ -111,6 +111,7 @@ int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64
                        uint32_t n_pairs, uint32_t level_count, uint32_t frame_w, uint32_t frame_h,
                        uint32_t search_range, uint32_t block_w, uint32_t block_h, float* d_mv_xy,
                        float* d_min_mad, uint32_t flags, void* stream) {
+  if (n_pairs == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_tracked && d_anchor && d_mv_xy && d_min_mad, "hbma: null pointer (motion.cpp:417-420)");
   int rc = validate_hbma(level_count, frame_w, frame_h, search_range, block_w, block_h);
   if (rc) return rc;
@@ -123,6 +124,7 @@ int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64
 int svc_hip_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride_bytes,
                        uint32_t n_pairs, uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
                        uint32_t block_w, uint32_t block_h, float* d_mv_xy, float* d_min_mad, void* stream) {
+  if (n_pairs == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_tracked && d_anchor && d_mv_xy && d_min_mad, "ebma: null pointer (motion.cpp:273-276)");
   SVC_REQUIRE(block_w > 0 && block_h > 0, "ebma: block must be positive (motion.cpp:278-279)");
   SVC_REQUIRE(frame_w > 0 && frame_h > 0 && frame_w % block_w == 0 && frame_h % block_h == 0,
@@ -141,6 +143,7 @@ uint32_t svc_hip_ransac_iter_count(svc_ransac_params p) {
 int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
                           const uint32_t* d_samples, uint32_t iter_count, float* d_gm_xy, float* d_rmse,
                           uint8_t* d_inlier_mask, uint32_t* d_inlier_count, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_mv_xy && d_gm_xy && d_rmse && d_inlier_mask && d_inlier_count, "ransac: null pointer (motion.cpp:189-192)");
   SVC_REQUIRE(iter_count == 0 || d_samples, "ransac: null samples");
   SVC_REQUIRE(params.subset_sz > 0 && blocks >= params.subset_sz,
@@ -152,6 +155,7 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
 
 int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks, uint32_t n_frames,
                                 uint32_t* d_block_types, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_inlier_mask && d_block_types, "block_types: null pointer");
   return launch_block_types(d_inlier_mask, (uint64_t)blocks * n_frames, d_block_types,
                             static_cast<hipStream_t>(stream));
@@ -192,6 +196,7 @@ int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32
                              const uint32_t* d_block_types, uint32_t frame_w, uint32_t frame_h, uint32_t tbw,
                              uint32_t tbh, uint32_t mv_field_w, uint32_t mv_field_h, uint32_t mv_block_w,
                              uint32_t mv_block_h, uint8_t* d_out, uint64_t out_stride_bytes, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_planes && d_block_types && d_out, "serialize: null pointer");
   SVC_REQUIRE(tbw > 0 && tbh > 0, "serialize: transform block must be positive (encoder.cpp:227-228)");
   SVC_REQUIRE(frame_w > 0 && frame_h > 0 && mv_block_w > 0 && mv_block_h > 0, "serialize: empty frame");
@@ -221,6 +226,7 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, u
                            uint32_t mv_field_h, uint32_t n_frames, uint32_t mv_block_w, uint32_t mv_block_h,
                            svc_segment_params params, uint64_t seed, uint8_t* d_workspace,
                            uint64_t workspace_bytes, uint32_t* d_block_types, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_inlier_mask && d_mv_xy && d_block_types && d_workspace, "segment: null pointer");
   SVC_REQUIRE(mv_field_w > 0 && mv_field_h > 0 && mv_block_w > 0 && mv_block_h > 0, "segment: empty motion field");
   // libs/encoder.cpp:39-61 (Validate(KMeansParams)), :92-97 (connectivity)
@@ -248,6 +254,7 @@ static int validate_dct(const void* in, const void* out, uint32_t w, uint32_t h,
 
 int svc_hip_dct_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                        uint32_t frame_h, uint32_t block_w, uint32_t block_h, float* d_planes, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block_w, block_h);
   if (rc) return rc;
   SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_planes, 8),
@@ -260,6 +267,7 @@ int svc_hip_dct_quant_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, 
                              uint32_t frame_w, uint32_t frame_h, uint32_t block_w, uint32_t block_h,
                              const uint32_t* d_block_types, uint32_t mv_block_w, uint32_t mv_block_h,
                              uint32_t fg_step, uint32_t bg_step, float* d_planes, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block_w, block_h);
   if (rc) return rc;
   SVC_REQUIRE(d_block_types, "dct_quant: null block types");
@@ -280,6 +288,7 @@ int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes
                                uint32_t mv_block_w, uint32_t mv_block_h, uint32_t fg_step, uint32_t bg_step,
                                uint32_t emit_frame_h, uint8_t* d_records, uint64_t records_stride_bytes,
                                void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   int rc = validate_dct(d_bgr, d_records, frame_w, frame_h, block, block);
   if (rc) return rc;
   SVC_REQUIRE(d_block_types, "dct_records: null block types");
@@ -307,6 +316,7 @@ int svc_hip_quant(float* d_coeffs, uint64_t n, uint32_t step, void* stream) {
 int svc_hip_quant_frames(float* d_planes, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
                          uint32_t mv_block_w, uint32_t mv_block_h, const uint32_t* d_block_types,
                          uint32_t fg_step, uint32_t bg_step, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_planes && d_block_types, "quant_frames: null pointer");
   SVC_REQUIRE(fg_step > 0 && bg_step > 0, "quant_frames: steps must be positive");
   SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
@@ -318,6 +328,7 @@ int svc_hip_quant_frames(float* d_planes, uint32_t n_frames, uint32_t frame_w, u
 int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames,
                                 uint32_t frame_w, uint32_t frame_h, uint32_t level_count, uint8_t* d_pyr,
                                 uint64_t pyr_stride_bytes, void* stream) {
+  if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_bgr && d_pyr, "luma_pyramid: null pointer");
   SVC_REQUIRE(level_count > 0 && level_count <= 16, "luma_pyramid: level_count %u out of range", level_count);
   const uint32_t f = 1u << (level_count - 1);

@@ -115,3 +115,28 @@ def test_invalid_args(native):
     with pytest.raises(native.SvcError) as e:
         native.hbma_host(t * 3, t * 3, 2, 16, 16)  # search_range < 2^(L-1) (motion.cpp:433)
     assert e.value.status == native.SVC_ERR_INVALID_ARG
+
+
+def test_empty_batches_are_noops(native):
+    """Zero pairs / frames: every batched entry point returns OK without touching memory."""
+    e8 = torch.empty(0, dtype=torch.uint8, device="cuda")
+    mv, mad = native.hbma_pairs(e8, e8, 256, 0, 3, 64, 64, 8)
+    assert mv.shape == (0, 16, 2) and mad.shape == (0, 16)
+    assert native.dct_frames(torch.empty((0, 32, 32, 3), dtype=torch.uint8, device="cuda"), 8).shape == (0, 3, 32, 32)
+    gm, rmse, mask, count = native.ransac_frames(torch.empty((0, 16, 2), device="cuda"),
+                                                 torch.empty((0, 7, 1), dtype=torch.int32, device="cuda"))
+    assert gm.shape == (0, 2) and mask.shape == (0, 16)
+    assert native.segment_frames(torch.empty((0, 16), dtype=torch.uint8, device="cuda"),
+                                 torch.empty((0, 16, 2), device="cuda"), 4, 4).shape == (0, 16)
+    buf, _ = native.luma_pyramid_frames(torch.empty((0, 32, 32, 3), dtype=torch.uint8, device="cuda"), 2)
+    assert buf.numel() == 0
+
+
+def test_tiny_frames_fall_back_to_the_general_kernel(native, oracle):
+    """Frames too small for the fused kernel's candidate grid (top plane < block + 2 R_top) still work."""
+    rng = np.random.default_rng(4)
+    for w, h, levels in ((16, 16, 3), (32, 16, 3), (48, 32, 4), (16, 48, 1)):
+        t, a = util.random_planes(rng, w, h, levels), util.random_planes(rng, w, h, levels)
+        exp_mv, exp_mad = oracle.hbma(t, a, 8, 16, 16)
+        mv, mad = native.hbma_host(t, a, 8, 16, 16)
+        _assert_same(mv, mad, exp_mv, exp_mad, f"{w}x{h} L={levels}")
