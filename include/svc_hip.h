@@ -235,6 +235,29 @@ int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes
                                uint64_t records_stride_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Decoder-side inverse path, headless: DecodeBlock over every tile
+ * (libs/decoder.cpp:128-149, :183-207) without the GUI.  d_planes: coefficient planes as the
+ * Dct entry points write them (raw, or already quantised: quantisation is idempotent);
+ * step = gazed ? 1 : (type == 0 ? bg_step : fg_step), gazed = the gaze rectangle (in padded
+ * frame coordinates; gaze_w or gaze_h == 0 = none) contains the tile origin.  d_bgr_f32:
+ * [n_frames][H][W][3] reconstructed B,G,R (the decoder's upscaled_frame before its / 255).
+ * ------------------------------------------------------------------------- */
+int svc_hip_decode_frames(const float* d_planes, uint32_t n_frames, uint32_t frame_w,
+                          uint32_t frame_h, uint32_t block, const uint32_t* d_block_types,
+                          uint32_t mv_block_w, uint32_t mv_block_h, uint32_t fg_step,
+                          uint32_t bg_step, uint32_t gaze_x, uint32_t gaze_y, uint32_t gaze_w,
+                          uint32_t gaze_h, float* d_bgr_f32, void* stream);
+
+/* Exact integer sum of squared errors per frame between the source frames (u8 B,G,R, as given
+ * to the Dct entry points) and a reconstruction rounded to u8 (clamp(round)), over the top-left
+ * region_w x region_h pixels (the unpadded picture).  PSNR = 10 log10(255^2 * 3 * region_w *
+ * region_h / sse).  d_sse: [n_frames] u64, overwritten. */
+int svc_hip_sse_frames(const uint8_t* d_src_bgr, uint64_t src_frame_stride_bytes,
+                       const float* d_rec_bgr_f32, uint32_t n_frames, uint32_t frame_w,
+                       uint32_t frame_h, uint32_t region_w, uint32_t region_h, uint64_t* d_sse,
+                       void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Pre-step: luma + pyramid on the device, so the pyramid never
  * crosses PCIe.  Stands in for cv::cvtColor(BGR2YUV) + cv::extractChannel +
  * cv::buildPyramid (libs/encoder.cpp:468-470) with this repo's fixed-point

@@ -72,6 +72,10 @@ class Oracle:
         L.svc_oracle_segment.argtypes = [_u8p, _f32p] + [C.c_uint32] * 9 + [C.c_float, C.c_uint32, C.c_uint64, _u32p]
         L.svc_oracle_serialize_frame.restype = C.c_uint64
         L.svc_oracle_serialize_frame.argtypes = [_f32p, C.c_uint64, C.c_uint32, _u32p] + [C.c_uint32] * 7 + [_u8p]
+        L.svc_oracle_decode_frame.restype = None
+        L.svc_oracle_decode_frame.argtypes = [_f32p] + [C.c_uint32] * 4 + [_u32p] + [C.c_uint32] * 8 + [_f64p]
+        L.svc_oracle_sse_frame.restype = C.c_uint64
+        L.svc_oracle_sse_frame.argtypes = [_u8p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.svc_oracle_quant.restype = None
         L.svc_oracle_quant.argtypes = [_f32p, C.c_uint64, C.c_uint32]
         L.svc_oracle_quant_frame.restype = None
@@ -171,6 +175,20 @@ class Oracle:
         n = self.lib.svc_oracle_serialize_frame(_ptr(pl, _f32p), pl.shape[1] * pl.shape[2], ch, _ptr(bt, _u32p),
                                                 frame_w, frame_h, tbw, tbh, mv_field_w, mv_bw, mv_bh, _ptr(out, _u8p))
         return out[:n].copy()
+
+    def decode_frame(self, planes, block, block_types, mv_block=16, fg_step=1, bg_step=640, gaze=(0, 0, 0, 0)):
+        pl = np.ascontiguousarray(planes, np.float32)
+        _, h, w = pl.shape
+        bt = np.ascontiguousarray(block_types, np.uint32)
+        out = np.empty((h, w, 3), np.float64)
+        self.lib.svc_oracle_decode_frame(_ptr(pl, _f32p), w, h, block, block, _ptr(bt, _u32p), mv_block, mv_block,
+                                         fg_step, bg_step, *gaze, _ptr(out, _f64p))
+        return out
+
+    def sse_frame(self, src_bgr, rec_bgr, region_w, region_h):
+        s = np.ascontiguousarray(src_bgr, np.uint8)
+        r = np.ascontiguousarray(rec_bgr, np.float32)
+        return int(self.lib.svc_oracle_sse_frame(_ptr(s, _u8p), _ptr(r, _f32p), s.shape[1], region_w, region_h))
 
     # -- quant / DCT --
     def quant(self, coeffs, step):

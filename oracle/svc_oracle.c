@@ -465,3 +465,73 @@ void svc_oracle_dct_frame_f32(const uint8_t* bgr, uint32_t w, uint32_t h,
   for (size_t i = 0; i < n; ++i) planes32[i] = (float)p64[i];
   free(p64);
 }
+
+/* ---- decoder-side inverse path (headless) -------------------------------- */
+
+/* libs/decoder.cpp:128-149 (DecodeBlock) over every tile of a frame, as Decoder::operator()
+ * walks them (:183-207): step = gazed ? 1 : (type == 0 ? bg : fg) with
+ * gazed = gaze_rect.contains(tile origin) (:202), quantise-round-dequantise (:140-144),
+ * cv::idct restated as the float64 inverse of the orthonormal DCT-II (X = C^T Y C), cv::merge
+ * into interleaved B,G,R.  gaze_w == 0 or gaze_h == 0 means no gaze rectangle.
+ * out64: H x W x 3 doubles. */
+void svc_oracle_decode_frame(const float* planes, uint32_t w, uint32_t h, uint32_t block_w, uint32_t block_h,
+                             const uint32_t* block_types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg_step,
+                             uint32_t bg_step, uint32_t gaze_x, uint32_t gaze_y, uint32_t gaze_w,
+                             uint32_t gaze_h, double* out64) {
+  double* cw = (double*)malloc(sizeof(double) * block_w * block_w);
+  double* ch = (double*)malloc(sizeof(double) * block_h * block_h);
+  double* q = (double*)malloc(sizeof(double) * block_w * block_h);
+  double* tmp = (double*)malloc(sizeof(double) * block_w * block_h);
+  dct_basis(block_w, cw);
+  dct_basis(block_h, ch);
+  const uint32_t mv_fw = w / mv_bw;
+  for (uint32_t ty = 0; ty < h; ty += block_h)
+    for (uint32_t tx = 0; tx < w; tx += block_w) {
+      const int gazed = gaze_w && gaze_h && tx >= gaze_x && tx < gaze_x + gaze_w && ty >= gaze_y && ty < gaze_y + gaze_h;
+      const uint32_t type = block_types[(ty / mv_bh) * mv_fw + tx / mv_bw];
+      const uint32_t step = gazed ? 1u : (type == 0 ? bg_step : fg_step); /* decoder.cpp:130-135 */
+      for (uint32_t p = 0; p < 3; ++p) {
+        const float* plane = planes + (size_t)p * w * h;
+        for (uint32_t v = 0; v < block_h; ++v)
+          for (uint32_t u = 0; u < block_w; ++u) {
+            float c = plane[(size_t)(ty + v) * w + tx + u];
+            c = c / (float)step;
+            c = roundf(c);
+            c = c * (float)step;
+            q[v * block_w + u] = (double)c;
+          }
+        /* rows: tmp[v][x] = sum_u Y[v][u] Cw[u][x] */
+        for (uint32_t v = 0; v < block_h; ++v)
+          for (uint32_t x = 0; x < block_w; ++x) {
+            double acc = 0.0;
+            for (uint32_t u = 0; u < block_w; ++u) acc += q[v * block_w + u] * cw[u * block_w + x];
+            tmp[v * block_w + x] = acc;
+          }
+        /* columns: X[y][x] = sum_v Ch[v][y] tmp[v][x] */
+        for (uint32_t y = 0; y < block_h; ++y)
+          for (uint32_t x = 0; x < block_w; ++x) {
+            double acc = 0.0;
+            for (uint32_t v = 0; v < block_h; ++v) acc += ch[v * block_h + y] * tmp[v * block_w + x];
+            out64[((size_t)(ty + y) * w + tx + x) * 3 + p] = acc;
+          }
+      }
+    }
+  free(cw); free(ch); free(q); free(tmp);
+}
+
+/* Sum of squared errors between the source frame and the reconstruction rounded to u8
+ * (clamp(round half away)), over the top-left region_w x region_h pixels: exact integer. */
+uint64_t svc_oracle_sse_frame(const uint8_t* src_bgr, const float* rec_bgr, uint32_t w, uint32_t region_w,
+                              uint32_t region_h) {
+  uint64_t sse = 0;
+  for (uint32_t y = 0; y < region_h; ++y)
+    for (uint32_t x = 0; x < region_w; ++x)
+      for (uint32_t c = 0; c < 3; ++c) {
+        size_t i = ((size_t)y * w + x) * 3 + c;
+        float r = roundf(rec_bgr[i]);
+        int v = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r);
+        int d = (int)src_bgr[i] - v;
+        sse += (uint64_t)(d * d);
+      }
+  return sse;
+}

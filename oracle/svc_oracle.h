@@ -139,6 +139,16 @@ void svc_oracle_dct_frame_f32(const uint8_t* bgr, uint32_t w, uint32_t h,
                               uint32_t block_w, uint32_t block_h,
                               float* planes32);
 
+/* libs/decoder.cpp:128-149 + :183-207, headless: reconstructed B,G,R (H x W x 3 doubles). */
+void svc_oracle_decode_frame(const float* planes, uint32_t w, uint32_t h, uint32_t block_w, uint32_t block_h,
+                             const uint32_t* block_types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg_step,
+                             uint32_t bg_step, uint32_t gaze_x, uint32_t gaze_y, uint32_t gaze_w,
+                             uint32_t gaze_h, double* out64);
+
+/* exact integer SSE of source vs reconstruction rounded to u8, over region_w x region_h */
+uint64_t svc_oracle_sse_frame(const uint8_t* src_bgr, const float* rec_bgr, uint32_t w, uint32_t region_w,
+                              uint32_t region_h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,6 +307,35 @@ int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes
                     static_cast<hipStream_t>(stream), d_records, records_stride_bytes, emit_frame_h);
 }
 
+int svc_hip_decode_frames(const float* d_planes, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                          uint32_t block, const uint32_t* d_block_types, uint32_t mv_block_w, uint32_t mv_block_h,
+                          uint32_t fg_step, uint32_t bg_step, uint32_t gaze_x, uint32_t gaze_y, uint32_t gaze_w,
+                          uint32_t gaze_h, float* d_bgr_f32, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  SVC_REQUIRE(d_planes && d_block_types && d_bgr_f32, "decode: null pointer");
+  SVC_REQUIRE(block > 0 && frame_w > 0 && frame_h > 0 && frame_w % block == 0 && frame_h % block == 0,
+              "decode: frame %ux%u not divisible by block %u", frame_w, frame_h, block);
+  SVC_REQUIRE(fg_step > 0 && bg_step > 0, "decode: quant steps must be positive (libs/decoder.cpp:35-47)");
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && mv_block_w % block == 0 && mv_block_h % block == 0 &&
+                  frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "decode: MV block %ux%u must be a multiple of the transform block %u and divide the frame", mv_block_w, mv_block_h, block);
+  SVC_REQUIRE(aligned(d_planes, 16) && aligned(d_bgr_f32, 8), "decode: planes must be 16-byte, output 8-byte aligned");
+  return launch_decode(d_planes, n_frames, frame_w, frame_h, block, d_block_types, mv_block_w, mv_block_h, fg_step,
+                       bg_step, gaze_x, gaze_y, gaze_w, gaze_h, d_bgr_f32, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_sse_frames(const uint8_t* d_src_bgr, uint64_t src_frame_stride_bytes, const float* d_rec_bgr_f32,
+                       uint32_t n_frames, uint32_t frame_w, uint32_t frame_h, uint32_t region_w, uint32_t region_h,
+                       uint64_t* d_sse, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  SVC_REQUIRE(d_src_bgr && d_rec_bgr_f32 && d_sse, "sse: null pointer");
+  SVC_REQUIRE(region_w > 0 && region_h > 0 && region_w <= frame_w && region_h <= frame_h,
+              "sse: region %ux%u outside the frame %ux%u", region_w, region_h, frame_w, frame_h);
+  SVC_REQUIRE(aligned(d_sse, 8), "sse: output must be 8-byte aligned");
+  return launch_sse(d_src_bgr, src_frame_stride_bytes, d_rec_bgr_f32, n_frames, frame_w, frame_h, region_w, region_h,
+                    d_sse, static_cast<hipStream_t>(stream));
+}
+
 int svc_hip_quant(float* d_coeffs, uint64_t n, uint32_t step, void* stream) {
   SVC_REQUIRE(d_coeffs || n == 0, "quant: null pointer");
   SVC_REQUIRE(step > 0, "quant: step must be positive (decoder.cpp:35-47)");

@@ -87,6 +87,11 @@ int launch_serialize(const float* d_planes, uint64_t plane_elems, uint32_t n_fra
                      uint32_t mv_blocks, uint32_t frame_w, uint32_t frame_h, uint32_t tbw, uint32_t tbh,
                      uint32_t mfw, uint32_t mv_bw, uint32_t mv_bh, uint8_t* d_out, uint64_t out_stride,
                      hipStream_t stream);
+int launch_decode(const float* d_planes, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t block,
+                  const uint32_t* d_types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step,
+                  uint32_t gx, uint32_t gy, uint32_t gw, uint32_t gh, float* d_bgr, hipStream_t stream);
+int launch_sse(const uint8_t* d_src, uint64_t src_stride, const float* d_rec, uint32_t n_frames, uint32_t w,
+               uint32_t h, uint32_t region_w, uint32_t region_h, uint64_t* d_sse, hipStream_t stream);
 uint64_t segment_workspace_per_frame(uint32_t n);
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
                    uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,

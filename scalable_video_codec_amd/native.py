@@ -66,6 +66,8 @@ SIGNATURES = {
     "svc_hip_serialized_frame_bytes": (_u64, [_u32, _u32, _u32, _u32]),
     "svc_hip_serialize_frames": (C.c_int, [_vp, _u64, _u32, _vp] + [_u32] * 8 + [_vp, _u64, _vp]),
     "svc_hip_dct_records_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
+    "svc_hip_decode_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp] + [_u32] * 8 + [_vp, _vp]),
+    "svc_hip_sse_frames": (C.c_int, [_vp, _u64, _vp] + [_u32] * 5 + [_vp, _vp]),
     "svc_hip_dct_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_dct_quant_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
@@ -240,6 +242,27 @@ def dct_records_frames(bgr: torch.Tensor, block: int, block_types: torch.Tensor,
     _check(load().svc_hip_dct_records_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block,
                                              _dev(block_types, torch.int32), mv_block, mv_block, fg_step, bg_step,
                                              emit_h, _dev(out, torch.uint8), out.stride(0), _stream()))
+    return out
+
+
+def decode_frames(planes: torch.Tensor, block: int, block_types: torch.Tensor, mv_block: int = 16, fg_step: int = 1,
+                  bg_step: int = 640, gaze=(0, 0, 0, 0), out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Coefficient planes (frames, 3, H, W) f32 -> reconstructed (frames, H, W, 3) f32 B,G,R
+    (libs/decoder.cpp:128-149 over every tile)."""
+    n, _, h, w = planes.shape
+    if out is None:
+        out = torch.empty((n, h, w, 3), dtype=torch.float32, device=planes.device)
+    _check(load().svc_hip_decode_frames(_dev(planes, torch.float32), n, w, h, block, _dev(block_types, torch.int32),
+                                        mv_block, mv_block, fg_step, bg_step, *gaze, _dev(out, torch.float32), _stream()))
+    return out
+
+
+def sse_frames(src_bgr: torch.Tensor, rec: torch.Tensor, region_w: int, region_h: int) -> torch.Tensor:
+    """Exact per-frame SSE (int64) of u8 source frames vs an f32 reconstruction rounded to u8."""
+    n, h, w, _ = src_bgr.shape
+    out = torch.empty(n, dtype=torch.int64, device=src_bgr.device)
+    _check(load().svc_hip_sse_frames(_dev(src_bgr, torch.uint8), h * w * 3, _dev(rec, torch.float32), n, w, h,
+                                     region_w, region_h, _dev(out, torch.int64), _stream()))
     return out
 
 
