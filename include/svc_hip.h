@@ -134,7 +134,7 @@ int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks,
  * section 4.6; parity with OpenCV 3.4's kmeans RNG cannot be pinned offline).  Frame f uses
  * seed + f.  d_workspace: svc_hip_segment_workspace_bytes() bytes of scratch. */
 uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h,
-                                         uint32_t n_frames);
+                                         uint32_t n_frames, uint32_t attempt_count);
 
 int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy,
                            uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames,

@@ -218,8 +218,9 @@ int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32
                           static_cast<hipStream_t>(stream));
 }
 
-uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames) {
-  return segment_workspace_per_frame(mv_field_w * mv_field_h) * n_frames;
+uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames,
+                                         uint32_t attempt_count) {
+  return segment_workspace_per_frame(mv_field_w * mv_field_h, attempt_count) * n_frames;
 }
 
 int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, uint32_t mv_field_w,
@@ -237,9 +238,9 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, u
   SVC_REQUIRE(params.connectivity == 4 || params.connectivity == 8,
               "segment: invalid connected components connectivity: must be either 4 or 8");
   SVC_REQUIRE(params.morph_rect_w > 0 && params.morph_rect_h > 0, "segment: morphology rectangle must be positive");
-  SVC_REQUIRE(workspace_bytes >= svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames),
+  SVC_REQUIRE(workspace_bytes >= svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames, params.attempt_count),
               "segment: workspace of %llu B is smaller than the %llu B needed", (unsigned long long)workspace_bytes,
-              (unsigned long long)svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames));
+              (unsigned long long)svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames, params.attempt_count));
   SVC_REQUIRE(aligned(d_workspace, 16) && aligned(d_mv_xy, 8), "segment: workspace must be 16-byte, motion field 8-byte aligned");
   return launch_segment(d_inlier_mask, d_mv_xy, mv_field_w, mv_field_h, n_frames, mv_block_w, mv_block_h, params,
                         seed, d_workspace, d_block_types, static_cast<hipStream_t>(stream));

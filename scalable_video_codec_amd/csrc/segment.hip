@@ -12,11 +12,12 @@
 // fixed-point compactness), so the parallel reductions here are order-free; the remaining
 // floating point is per-element f64 in a fixed operation order (FP contraction is off).
 //
-// The field is small (8 160 blocks at 1080p): the byte masks and the union-find parents of a
-// frame sit in LDS when they fit (7 B per block), the point lists in a caller-provided global
-// workspace (L2-resident); phases are separated by workgroup barriers; frames run on
-// separate CUs.  Connected components are a lock-free union-find (one merge sweep + one
-// flatten sweep), not iterative label propagation.
+// The work is latency-bound (hundreds of short barrier-separated phases over a small field), so it
+// is cut to shorten the chain: kernel A runs every k-means attempt of every frame as its own
+// workgroup (grid = frames x attempts); kernel B picks the best attempt per frame and does the
+// connected components (a lock-free union-find: one merge sweep + one flatten sweep).  Byte
+// masks, feature points and union-find parents sit in LDS when they fit, otherwise in the
+// caller-provided global workspace (L2-resident).
 #include "svc_common.hpp"
 
 namespace svc {
@@ -165,10 +166,43 @@ __device__ __forceinline__ void morph_pass(const uint8_t* src, uint8_t* dst, con
   __syncthreads();
 }
 
-// LDS_ARRAYS: the per-block byte masks and the union-find parents live in dynamic LDS
-// (7 bytes per MV block: 57 KB at 1080p); otherwise in the global workspace.
+// ---- workspace layout (per frame) -----------------------------------------------------------
+//   [0, 256)            header: u32 nf at 0; u64 compactness[attempt] at 8 + 8 * attempt
+//   idx      [n]  u32   foreground list, raster order (written by attempt 0's workgroup)
+//   lab      [A][n] u8  labels of each k-means attempt
+//   scratch  [A][2n] u8 + [A][n] Pt: masks / feature points of an attempt when they do not fit LDS
+//   cl [n] u8, parent [n] u32: connected-components arrays when they do not fit LDS
+constexpr uint32_t kMaxAttempts = 16;
+
+struct Workspace {
+  uint8_t* base;
+  uint32_t n, attempts;
+  __host__ __device__ static uint64_t a16(uint64_t v) { return (v + 15) & ~15ull; }
+  __host__ __device__ uint64_t off_idx() const { return 256; }
+  __host__ __device__ uint64_t off_lab() const { return off_idx() + a16(4ull * n); }
+  __host__ __device__ uint64_t off_masks() const { return off_lab() + a16((uint64_t)attempts * n); }
+  __host__ __device__ uint64_t off_pts() const { return off_masks() + a16(2ull * attempts * n); }
+  __host__ __device__ uint64_t off_cl() const { return off_pts() + a16(12ull * attempts * n); }
+  __host__ __device__ uint64_t off_parent() const { return off_cl() + a16(n); }
+  __host__ __device__ uint64_t bytes() const { return (off_parent() + 4ull * n + 255) & ~255ull; }
+  __device__ uint32_t* nf() const { return reinterpret_cast<uint32_t*>(base); }
+  __device__ unsigned long long* compact() const { return reinterpret_cast<unsigned long long*>(base + 8); }
+  __device__ uint32_t* idx() const { return reinterpret_cast<uint32_t*>(base + off_idx()); }
+  __device__ uint8_t* lab(uint32_t a) const { return base + off_lab() + (uint64_t)a * n; }
+  __device__ uint8_t* masks(uint32_t a) const { return base + off_masks() + 2ull * a * n; }
+  __device__ Pt* pts(uint32_t a) const { return reinterpret_cast<Pt*>(base + off_pts() + 12ull * a * n); }
+  __device__ uint8_t* cl() const { return base + off_cl(); }
+  __device__ uint32_t* parent() const { return reinterpret_cast<uint32_t*>(base + off_parent()); }
+};
+
+constexpr uint32_t kPtsLds = 1024;  // feature points kept in LDS by an attempt (12 KB); more go to global
+
+// Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
+// (cv::kmeans' `attempts`), so they run side by side instead of one after the other; each
+// rebuilds the (cheap) mask + foreground list for itself.
+// LDS_ARRAYS: the two byte masks live in dynamic LDS (2 B per MV block), else in the workspace.
 template <bool LDS_ARRAYS, uint32_t T>
-__global__ __launch_bounds__(T) void segment_kernel(SegArgs a) {
+__global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
   __shared__ uint64_t s_scan[T / 64];
   __shared__ int s_cint[kMaxK][3];
@@ -177,36 +211,28 @@ __global__ __launch_bounds__(T) void segment_kernel(SegArgs a) {
   __shared__ uint32_t s_cnt[kMaxK];
   __shared__ double s_shift[kMaxK];
   __shared__ unsigned long long s_compact;
-  __shared__ uint32_t s_pick, s_changed;
+  __shared__ uint32_t s_pick;
 
-  const uint32_t tid = threadIdx.x, frame = blockIdx.x, n = a.n;
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
   const uint8_t* mask = a.mask + (size_t)frame * n;
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
-  uint32_t* types = a.types + (size_t)frame * n;
-  uint8_t* w = a.ws + (size_t)frame * a.ws_stride;
-  uint8_t* lab = w + 2 * (size_t)n;
-  uint8_t* best_lab = w + 3 * (size_t)n;
-  uint32_t* idx = reinterpret_cast<uint32_t*>(w + ((5 * (size_t)n + 15) & ~(size_t)15));
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  uint8_t* fg = LDS_ARRAYS ? dyn_lds + 4 * n4 : w;
-  uint8_t* tmp = LDS_ARRAYS ? dyn_lds + 5 * n4 : w + n;
-  uint8_t* cl = LDS_ARRAYS ? dyn_lds + 6 * n4 : w + 4 * (size_t)n;
-  uint32_t* label = LDS_ARRAYS ? reinterpret_cast<uint32_t*>(dyn_lds) : idx + n;  // union-find parents
-  Pt* pts_global = reinterpret_cast<Pt*>(idx + 2 * (size_t)n);
+  uint8_t* fg = LDS_ARRAYS ? dyn_lds : ws.masks(att);
+  uint8_t* tmp = LDS_ARRAYS ? dyn_lds + n4 : ws.masks(att) + n;
+  uint8_t* lab = ws.lab(att);
+  uint32_t* idx = ws.idx();
   const uint64_t seed = a.seed + frame;
 
   // ---- foreground mask, close, open (encoder.cpp:507-527) ---------------------------------
-  for (uint32_t i = tid; i < n; i += T) {
-    fg[i] = mask[i] ? 0 : 255;
-    types[i] = 0;  // :549-551
-  }
+  for (uint32_t i = tid; i < n; i += T) fg[i] = mask[i] ? 0 : 255;
   __syncthreads();
   morph_pass<T>(fg, tmp, a, true, tid);
   morph_pass<T>(tmp, fg, a, false, tid);
   morph_pass<T>(fg, tmp, a, false, tid);
   morph_pass<T>(tmp, fg, a, true, tid);
 
-  // ---- foreground list in raster order (:538-546) -----------------------------------------
+  // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
   const uint32_t per = (n + T - 1) / T;
   const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
   uint32_t local = 0;
@@ -214,144 +240,163 @@ __global__ __launch_bounds__(T) void segment_kernel(SegArgs a) {
   uint64_t tot64;
   uint32_t pos = (uint32_t)block_excl_scan<T>(local, s_scan, tid, &tot64);
   const uint32_t nf = (uint32_t)tot64;
+  Pt* pts_lds = reinterpret_cast<Pt*>(dyn_lds + (LDS_ARRAYS ? 2 * n4 : 0));
+  Pt* pts = nf <= kPtsLds ? pts_lds : ws.pts(att);
   for (uint32_t i = c0; i < c1; ++i)
-    if (fg[i] == 255) idx[pos++] = i;
+    if (fg[i] == 255) {
+      if (att == 0) idx[pos] = i;
+      pts[pos] = make_pt(mv, i, a.mfw, a.mv_bw, a.mv_bh);
+      ++pos;
+    }
+  if (att == 0 && tid == 0) *ws.nf() = nf;
   __syncthreads();
   if (nf == 0) return;
   const uint32_t k = min(a.k, nf);  // :555
 
-  // feature points (:300-321) computed once; during k-means they borrow the LDS space of the
-  // union-find parents (not needed before the connected-components step) when they fit
-  Pt* pts = (LDS_ARRAYS && (size_t)nf * sizeof(Pt) <= 4 * n4) ? reinterpret_cast<Pt*>(dyn_lds) : pts_global;
-  for (uint32_t i = tid; i < nf; i += T) pts[i] = make_pt(mv, idx[i], a.mfw, a.mv_bw, a.mv_bh);
-  __syncthreads();
-
-  // ---- k-means on (mv.x, x_px, y_px) (:557-578), `attempts` restarts ------------------------
+  // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
   const uint32_t pper = (nf + T - 1) / T;
   const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
-  uint64_t best_compact = ~0ull;
-  for (uint32_t att = 0; att < a.attempts; ++att) {
-    const uint64_t aseed = seed ^ ((uint64_t)att << 32);
+  const uint64_t aseed = seed ^ ((uint64_t)att << 32);
+  if (tid == 0) {
+    const uint32_t first = (uint32_t)(seg_hash(aseed) % nf);
+    const Pt p = pts[first];
+    s_cint[0][0] = p.f[0]; s_cint[0][1] = p.f[1]; s_cint[0][2] = p.f[2];
+  }
+  __syncthreads();
+  for (uint32_t j = 1; j < k; ++j) {  // k-means++: next centre with probability ~ min dist^2
+    uint64_t lsum = 0;
+    for (uint32_t i = p0; i < p1; ++i) {
+      const Pt p = pts[i];
+      uint64_t m = ~0ull;
+      for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+      lsum += m;
+    }
+    uint64_t total;
+    const uint64_t excl = block_excl_scan<T>(lsum, s_scan, tid, &total);
+    if (total == 0) {
+      if (tid == 0) s_pick = j < nf ? j : 0;
+    } else {
+      const uint64_t r = seg_hash(aseed ^ j) % total;
+      if (r >= excl && r < excl + lsum) {  // exactly one lane owns the crossing
+        uint64_t acc = excl;
+        for (uint32_t i = p0; i < p1; ++i) {
+          const Pt p = pts[i];
+          uint64_t m = ~0ull;
+          for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+          acc += m;
+          if (acc > r) { s_pick = i; break; }
+        }
+      }
+    }
+    __syncthreads();
     if (tid == 0) {
-      const uint32_t first = (uint32_t)(seg_hash(aseed) % nf);
-      const Pt p = pts[first];
-      s_cint[0][0] = p.f[0]; s_cint[0][1] = p.f[1]; s_cint[0][2] = p.f[2];
-    }
-    __syncthreads();
-    for (uint32_t j = 1; j < k; ++j) {  // k-means++: next centre with probability ~ min dist^2
-      uint64_t lsum = 0;
-      for (uint32_t i = p0; i < p1; ++i) {
-        const Pt p = pts[i];
-        uint64_t m = ~0ull;
-        for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
-        lsum += m;
-      }
-      uint64_t total;
-      const uint64_t excl = block_excl_scan<T>(lsum, s_scan, tid, &total);
-      if (total == 0) {
-        if (tid == 0) s_pick = j < nf ? j : 0;
-      } else {
-        const uint64_t r = seg_hash(aseed ^ j) % total;
-        if (r >= excl && r < excl + lsum) {  // exactly one lane owns the crossing
-          uint64_t acc = excl;
-          for (uint32_t i = p0; i < p1; ++i) {
-            const Pt p = pts[i];
-            uint64_t m = ~0ull;
-            for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
-            acc += m;
-            if (acc > r) { s_pick = i; break; }
-          }
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const Pt p = pts[s_pick];
-        s_cint[j][0] = p.f[0]; s_cint[j][1] = p.f[1]; s_cint[j][2] = p.f[2];
-      }
-      __syncthreads();
-    }
-    if (tid < k) {
-      s_c[tid][0] = (double)s_cint[tid][0];
-      s_c[tid][1] = (double)s_cint[tid][1];
-      s_c[tid][2] = (double)s_cint[tid][2];
-    }
-    __syncthreads();
-
-    uint64_t compact = 0;
-    for (uint32_t it = 0;; ++it) {  // Lloyd
-      if (tid < k) { s_sum[tid][0] = 0; s_sum[tid][1] = 0; s_sum[tid][2] = 0; s_cnt[tid] = 0; }
-      if (tid == 0) s_compact = 0;
-      __syncthreads();
-      unsigned long long lc = 0;
-      const uint32_t lane = tid & 63u;
-      for (uint32_t i0 = 0; i0 < nf; i0 += T) {  // wave-uniform trip count
-        const uint32_t i = i0 + tid;
-        const bool active = i < nf;
-        Pt p = {{0, 0, 0}};
-        uint32_t bj = 0xFFFFFFFFu;
-        if (active) {
-          p = pts[i];
-          double best = dist2_dbl(p, s_c[0]);
-          bj = 0;
-          for (uint32_t j = 1; j < k; ++j) {
-            const double d = dist2_dbl(p, s_c[j]);
-            if (d < best) { best = d; bj = j; }
-          }
-          lab[i] = (uint8_t)bj;
-          lc += (unsigned long long)(best * 256.0);
-        }
-        // per-cluster sums: reduce inside the wave first, then ONE LDS atomic per wave and
-        // cluster (256 lanes adding to ~10 addresses serialise badly); 64 lanes x |coord| fits int32
-        for (uint32_t j = 0; j < k; ++j) {
-          const bool mine = bj == j;
-          const unsigned long long bal = __ballot(mine);
-          if (bal == 0) continue;
-          int sx = mine ? p.f[0] : 0, sy = mine ? p.f[1] : 0, sz = mine ? p.f[2] : 0;
-#pragma unroll
-          for (int off = 32; off >= 1; off >>= 1) {
-            sx += __shfl_xor(sx, off, 64);
-            sy += __shfl_xor(sy, off, 64);
-            sz += __shfl_xor(sz, off, 64);
-          }
-          if (lane == 0) {
-            atomicAdd(&s_cnt[j], (uint32_t)__popcll(bal));
-            atomicAdd(&s_sum[j][0], (unsigned long long)(long long)sx);
-            atomicAdd(&s_sum[j][1], (unsigned long long)(long long)sy);
-            atomicAdd(&s_sum[j][2], (unsigned long long)(long long)sz);
-          }
-        }
-      }
-      atomicAdd(&s_compact, lc);
-      __syncthreads();
-      compact = s_compact;
-      if (it + 1 >= a.max_iter) break;
-      if (tid < k) {
-        double s = 0.0;
-        if (s_cnt[tid]) {
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const double nc = (double)(long long)s_sum[tid][d] / (double)s_cnt[tid];
-            const double t = nc - s_c[tid][d];
-            s = s + t * t;
-            s_c[tid][d] = nc;
-          }
-        }
-        s_shift[tid] = s;
-      }
-      __syncthreads();
-      double shift = 0.0;
-      for (uint32_t j = 0; j < k; ++j) shift = s_shift[j] > shift ? s_shift[j] : shift;
-      if (shift <= a.eps2) break;
-    }
-    if (compact < best_compact) {  // uniform; ties keep the earlier attempt
-      best_compact = compact;
-      for (uint32_t i = tid; i < nf; i += T) best_lab[i] = lab[i];
+      const Pt p = pts[s_pick];
+      s_cint[j][0] = p.f[0]; s_cint[j][1] = p.f[1]; s_cint[j][2] = p.f[2];
     }
     __syncthreads();
   }
+  if (tid < k) {
+    s_c[tid][0] = (double)s_cint[tid][0];
+    s_c[tid][1] = (double)s_cint[tid][1];
+    s_c[tid][2] = (double)s_cint[tid][2];
+  }
+  __syncthreads();
 
-  // ---- connected components per cluster, numbered as the reference (:597-623) ------------
-  for (uint32_t i = tid; i < n; i += T) { cl[i] = 255; label[i] = i; }
+  uint64_t compact = 0;
+  for (uint32_t it = 0;; ++it) {  // Lloyd
+    if (tid < k) { s_sum[tid][0] = 0; s_sum[tid][1] = 0; s_sum[tid][2] = 0; s_cnt[tid] = 0; }
+    if (tid == 0) s_compact = 0;
+    __syncthreads();
+    unsigned long long lc = 0;
+    const uint32_t lane = tid & 63u;
+    for (uint32_t i0 = 0; i0 < nf; i0 += T) {  // wave-uniform trip count
+      const uint32_t i = i0 + tid;
+      const bool active = i < nf;
+      Pt p = {{0, 0, 0}};
+      uint32_t bj = 0xFFFFFFFFu;
+      if (active) {
+        p = pts[i];
+        double best = dist2_dbl(p, s_c[0]);
+        bj = 0;
+        for (uint32_t j = 1; j < k; ++j) {
+          const double d = dist2_dbl(p, s_c[j]);
+          if (d < best) { best = d; bj = j; }
+        }
+        lab[i] = (uint8_t)bj;
+        lc += (unsigned long long)(best * 256.0);
+      }
+      // per-cluster sums: reduce inside the wave first, then ONE LDS atomic per wave and
+      // cluster; 64 lanes x |coord| fits int32
+      for (uint32_t j = 0; j < k; ++j) {
+        const bool mine = bj == j;
+        const unsigned long long bal = __ballot(mine);
+        if (bal == 0) continue;
+        int sx = mine ? p.f[0] : 0, sy = mine ? p.f[1] : 0, sz = mine ? p.f[2] : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          sx += __shfl_xor(sx, off, 64);
+          sy += __shfl_xor(sy, off, 64);
+          sz += __shfl_xor(sz, off, 64);
+        }
+        if (lane == 0) {
+          atomicAdd(&s_cnt[j], (uint32_t)__popcll(bal));
+          atomicAdd(&s_sum[j][0], (unsigned long long)(long long)sx);
+          atomicAdd(&s_sum[j][1], (unsigned long long)(long long)sy);
+          atomicAdd(&s_sum[j][2], (unsigned long long)(long long)sz);
+        }
+      }
+    }
+    atomicAdd(&s_compact, lc);
+    __syncthreads();
+    compact = s_compact;
+    if (it + 1 >= a.max_iter) break;
+    if (tid < k) {
+      double s = 0.0;
+      if (s_cnt[tid]) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double nc = (double)(long long)s_sum[tid][d] / (double)s_cnt[tid];
+          const double t = nc - s_c[tid][d];
+          s = s + t * t;
+          s_c[tid][d] = nc;
+        }
+      }
+      s_shift[tid] = s;
+    }
+    __syncthreads();
+    double shift = 0.0;
+    for (uint32_t j = 0; j < k; ++j) shift = s_shift[j] > shift ? s_shift[j] : shift;
+    if (shift <= a.eps2) break;
+  }
+  if (tid == 0) ws.compact()[att] = compact;
+}
+
+// Kernel B: one workgroup per frame.  Takes the attempt with the smallest compactness (ties ->
+// the earlier attempt), then connected components per cluster, numbered as the reference
+// numbers them (:597-623).  LDS_ARRAYS: cluster ids + union-find parents in LDS (5 B per block).
+template <bool LDS_ARRAYS, uint32_t T>
+__global__ __launch_bounds__(T) void segment_label_kernel(SegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+  __shared__ uint64_t s_scan[T / 64];
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, n = a.n;
+  uint32_t* types = a.types + (size_t)frame * n;
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
+  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+  uint32_t* label = LDS_ARRAYS ? reinterpret_cast<uint32_t*>(dyn_lds) : ws.parent();
+  uint8_t* cl = LDS_ARRAYS ? dyn_lds + 4 * n4 : ws.cl();
+  uint32_t* idx = ws.idx();
+  const uint32_t nf = *ws.nf();
+
+  for (uint32_t i = tid; i < n; i += T) { types[i] = 0; cl[i] = 255; label[i] = i; }  // :549-551
+  if (nf == 0) return;
+  const uint32_t k = min(a.k, nf);
+  uint32_t best = 0;
+  unsigned long long best_c = ws.compact()[0];
+  for (uint32_t t = 1; t < a.attempts; ++t) {
+    const unsigned long long c = ws.compact()[t];
+    if (c < best_c) { best_c = c; best = t; }
+  }
+  const uint8_t* best_lab = ws.lab(best);
   __syncthreads();
   for (uint32_t i = tid; i < nf; i += T) cl[idx[i]] = best_lab[i];
   __syncthreads();
@@ -376,6 +421,8 @@ __global__ __launch_bounds__(T) void segment_kernel(SegArgs a) {
       if (r != i) label[i] = r;  // still an ancestor for any concurrent walker; roots are never rewritten
     }
   __syncthreads();
+  const uint32_t per = (n + T - 1) / T;
+  const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
   uint32_t offset = 0;  // BLOCK_TYPE_BACKGROUND, libs/codec.hpp:6
   for (uint32_t cid = 0; cid < k; ++cid) {
     uint32_t roots = 0;
@@ -392,9 +439,8 @@ __global__ __launch_bounds__(T) void segment_kernel(SegArgs a) {
   }
 }
 
-uint64_t segment_workspace_per_frame(uint32_t n) {
-  // 5 byte arrays, then idx + label (u32 each), then the feature points (3 x i32)
-  return ((((5ull * n + 15) & ~15ull) + 8ull * n + 12ull * n) + 255) & ~255ull;
+uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts) {
+  return Workspace{nullptr, n, attempts ? attempts : 1}.bytes();
 }
 
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
@@ -403,25 +449,32 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   if (n_frames == 0) return SVC_OK;
   if (p.cluster_count > kMaxK)
     return fail(SVC_ERR_UNSUPPORTED, "segment: cluster_count %u exceeds %u", p.cluster_count, kMaxK);
+  if (p.attempt_count > kMaxAttempts)
+    return fail(SVC_ERR_UNSUPPORTED, "segment: attempt_count %u exceeds %u", p.attempt_count, kMaxAttempts);
   SegArgs a;
   a.mask = d_mask;
   a.mv = d_mv;
   a.types = d_types;
   a.ws = d_ws;
   a.mfw = mfw; a.mfh = mfh; a.n = mfw * mfh;
-  a.ws_stride = segment_workspace_per_frame(a.n);
+  a.ws_stride = segment_workspace_per_frame(a.n, p.attempt_count);
   a.seed = seed;
   a.eps2 = (double)p.epsilon * (double)p.epsilon;
   a.mv_bw = mv_bw; a.mv_bh = mv_bh;
   a.morph_w = p.morph_rect_w; a.morph_h = p.morph_rect_h;
   a.k = p.cluster_count; a.attempts = p.attempt_count; a.max_iter = p.max_iter_count;
   a.conn = p.connectivity;
-  const size_t lds_bytes = 7 * (((size_t)a.n + 3) & ~(size_t)3);
-  if (lds_bytes <= 120 * 1024)
-    hipLaunchKernelGGL((segment_kernel<true, 256>), dim3(n_frames), dim3(256), lds_bytes, stream, a);
-  else
-    hipLaunchKernelGGL((segment_kernel<false, 1024>), dim3(n_frames), dim3(1024), 0, stream, a);
-  return check_launch("segment_kernel");
+  const size_t n4 = ((size_t)a.n + 3) & ~(size_t)3;
+  const size_t pts_lds = (size_t)kPtsLds * sizeof(Pt);
+  const dim3 grid_a(n_frames, p.attempt_count);
+  if (5 * n4 <= 100 * 1024) {  // masks (2 B/block) and cluster ids + parents (5 B/block) fit LDS
+    hipLaunchKernelGGL((segment_attempt_kernel<true, 256>), grid_a, dim3(256), 2 * n4 + pts_lds, stream, a);
+    hipLaunchKernelGGL((segment_label_kernel<true, 256>), dim3(n_frames), dim3(256), 5 * n4, stream, a);
+  } else {
+    hipLaunchKernelGGL((segment_attempt_kernel<false, 1024>), grid_a, dim3(1024), pts_lds, stream, a);
+    hipLaunchKernelGGL((segment_label_kernel<false, 1024>), dim3(n_frames), dim3(1024), 0, stream, a);
+  }
+  return check_launch("segment kernels");
 }
 
 }  // namespace svc

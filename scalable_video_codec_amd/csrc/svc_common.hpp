@@ -92,7 +92,7 @@ int launch_decode(const float* d_planes, uint32_t n_frames, uint32_t w, uint32_t
                   uint32_t gx, uint32_t gy, uint32_t gw, uint32_t gh, float* d_bgr, hipStream_t stream);
 int launch_sse(const uint8_t* d_src, uint64_t src_stride, const float* d_rec, uint32_t n_frames, uint32_t w,
                uint32_t h, uint32_t region_w, uint32_t region_h, uint64_t* d_sse, hipStream_t stream);
-uint64_t segment_workspace_per_frame(uint32_t n);
+uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts);
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
                    uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,
                    uint32_t* d_types, hipStream_t stream);

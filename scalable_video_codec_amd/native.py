@@ -60,7 +60,7 @@ SIGNATURES = {
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
-    "svc_hip_segment_workspace_bytes": (_u64, [_u32, _u32, _u32]),
+    "svc_hip_segment_workspace_bytes": (_u64, [_u32, _u32, _u32, _u32]),
     "svc_hip_segment_frames": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, SegmentParams, _u64, _vp, _u64, _vp, _vp]),
     "svc_hip_wire_header": (C.c_int, [_u32] * 8 + [C.POINTER(WireHeader)]),
     "svc_hip_serialized_frame_bytes": (_u64, [_u32, _u32, _u32, _u32]),
@@ -184,8 +184,8 @@ def block_types_frames(mask: torch.Tensor, out: Optional[torch.Tensor] = None) -
     return out
 
 
-def segment_workspace_bytes(mfw: int, mfh: int, frames: int) -> int:
-    return int(load().svc_hip_segment_workspace_bytes(mfw, mfh, frames))
+def segment_workspace_bytes(mfw: int, mfh: int, frames: int, attempts: int = 3) -> int:
+    return int(load().svc_hip_segment_workspace_bytes(mfw, mfh, frames, attempts))
 
 
 def segment_frames(mask: torch.Tensor, mv: torch.Tensor, mfw: int, mfh: int, mv_block: int = 16, seed: int = 0,
@@ -194,7 +194,7 @@ def segment_frames(mask: torch.Tensor, mv: torch.Tensor, mfw: int, mfh: int, mv_
     frames, blocks = mask.shape
     assert blocks == mfw * mfh
     p = SegmentParams(**{**DEFAULT_SEGMENT, **params})
-    need = int(load().svc_hip_segment_workspace_bytes(mfw, mfh, frames))
+    need = int(load().svc_hip_segment_workspace_bytes(mfw, mfh, frames, p.attempt_count))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=mask.device)
     if out is None:

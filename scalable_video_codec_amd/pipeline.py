@@ -130,7 +130,7 @@ class ClipEncoder:
         if segment:
             self.segment.update(segment)
         self.mfw, self.mfh = cfg.mv_field
-        self.seg_ws = (torch.empty(native.segment_workspace_bytes(self.mfw, self.mfh, p), dtype=torch.uint8, device=device)
+        self.seg_ws = (torch.empty(native.segment_workspace_bytes(self.mfw, self.mfh, p, self.segment["attempt_count"]), dtype=torch.uint8, device=device)
                        if segmentation else None)
         self.seg_seed = cfg.seed * 1000003 + rank * 100003
         self.iters = native.ransac_iter_count(**self.ransac)
