@@ -18,6 +18,8 @@
 // connected components (a lock-free union-find: one merge sweep + one flatten sweep).  Byte
 // masks, feature points and union-find parents sit in LDS when they fit, otherwise in the
 // caller-provided global workspace (L2-resident).
+#include <cstdlib>
+
 #include "svc_common.hpp"
 
 namespace svc {
@@ -32,6 +34,8 @@ struct SegArgs {
   double eps2;
   uint32_t mfw, mfh, n, mv_bw, mv_bh;
   uint32_t morph_w, morph_h, k, attempts, max_iter, conn;
+  uint32_t pts_lds_cap;  // feature points an attempt can keep in LDS; more go to the workspace
+  uint32_t stop_after;   // diagnostic only (SVC_SEG_STOP): attempt kernel returns after phase N
 };
 
 constexpr uint32_t kMaxK = 64;
@@ -73,6 +77,18 @@ __device__ __forceinline__ double dist2_dbl(const Pt& p, const double* c) {
   s = s + dy * dy;
   s = s + dz * dz;
   return s;
+}
+
+// Sum of one int per lane over the wavefront, without touching LDS: four DPP steps leave every
+// 16-lane row holding its row sum (quad_perm, quad_perm, row_ror:4, row_ror:8), then the four
+// row sums are read back as scalars.  Returns the same value in every lane.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);  // row_ror:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+         __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // exclusive block scan of one u64 per thread (wave scan by shuffles + 4 wave totals in LDS:
@@ -195,7 +211,7 @@ struct Workspace {
   __device__ uint32_t* parent() const { return reinterpret_cast<uint32_t*>(base + off_parent()); }
 };
 
-constexpr uint32_t kPtsLds = 1024;  // feature points kept in LDS by an attempt (12 KB); more go to global
+constexpr uint32_t kPtsLds = 1024;  // feature points kept in LDS by an attempt at 1080p (12 KB, 5 workgroups/CU)
 
 // Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
 // (cv::kmeans' `attempts`), so they run side by side instead of one after the other; each
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
   morph_pass<T>(fg, tmp, a, false, tid);
   morph_pass<T>(tmp, fg, a, true, tid);
 
+  if (a.stop_after == 1) return;
   // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
   const uint32_t per = (n + T - 1) / T;
   const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
   uint32_t pos = (uint32_t)block_excl_scan<T>(local, s_scan, tid, &tot64);
   const uint32_t nf = (uint32_t)tot64;
   Pt* pts_lds = reinterpret_cast<Pt*>(dyn_lds + (LDS_ARRAYS ? 2 * n4 : 0));
-  Pt* pts = nf <= kPtsLds ? pts_lds : ws.pts(att);
+  Pt* pts = nf <= a.pts_lds_cap ? pts_lds : ws.pts(att);
   for (uint32_t i = c0; i < c1; ++i)
     if (fg[i] == 255) {
       if (att == 0) idx[pos] = i;
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
   __syncthreads();
   if (nf == 0) return;
   const uint32_t k = min(a.k, nf);  // :555
+  if (a.stop_after == 2) return;
 
   // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
   const uint32_t pper = (nf + T - 1) / T;
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
     }
     __syncthreads();
   }
+  if (a.stop_after == 3) return;
   if (tid < k) {
     s_c[tid][0] = (double)s_cint[tid][0];
     s_c[tid][1] = (double)s_cint[tid][1];
@@ -325,19 +344,15 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
         lab[i] = (uint8_t)bj;
         lc += (unsigned long long)(best * 256.0);
       }
-      // per-cluster sums: reduce inside the wave first, then ONE LDS atomic per wave and
-      // cluster; 64 lanes x |coord| fits int32
+      // per-cluster sums: reduce inside the wave first (DPP, no LDS traffic: same-address LDS
+      // atomics from 64 lanes serialise, and shuffle reductions load the LDS crossbar), then ONE
+      // LDS atomic per wave and cluster; 64 lanes x |coord| fits int32 for |coord| < 2^24
       for (uint32_t j = 0; j < k; ++j) {
         const bool mine = bj == j;
         const unsigned long long bal = __ballot(mine);
         if (bal == 0) continue;
-        int sx = mine ? p.f[0] : 0, sy = mine ? p.f[1] : 0, sz = mine ? p.f[2] : 0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          sx += __shfl_xor(sx, off, 64);
-          sy += __shfl_xor(sy, off, 64);
-          sz += __shfl_xor(sz, off, 64);
-        }
+        const int sx = wave_sum_i32(mine ? p.f[0] : 0), sy = wave_sum_i32(mine ? p.f[1] : 0),
+                  sz = wave_sum_i32(mine ? p.f[2] : 0);
         if (lane == 0) {
           atomicAdd(&s_cnt[j], (uint32_t)__popcll(bal));
           atomicAdd(&s_sum[j][0], (unsigned long long)(long long)sx);
@@ -373,8 +388,9 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
 
 // Kernel B: one workgroup per frame.  Takes the attempt with the smallest compactness (ties ->
 // the earlier attempt), then connected components per cluster, numbered as the reference
-// numbers them (:597-623).  LDS_ARRAYS: cluster ids + union-find parents in LDS (5 B per block).
-template <bool LDS_ARRAYS, uint32_t T>
+// numbers them (:597-623).  LDS_PARENT / LDS_CL: union-find parents (4 B per block) and cluster
+// ids (1 B per block) in LDS; at 4K only the parents fit (130 KB).
+template <bool LDS_PARENT, bool LDS_CL, uint32_t T>
 __global__ __launch_bounds__(T) void segment_label_kernel(SegArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
   __shared__ uint64_t s_scan[T / 64];
@@ -382,8 +398,8 @@ __global__ __launch_bounds__(T) void segment_label_kernel(SegArgs a) {
   uint32_t* types = a.types + (size_t)frame * n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  uint32_t* label = LDS_ARRAYS ? reinterpret_cast<uint32_t*>(dyn_lds) : ws.parent();
-  uint8_t* cl = LDS_ARRAYS ? dyn_lds + 4 * n4 : ws.cl();
+  uint32_t* label = LDS_PARENT ? reinterpret_cast<uint32_t*>(dyn_lds) : ws.parent();
+  uint8_t* cl = LDS_CL ? dyn_lds + 4 * n4 : ws.cl();
   uint32_t* idx = ws.idx();
   const uint32_t nf = *ws.nf();
 
@@ -467,12 +483,24 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   const size_t n4 = ((size_t)a.n + 3) & ~(size_t)3;
   const size_t pts_lds = (size_t)kPtsLds * sizeof(Pt);
   const dim3 grid_a(n_frames, p.attempt_count);
-  if (5 * n4 <= 100 * 1024) {  // masks (2 B/block) and cluster ids + parents (5 B/block) fit LDS
+  const char* stop = getenv("SVC_SEG_STOP");
+  a.stop_after = stop ? (uint32_t)atoi(stop) : 0;
+  constexpr size_t kLdsMax = 152 * 1024;  // of the CU's 160 KB; statics take ~4 KB
+  a.pts_lds_cap = kPtsLds;
+  if (5 * n4 <= 100 * 1024) {  // small fields (1080p: 8 160 blocks): everything in LDS, 256 lanes
     hipLaunchKernelGGL((segment_attempt_kernel<true, 256>), grid_a, dim3(256), 2 * n4 + pts_lds, stream, a);
-    hipLaunchKernelGGL((segment_label_kernel<true, 256>), dim3(n_frames), dim3(256), 5 * n4, stream, a);
-  } else {
-    hipLaunchKernelGGL((segment_attempt_kernel<false, 1024>), grid_a, dim3(1024), pts_lds, stream, a);
-    hipLaunchKernelGGL((segment_label_kernel<false, 1024>), dim3(n_frames), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL((segment_label_kernel<true, true, 256>), dim3(n_frames), dim3(256), 5 * n4, stream, a);
+  } else {  // big fields (4K: 32 400 blocks): 1024 lanes, LDS for whatever fits
+    if (2 * n4 + pts_lds <= kLdsMax) {  // one workgroup per CU anyway: give the points the rest of the LDS
+      a.pts_lds_cap = (uint32_t)((kLdsMax - 2 * n4) / sizeof(Pt));
+      hipLaunchKernelGGL((segment_attempt_kernel<true, 1024>), grid_a, dim3(1024), 2 * n4 + a.pts_lds_cap * sizeof(Pt), stream, a);
+    } else {
+      hipLaunchKernelGGL((segment_attempt_kernel<false, 1024>), grid_a, dim3(1024), pts_lds, stream, a);
+    }
+    if (4 * n4 <= kLdsMax - 4096)
+      hipLaunchKernelGGL((segment_label_kernel<true, false, 1024>), dim3(n_frames), dim3(1024), 4 * n4, stream, a);
+    else
+      hipLaunchKernelGGL((segment_label_kernel<false, false, 1024>), dim3(n_frames), dim3(1024), 0, stream, a);
   }
   return check_launch("segment kernels");
 }

@@ -65,3 +65,14 @@ def test_segment_edge_cases(native, oracle):
     with pytest.raises(native.SvcError) as e:
         native.segment_frames(torch.from_numpy(one[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh, connectivity=6)
     assert e.value.status == native.SVC_ERR_INVALID_ARG
+
+
+def test_segment_unpacked_accumulator_path(native, oracle):
+    """|mv.x| > 1023 (never produced by block matching) takes the shuffle-based accumulation path."""
+    rng = np.random.default_rng(17)
+    mfw, mfh = 40, 30
+    mask, mv = _scene(rng, mfw, mfh, 3, 0.02)
+    mv[mask == 0, 0] *= 400.0
+    got = native.segment_frames(torch.from_numpy(mask[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh,
+                                seed=21).cpu().numpy()[0]
+    assert np.array_equal(got.astype(np.uint32), oracle.segment(mask, mv, mfw, mfh, seed=21))
