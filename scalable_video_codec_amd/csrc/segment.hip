@@ -36,6 +36,7 @@ struct SegArgs {
   uint32_t morph_w, morph_h, k, attempts, max_iter, conn;
   uint32_t pts_lds_cap;  // feature points an attempt can keep in LDS; more go to the workspace
   uint32_t stop_after;   // diagnostic only (SVC_SEG_STOP): attempt kernel returns after phase N
+  uint32_t small_coords; // host check: x_px, y_px < 2^14, so squared distances fit 32 bits
 };
 
 constexpr uint32_t kMaxK = 64;
@@ -69,6 +70,14 @@ __device__ __forceinline__ uint64_t dist2_int(const Pt& a, const int* c) {
     s += (uint64_t)(t * t);
   }
   return s;
+}
+
+// Same value with 32-bit arithmetic: valid when every coordinate difference is < 2^15 in
+// magnitude and |mv.x| differences < 2^15 too (three squares < 2^30 each... the host checks the
+// frame size, the kernel checks mv.x), which covers every real frame.
+__device__ __forceinline__ uint32_t dist2_u32(const Pt& a, const int* c) {
+  const int dx = a.f[0] - c[0], dy = a.f[1] - c[1], dz = a.f[2] - c[2];
+  return (uint32_t)(dx * dx) + (uint32_t)(dy * dy) + (uint32_t)(dz * dz);
 }
 
 __device__ __forceinline__ double dist2_dbl(const Pt& p, const double* c) {
@@ -281,13 +290,39 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
     s_cint[0][0] = p.f[0]; s_cint[0][1] = p.f[1]; s_cint[0][2] = p.f[2];
   }
   __syncthreads();
-  for (uint32_t j = 1; j < k; ++j) {  // k-means++: next centre with probability ~ min dist^2
+  // k-means++: the next centre is drawn with probability ~ (distance to the nearest chosen
+  // centre)^2.  Each point's running minimum is kept across steps (in the LDS that held the
+  // masks, which are dead now, or in the workspace), so a step costs ONE new distance per point;
+  // 32-bit arithmetic when the coordinates allow (same integers either way).
+  uint32_t* dmin32 = reinterpret_cast<uint32_t*>(LDS_ARRAYS && 4 * (size_t)nf <= 2 * n4 ? fg : ws.masks(att));
+  bool use32 = a.small_coords != 0 && 4 * (size_t)nf <= 2 * (size_t)n;  // workspace slot is 2n bytes too
+  {
+    bool ok = true;
+    for (uint32_t i = tid; i < nf; i += T) ok = ok && pts[i].f[0] > -8192 && pts[i].f[0] < 8192;
+    __shared__ uint32_t s_ok;
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    if (!ok) s_ok = 0;
+    __syncthreads();
+    use32 = use32 && s_ok != 0;
+  }
+  if (use32)
+    for (uint32_t i = p0; i < p1; ++i) dmin32[i] = 0xFFFFFFFFu;
+  for (uint32_t j = 1; j < k; ++j) {
     uint64_t lsum = 0;
-    for (uint32_t i = p0; i < p1; ++i) {
-      const Pt p = pts[i];
-      uint64_t m = ~0ull;
-      for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
-      lsum += m;
+    if (use32) {
+      for (uint32_t i = p0; i < p1; ++i) {  // a lane only ever touches its own contiguous range
+        const uint32_t m = min(dmin32[i], dist2_u32(pts[i], s_cint[j - 1]));
+        dmin32[i] = m;
+        lsum += m;
+      }
+    } else {
+      for (uint32_t i = p0; i < p1; ++i) {
+        const Pt p = pts[i];
+        uint64_t m = ~0ull;
+        for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+        lsum += m;
+      }
     }
     uint64_t total;
     const uint64_t excl = block_excl_scan<T>(lsum, s_scan, tid, &total);
@@ -298,9 +333,14 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
       if (r >= excl && r < excl + lsum) {  // exactly one lane owns the crossing
         uint64_t acc = excl;
         for (uint32_t i = p0; i < p1; ++i) {
-          const Pt p = pts[i];
-          uint64_t m = ~0ull;
-          for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+          uint64_t m;
+          if (use32) {
+            m = dmin32[i];
+          } else {
+            const Pt p = pts[i];
+            m = ~0ull;
+            for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+          }
           acc += m;
           if (acc > r) { s_pick = i; break; }
         }
@@ -483,6 +523,7 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   const size_t n4 = ((size_t)a.n + 3) & ~(size_t)3;
   const size_t pts_lds = (size_t)kPtsLds * sizeof(Pt);
   const dim3 grid_a(n_frames, p.attempt_count);
+  a.small_coords = ((uint64_t)mfw * mv_bw < (1u << 14) && (uint64_t)mfh * mv_bh < (1u << 14)) ? 1u : 0u;
   const char* stop = getenv("SVC_SEG_STOP");
   a.stop_after = stop ? (uint32_t)atoi(stop) : 0;
   constexpr size_t kLdsMax = 152 * 1024;  // of the CU's 160 KB; statics take ~4 KB
