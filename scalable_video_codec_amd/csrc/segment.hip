@@ -18,8 +18,6 @@
 // connected components (a lock-free union-find: one merge sweep + one flatten sweep).  Byte
 // masks, feature points and union-find parents sit in LDS when they fit, otherwise in the
 // caller-provided global workspace (L2-resident).
-#include <cstdlib>
-
 #include "svc_common.hpp"
 
 namespace svc {
@@ -35,7 +33,6 @@ struct SegArgs {
   uint32_t mfw, mfh, n, mv_bw, mv_bh;
   uint32_t morph_w, morph_h, k, attempts, max_iter, conn;
   uint32_t pts_lds_cap;  // feature points an attempt can keep in LDS; more go to the workspace
-  uint32_t stop_after;   // diagnostic only (SVC_SEG_STOP): attempt kernel returns after phase N
   uint32_t small_coords; // host check: x_px, y_px < 2^14, so squared distances fit 32 bits
 };
 
@@ -257,7 +254,6 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
   morph_pass<T>(fg, tmp, a, false, tid);
   morph_pass<T>(tmp, fg, a, true, tid);
 
-  if (a.stop_after == 1) return;
   // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
   const uint32_t per = (n + T - 1) / T;
   const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
@@ -278,7 +274,6 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
   __syncthreads();
   if (nf == 0) return;
   const uint32_t k = min(a.k, nf);  // :555
-  if (a.stop_after == 2) return;
 
   // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
   const uint32_t pper = (nf + T - 1) / T;
@@ -353,7 +348,6 @@ __global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
     }
     __syncthreads();
   }
-  if (a.stop_after == 3) return;
   if (tid < k) {
     s_c[tid][0] = (double)s_cint[tid][0];
     s_c[tid][1] = (double)s_cint[tid][1];
@@ -524,8 +518,6 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   const size_t pts_lds = (size_t)kPtsLds * sizeof(Pt);
   const dim3 grid_a(n_frames, p.attempt_count);
   a.small_coords = ((uint64_t)mfw * mv_bw < (1u << 14) && (uint64_t)mfh * mv_bh < (1u << 14)) ? 1u : 0u;
-  const char* stop = getenv("SVC_SEG_STOP");
-  a.stop_after = stop ? (uint32_t)atoi(stop) : 0;
   constexpr size_t kLdsMax = 152 * 1024;  // of the CU's 160 KB; statics take ~4 KB
   a.pts_lds_cap = kPtsLds;
   if (5 * n4 <= 100 * 1024) {  // small fields (1080p: 8 160 blocks): everything in LDS, 256 lanes

@@ -97,3 +97,29 @@ def test_dct_energy_dc_and_quant_properties(native, encoded):
     bg = (enc.types == 0).reshape(n, 1, enc.ph // 16, 1, enc.pw // 16, 1).expand(n, 3, enc.ph // 16, 16, enc.pw // 16, 16)
     bgc = q.reshape(n, 3, enc.ph // 16, 16, enc.pw // 16, 16)[bg]
     assert bool((bgc % cfg.bg_step == 0).all())
+
+
+def test_chunked_schedule_and_wire_mode_agree_with_the_plain_step(native):
+    """The two-stream chunked schedule and the fused record output are scheduling / layout choices:
+    every output must be identical to the single-launch planar step."""
+    cfg = configs.C2
+    dev = torch.device("cuda")
+    n = 9
+    clip = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
+    pw, ph = cfg.padded
+    frames = [synth.pad_frame(clip.frame_bgr(t), pw, ph) for t in range(n)]
+    base = pipeline.ClipEncoder(cfg, n, dev)
+    base.load_frames(frames)
+    base.step()
+    chunked = pipeline.ClipEncoder(cfg, n, dev)
+    chunked.load_frames(frames)
+    chunked.step(chunks=3)
+    wired = pipeline.ClipEncoder(cfg, n, dev, wire=True)
+    wired.load_frames(frames)
+    wired.step()
+    torch.cuda.synchronize()
+    for name in ("mv", "mad", "gm", "rmse", "mask", "count", "types", "coeffs"):
+        assert torch.equal(getattr(base, name), getattr(chunked, name)), name
+    assert torch.equal(base.types, wired.types)
+    want = native.serialize_frames(base.coeffs, base.types, pw, ph, 8, 8, base.mfw, base.mfh)
+    assert torch.equal(wired.records, want)
