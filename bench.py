@@ -256,7 +256,7 @@ def main() -> None:
             out.pop("roofline_dct")
         if "hbma_wave" in (enc.hbma_kernel_name or ""):
             out["roofline"]["kernel"] = "hbma_wave_level_kernel (LDS-staged wave-per-block search)"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, frames)
             if out["cpu_baseline"]["value"]:
                 out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
