@@ -129,6 +129,8 @@ def main() -> None:
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
+    ap.add_argument("--overlap", action="store_true",
+                    help="software-pipeline consecutive passes on two streams (back end of pass s beside the front end of pass s+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -169,8 +171,15 @@ def main() -> None:
     del clip
     torch.cuda.synchronize()
 
+    def one_step(timed=False):
+        if args.overlap:
+            enc.step_overlapped(timed=timed)
+        else:
+            enc.step(timed=timed, chunks=args.chunks)
+
     for _ in range(args.warmup):
-        enc.step(chunks=args.chunks)
+        one_step()
+    enc.finish_overlapped()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,7 +187,8 @@ def main() -> None:
     enc.reset_kernel_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        enc.step(timed=True, chunks=args.chunks)
+        one_step(timed=True)
+    enc.finish_overlapped()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -230,6 +240,7 @@ def main() -> None:
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
                 "chunks_per_step": args.chunks,
+                "schedule": "two-stream software pipeline across passes" if args.overlap else "one stream, passes back to back",
                 "parallelism": f"frame-sharded x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} halo (1 pyramid/rank/step)" if world > 1 else ""),
             },
             "roofline": {

@@ -184,6 +184,83 @@ class ClipEncoder:
         """Ring-less neighbour shift: my last pyramid -> rank+1's halo slot (RCCL over xGMI)."""
         halo_exchange(self.pyr, self.stride, self.n, self.rank, self.world)
 
+    # -- software-pipelined schedule ---------------------------------------------------------
+    def _ensure_overlap_buffers(self) -> None:
+        if getattr(self, "_ov", None) is not None:
+            return
+        names = ("mv", "mad", "gm", "rmse", "mask", "count", "types")
+        # parity 0 = the ordinary buffers, parity 1 = a second set (small: ~50 KB per frame)
+        self._ov = [{n: getattr(self, n) for n in names},
+                    {n: torch.empty_like(getattr(self, n)) for n in names}]
+        self._ov[1]["gm"].zero_()
+        self._front = torch.cuda.Stream(device=self.dev)
+        self._back = torch.cuda.Stream(device=self.dev)
+        self._front_done = [None, None]
+        self._back_done = [None, None]
+        self._ov_step = 0
+
+    def step_overlapped(self, timed: bool = False) -> None:
+        """One pass, software-pipelined across passes as a streaming encoder would run: the front end
+        of this pass (luma + pyramid, halo, motion search) goes to one HIP stream, its back end
+        (RANSAC, segmentation, transform) to another, so the back end of pass s overlaps the front
+        end of pass s + 1.  The per-frame outputs that cross the two halves are double-buffered.
+        Call finish_overlapped() before reading results or stopping the clock."""
+        self._ensure_overlap_buffers()
+        c = self.cfg
+        b = self._ov_step & 1
+        buf = self._ov[b]
+        t0 = 0 if self.has_halo else 1
+        with torch.cuda.stream(self._front):
+            if self._back_done[b] is not None:      # pass s - 2 must have released buffer set b
+                self._front.wait_event(self._back_done[b])
+            with self._timed("luma_pyramid", timed):
+                native.luma_pyramid_frames(self.bgr, self.levels, out=self.pyr[self.stride:], stride=self.stride)
+            with self._timed("halo_exchange", timed and self.world > 1):
+                self.exchange_halo()
+            with self._timed("hbma", timed):
+                native.hbma_pairs(self.pyr[t0 * self.stride:], self.pyr[(t0 + 1) * self.stride:], self.stride,
+                                  self.pairs_per_step, self.levels, self.pw, self.ph, c.search_range,
+                                  c.mv_block, c.mv_block, out=(buf["mv"], buf["mad"]))
+            ev = torch.cuda.Event()
+            ev.record(self._front)
+            self._front_done[b] = ev
+        with torch.cuda.stream(self._back):
+            self._back.wait_event(self._front_done[b])
+            with self._timed("ransac", timed):
+                native.ransac_frames(buf["mv"], self.samples, out=(buf["gm"], buf["rmse"], buf["mask"], buf["count"]),
+                                     **self.ransac)
+            if self.segmentation:
+                with self._timed("segment", timed):
+                    native.segment_frames(buf["mask"], buf["mv"], self.mfw, self.mfh, c.mv_block, seed=self.seg_seed,
+                                          out=buf["types"], workspace=self.seg_ws, **self.segment)
+            else:
+                with self._timed("block_types", timed):
+                    native.block_types_frames(buf["mask"], out=buf["types"])
+            if c.dct_block:
+                with self._timed("dct_quant", timed):
+                    if self.wire:
+                        native.dct_records_frames(self.bgr[self.first_encoded:], c.dct_block, buf["types"], c.mv_block,
+                                                  c.fg_step, c.bg_step, out=self.records)
+                    else:
+                        native.dct_quant_frames(self.bgr[self.first_encoded:], c.dct_block, buf["types"], c.mv_block,
+                                                c.fg_step, c.bg_step, out=self.coeffs)
+            ev = torch.cuda.Event()
+            ev.record(self._back)
+            self._back_done[b] = ev
+        self._ov_step += 1
+        self._steps_timed += 1 if timed else 0
+
+    def finish_overlapped(self) -> None:
+        """Joins both streams into the current one and points the result attributes at the newest buffers."""
+        if getattr(self, "_ov", None) is None:
+            return
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._front)
+        cur.wait_stream(self._back)
+        if self._ov_step:
+            for n, t in self._ov[(self._ov_step - 1) & 1].items():
+                setattr(self, n, t)
+
     def step(self, timed: bool = False, chunks: int = 1) -> None:
         """One pass over the clip.  chunks > 1 cuts the clip into consecutive chunks and runs
         the transform of chunk k on a second HIP stream while the front (luma, pyramid, motion

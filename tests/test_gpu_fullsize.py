@@ -118,8 +118,15 @@ def test_chunked_schedule_and_wire_mode_agree_with_the_plain_step(native):
     wired.load_frames(frames)
     wired.step()
     torch.cuda.synchronize()
+    piped = pipeline.ClipEncoder(cfg, n, dev)
+    piped.load_frames(frames)
+    for _ in range(3):  # three passes in flight across the two streams
+        piped.step_overlapped()
+    piped.finish_overlapped()
+    torch.cuda.synchronize()
     for name in ("mv", "mad", "gm", "rmse", "mask", "count", "types", "coeffs"):
         assert torch.equal(getattr(base, name), getattr(chunked, name)), name
+        assert torch.equal(getattr(base, name), getattr(piped, name)), f"overlapped {name}"
     assert torch.equal(base.types, wired.types)
     want = native.serialize_frames(base.coeffs, base.types, pw, ph, 8, 8, base.mfw, base.mfh)
     assert torch.equal(wired.records, want)
