@@ -285,8 +285,10 @@ bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, ui
   const uint32_t rt = range >> (levels - 1);
   if (rt != 1 && rt != 2) return false;
   const uint32_t tw = w >> (levels - 1), th = h >> (levels - 1), tb = 16u >> (levels - 1);
-  // the top plane must hold a whole candidate grid (clamped loads stay in the row)
-  return tw >= tb + 8 && tw >= 12 && th >= tb + 2 * rt && (w % 16 == 0) && (h % 16 == 0);
+  // the top plane must hold a whole candidate grid, and its rows must be dword-aligned: the
+  // clamped top-level loads (load_row<.., true>) only leave needed bytes alone when the row
+  // width is a multiple of 4 (found by tests/test_gpu_hbma_property.py: 112 x 32, 4 levels)
+  return tw >= tb + 8 && tw >= 12 && tw % 4 == 0 && th >= tb + 2 * rt && (w % 16 == 0) && (h % 16 == 0);
 }
 
 int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,

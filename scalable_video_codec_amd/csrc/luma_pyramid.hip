@@ -162,8 +162,12 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
   const uint8_t* src = a.bgr + (size_t)frame * a.frame_stride;
   uint8_t* y_plane = a.pyr + (size_t)frame * a.pyr_stride;
 
+  // Rows past y = h are never needed (the last level-1 row is centred on h - 2, its taps end at
+  // row h) and must not be touched: reflect101 folds once, so a row further out would index
+  // outside the frame (short frames: found by tests/test_gpu_misc_property.py).
+  const int rows = min(kTH + 4, h - y0 + 3);  // LDS rows 0 .. rows-1 <-> y = y0 - 2 .. min(y0 + 33, h)
   // (a) segment tasks: 16 pixels of one row -> 4 dwords of LDS (+ the level-0 store)
-  for (int task = (int)tid; task < (kTH + 4) * segs; task += 256) {
+  for (int task = (int)tid; task < rows * segs; task += 256) {
     const int r = task / segs, sgm = task - r * segs;
     const int y = y0 - 2 + r, yr = reflect101(y, h);
     const int x = x0 + sgm * 16;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
   }
   // (b) halo pixels: two columns on each side of the valid part, every row
-  for (int task = (int)tid; task < (kTH + 4) * 4; task += 256) {
+  for (int task = (int)tid; task < rows * 4; task += 256) {
     const int r = task >> 2, k = task & 3;
     const int yr = reflect101(y0 - 2 + r, h);
     const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);

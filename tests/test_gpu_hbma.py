@@ -135,7 +135,9 @@ def test_empty_batches_are_noops(native):
 def test_tiny_frames_fall_back_to_the_general_kernel(native, oracle):
     """Frames too small for the fused kernel's candidate grid (top plane < block + 2 R_top) still work."""
     rng = np.random.default_rng(4)
-    for w, h, levels in ((16, 16, 3), (32, 16, 3), (48, 32, 4), (16, 48, 1)):
+    # (112, 32, 4): top plane 14 px wide, not dword-aligned -> the fused kernel must decline
+    # (regression, found by tests/test_gpu_hbma_property.py)
+    for w, h, levels in ((16, 16, 3), (32, 16, 3), (48, 32, 4), (16, 48, 1), (112, 32, 4), (176, 64, 4)):
         t, a = util.random_planes(rng, w, h, levels), util.random_planes(rng, w, h, levels)
         exp_mv, exp_mad = oracle.hbma(t, a, 8, 16, 16)
         mv, mad = native.hbma_host(t, a, 8, 16, 16)

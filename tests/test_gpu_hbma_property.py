@@ -1,0 +1,71 @@
+"""Randomised shapes for the motion search (hypothesis): any block size, search range, level
+count and frame size the reference accepts must give the oracle's MVs and min-MADs bit for bit,
+through whichever kernel the dispatcher picks and through the forced general kernel."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+
+@st.composite
+def hbma_case(draw):
+    levels = draw(st.integers(1, 4))
+    f = 1 << (levels - 1)
+    bw = f * draw(st.integers(1, 32 // f))
+    bh = f * draw(st.integers(1, 32 // f))
+    nbx, nby = draw(st.integers(1, 6)), draw(st.integers(1, 5))
+    r = draw(st.integers(f, max(f, 12)))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    kind = draw(st.sampled_from(["noise", "shifted", "flat", "periodic"]))
+    return levels, bw, bh, bw * nbx, bh * nby, r, seed, kind
+
+
+def _planes(kind, rng, w, h, levels):
+    if kind == "flat":
+        base_t = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+        base_a = base_t.copy()
+    elif kind == "periodic":
+        yy, xx = np.mgrid[0:h, 0:w]
+        p = int(rng.integers(1, 4))
+        base_t = ((((xx // p) % 2) * 150 + ((yy // p) % 2) * 70) % 256).astype(np.uint8)
+        base_a = np.roll(base_t, (int(rng.integers(-2, 3)), int(rng.integers(-2, 3))), (0, 1))
+    else:
+        base_t = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        base_a = (np.roll(base_t, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), (0, 1))
+                  if kind == "shifted" else rng.integers(0, 256, (h, w), dtype=np.uint8))
+
+    def pyr(b):
+        out = [b]
+        for _ in range(levels - 1):
+            out.append(np.ascontiguousarray(out[-1][::2, ::2]))
+        return out
+    return pyr(base_t), pyr(base_a)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+@given(case=hbma_case())
+def test_hbma_random_shapes(native, oracle, case):
+    levels, bw, bh, w, h, r, seed, kind = case
+    t, a = _planes(kind, np.random.default_rng(seed), w, h, levels)
+    exp_mv, exp_mad = oracle.hbma(t, a, r, bw, bh)
+    for flags in (native.HBMA_AUTO, native.HBMA_FORCE_WAVE_PER_BLOCK):
+        mv, mad = native.hbma_host(t, a, r, bw, bh, flags=flags)
+        assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (case, flags)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+@given(levels=st.sampled_from([3, 4]), rt=st.sampled_from([1, 2]), nbx=st.integers(2, 9), nby=st.integers(1, 6),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["noise", "shifted", "flat", "periodic"]))
+def test_fused_kernel_random_frames(native, oracle, levels, rt, nbx, nby, seed, kind):
+    """The fused 16x16 kernel on small odd-shaped fields: every block near a border."""
+    w, h = 16 * nbx, 16 * nby
+    r = rt << (levels - 1)
+    t, a = _planes(kind, np.random.default_rng(seed), w, h, levels)
+    exp_mv, exp_mad = oracle.hbma(t, a, r, 16, 16)
+    try:
+        mv, mad = native.hbma_host(t, a, r, 16, 16, flags=native.HBMA_FORCE_FUSED)
+    except native.SvcError as e:  # too small for the fused kernel's candidate grid: must say so, not guess
+        assert e.status == native.SVC_ERR_UNSUPPORTED
+        mv, mad = native.hbma_host(t, a, r, 16, 16)
+    assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (levels, rt, w, h, kind)

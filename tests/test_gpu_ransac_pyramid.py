@@ -72,7 +72,9 @@ def test_ransac_frames_batched(native, oracle):
         assert np.array_equal(oracle.fg_mask(inl_o, n) == 0, mask[f].cpu().numpy() == 1)
 
 
-@pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4)])
+# the last three are regressions: frames shorter than one 32-row LDS tile (rows beyond the frame
+# must not be reflected twice), found by tests/test_gpu_misc_property.py
+@pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4), (64, 16, 2), (32, 8, 3), (128, 2, 2)])
 def test_luma_pyramid(native, w, h, levels):
     clip = synth.SynthClip(w, h, 2, 42, device="cpu")
     frames = [clip.frame_bgr(t) for t in range(2)]
