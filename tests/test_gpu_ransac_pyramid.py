@@ -76,8 +76,8 @@ def test_ransac_frames_batched(native, oracle):
 # must not be reflected twice), found by tests/test_gpu_misc_property.py
 @pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4), (64, 16, 2), (32, 8, 3), (128, 2, 2)])
 def test_luma_pyramid(native, w, h, levels):
-    clip = synth.SynthClip(w, h, 2, 42, device="cpu")
-    frames = [clip.frame_bgr(t) for t in range(2)]
+    rng = np.random.default_rng(w * 31 + h)
+    frames = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for _ in range(2)]
     bgr = torch.stack(frames).cuda()
     buf, stride = native.luma_pyramid_frames(bgr, levels)
     torch.cuda.synchronize()
