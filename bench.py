@@ -251,6 +251,8 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": hbma_bytes / nl["hbma"],
                 "avg_launch_ms": kt["hbma"] / nl["hbma"],
                 "launches_per_step": nl["hbma"],
+                "note": "HBM is the stated bound; measured VALU busy ~86 % (byte-SAD ops issue at 4 cycles/wave): "
+                        "VALU time ~= HBM floor, see DESIGN.md 4.1",
             },
             "roofline_dct": {
                 "kernel": f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)",

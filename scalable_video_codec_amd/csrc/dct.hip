@@ -5,11 +5,14 @@
 // it, the decoder's quant lines (libs/decoder.cpp:130-144).  cv::dct(flags = 0) is
 // the orthonormal DCT-II, Y = C X C^T.
 //
-// Bound: HBM.  3 B/pixel in, 12 B/pixel out, 4N flops/sample: 6.4 flop/B (N = 8),
-// 12.8 (N = 16) -- far under any compute ridge, so the arithmetic is done in float64
-// and rounded to f32 once.  That puts every coefficient within 1/2 ulp(f32) of the
-// exact value, well inside the 1e-4 * max(1, |ref|) parity bar that plain f32
-// accumulation misses for small AC coefficients of bright tiles.
+// Bound: HBM (3 B/pixel in, 12 B/pixel out; measured 5.45 TB/s at N = 8, 87 % of the chip's
+// copy rate) -- but only after the arithmetic was trimmed: f64 issues at 4 cycles per wave
+// instruction on gfx950, and the first version (f64 butterflies, IEEE f32 divide + roundf in the
+// quantiser, ~60 issue cycles per coefficient) was VALU-bound with the VALU ~100 % busy.
+// float64 is still the right precision: rounding once to f32 puts every coefficient within
+// 1/2 ulp(f32) of the exact value, well inside the 1e-4 * max(1, |ref|) parity bar that plain
+// f32 accumulation misses for small AC coefficients of bright tiles; the even/odd split of
+// the basis halves the multiplies, and the butterflies of the row pass run in f32 (exact).
 //
 // Shape.  The unit of work is a "segment column": 16 pixels wide x N rows tall x 3
 // channels (two 8x8 tiles or one 16x16 tile per channel).  N consecutive lanes own
