@@ -64,6 +64,32 @@ int main(int argc, char** argv) {
   const uint n = static_cast<uint>(inliers.size());
   std::fwrite(&n, 4, 1, o);
   std::fwrite(inliers.data(), 4, n, o);
+#ifdef SVC_MOTION_HPP
+  // Only with this repo's header: the additions that have no counterpart in the reference's
+  // motion.hpp.  A seeded RANSAC run (must repeat exactly), then Dct + QuantizeDequantize on a
+  // fixed 48 x 32 pattern.
+  float rmse2[2];
+  Vec2f gm2[2];
+  std::vector<uint> inl2[2];
+  for (int k = 0; k < 2; ++k) {
+    SvcSeedRansac(12345u);
+    gm2[k] = Vec2f{0.f, 0.f};
+    EstimateGlobalMotionRansac(mv.data(), static_cast<uint>(mv.size()), params, &rmse2[k], &gm2[k], &inl2[k]);
+  }
+  const uint same = (gm2[0].x == gm2[1].x && gm2[0].y == gm2[1].y && rmse2[0] == rmse2[1] && inl2[0] == inl2[1]) ? 1u : 0u;
+  std::fwrite(&same, 4, 1, o);
+  const uint dw = 48, dh = 32;
+  std::vector<uchar> bgr(dw * dh * 3);
+  for (uint y = 0; y < dh; ++y)
+    for (uint x = 0; x < dw; ++x)
+      for (uint c = 0; c < 3; ++c) bgr[(y * dw + x) * 3 + c] = static_cast<uchar>((x * 7 + y * 13 + c * 29) & 255);
+  std::vector<float> planes(3 * dw * dh);
+  float* pp[3] = {planes.data(), planes.data() + dw * dh, planes.data() + 2 * dw * dh};
+  Dct(bgr.data(), dw, dh, 8, 8, pp);
+  std::fwrite(planes.data(), 4, planes.size(), o);
+  QuantizeDequantize(planes.data(), planes.size(), 640);
+  std::fwrite(planes.data(), 4, planes.size(), o);
+#endif
   std::fclose(o);
   return 0;
 }

@@ -35,6 +35,7 @@ def _run(exe, cfg, tmp_path):
     rmse = np.frombuffer(raw, np.float32, 1, 12 * b + 8)[0]
     n = int(np.frombuffer(raw, np.uint32, 1, 12 * b + 12)[0])
     inl = np.frombuffer(raw, np.uint32, n, 12 * b + 16)
+    _run.extra = raw[12 * b + 16 + 4 * n:]
     return mv, mad, gm, rmse, inl
 
 
@@ -57,3 +58,18 @@ def test_dropin_binary(native, exe, cfg, tmp_path):
         d = (mv[i] - gm).astype(np.float32)
         acc = np.float32(acc + np.float32(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1])))
     assert np.float32(np.sqrt(np.float32(acc / np.float32(len(inl))))).tobytes() == np.float32(rmse).tobytes()
+
+
+def test_dropin_additions(native, oracle, tmp_path):
+    """SvcSeedRansac makes a thread's draws repeat; Dct / QuantizeDequantize through the C++ wrappers."""
+    _run("dropin_own_hdr", configs.C2, tmp_path)
+    extra = _run.extra
+    assert struct.unpack("<I", extra[:4])[0] == 1
+    dw, dh = 48, 32
+    yy, xx, cc = np.meshgrid(np.arange(dh), np.arange(dw), np.arange(3), indexing="ij")
+    bgr = ((xx * 7 + yy * 13 + cc * 29) & 255).astype(np.uint8)
+    planes = np.frombuffer(extra, np.float32, 3 * dw * dh, 4).reshape(3, dh, dw)
+    ref = oracle.dct_frame_f64(bgr, 8, 8)
+    assert (np.abs(planes - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))).all()
+    q = np.frombuffer(extra, np.float32, 3 * dw * dh, 4 + 4 * 3 * dw * dh).reshape(3, dh, dw)
+    assert q.tobytes() == oracle.quant(planes, 640).tobytes()
