@@ -130,3 +130,23 @@ def test_chunked_schedule_and_wire_mode_agree_with_the_plain_step(native):
     assert torch.equal(base.types, wired.types)
     want = native.serialize_frames(base.coeffs, base.types, pw, ph, 8, 8, base.mfw, base.mfh)
     assert torch.equal(wired.records, want)
+
+
+def test_8k_frame_pair(native, oracle):
+    """Largest realistic frame: 7680 x 4320 (129 600 MV blocks, 4-level pyramid), one pair."""
+    rng = np.random.default_rng(8)
+    w, h, levels = 7680, 4320, 4
+    base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2), dtype=np.uint8)
+    big = np.kron(base, np.ones((8, 8), np.uint8))  # blocky texture: plenty of exact ties
+    t0 = np.ascontiguousarray(big[4:4 + h, 5:5 + w])
+    a0 = np.ascontiguousarray(big[6:6 + h, 2:2 + w])
+    a0 = (a0.astype(np.int16) + rng.integers(-2, 3, a0.shape)).clip(0, 255).astype(np.uint8)
+    t = [np.ascontiguousarray(t0[:: 1 << l, :: 1 << l]) for l in range(levels)]
+    a = [np.ascontiguousarray(a0[:: 1 << l, :: 1 << l]) for l in range(levels)]
+    mv, mad = native.hbma_host(t, a, 8, 16, 16)
+    exp_mv, exp_mad = oracle.hbma16_sse2(t, a, 8)  # the reference's 4-level path, restated
+    assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad)
+    bgr = np.stack([t0, a0, t0], axis=-1)
+    planes = native.dct_host(np.ascontiguousarray(bgr[:256]), 16)  # a 256-row band of it through the host path
+    ref = oracle.dct_frame_f64(np.ascontiguousarray(bgr[:256]), 16, 16)
+    assert (np.abs(planes - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))).all()
