@@ -32,8 +32,8 @@ struct SegArgs {
   double eps2;
   uint32_t mfw, mfh, n, mv_bw, mv_bh;
   uint32_t morph_w, morph_h, k, attempts, max_iter, conn;
-  uint32_t pts_lds_cap;  // feature points an attempt can keep in LDS; more go to the workspace
-  uint32_t small_coords; // host check: x_px, y_px < 2^14, so squared distances fit 32 bits
+  uint32_t lds_bytes;    // dynamic LDS of the attempt kernel
+  uint32_t packable;     // host check: field <= 512 x 512 blocks and x_px, y_px < 2^14 (32-bit distances)
 };
 
 constexpr uint32_t kMaxK = 64;
@@ -104,8 +104,10 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int off) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-template <uint32_t T>
-__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* s_scan, uint32_t tid, uint64_t* total) {
+// exclusive block scan of one u64 per thread over the first nw waves of the workgroup (wave scan by
+// shuffles + nw wave totals in LDS: two barriers); returns this thread's prefix, *total = block sum
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* s_scan, uint32_t tid, uint32_t nw,
+                                                    uint64_t* total) {
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   uint64_t x = v;
 #pragma unroll
@@ -117,14 +119,28 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* s_scan
   if (lane == 63) s_scan[wave] = x;
   __syncthreads();
   uint64_t woff = 0, tot = 0;
-#pragma unroll
-  for (uint32_t wv = 0; wv < T / 64; ++wv) {
+  for (uint32_t wv = 0; wv < nw; ++wv) {
     const uint64_t t = s_scan[wv];
     woff += wv < wave ? t : 0;
     tot += t;
   }
   *total = tot;
   return woff + x - v;
+}
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane) {
+  uint64_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t y = shfl_up_u64(x, off);
+    if (lane >= (uint32_t)off) x += y;
+  }
+  return x;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
 }
 
 // Lock-free union-find on `parent` (LDS or global): a set's root is its smallest block index
@@ -148,9 +164,8 @@ __device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t 
   }
 }
 
-template <uint32_t T>
 __device__ __forceinline__ void morph_pass(const uint8_t* src, uint8_t* dst, const SegArgs& a, bool dilate,
-                                           uint32_t tid) {
+                                           uint32_t tid, uint32_t T) {
   const int ax = (int)a.morph_w / 2, ay = (int)a.morph_h / 2;
   if (a.morph_w == 3 && a.morph_h == 3) {  // the default element: branch-free, loads in flight together
     const int W = (int)a.mfw, H = (int)a.mfh;
@@ -192,8 +207,12 @@ __device__ __forceinline__ void morph_pass(const uint8_t* src, uint8_t* dst, con
 //   [0, 256)            header: u32 nf at 0; u64 compactness[attempt] at 8 + 8 * attempt
 //   idx      [n]  u32   foreground list, raster order (written by attempt 0's workgroup)
 //   lab      [A][n] u8  labels of each k-means attempt
-//   scratch  [A][2n] u8 + [A][n] Pt: masks / feature points of an attempt when they do not fit LDS
+//   masks    [A][2n] u8 byte masks of an attempt when they do not fit LDS
+//   pts      [A][n] Pt  feature points of an attempt when they do not fit LDS (packed points use the
+//                       first 4n bytes of the slot)
+//   dmin     [A][n] u32 k-means++ running minima when they do not fit LDS
 //   cl [n] u8, parent [n] u32: connected-components arrays when they do not fit LDS
+//   roots    [n] u32    component roots in raster order
 constexpr uint32_t kMaxAttempts = 16;
 
 struct Workspace {
@@ -204,241 +223,442 @@ struct Workspace {
   __host__ __device__ uint64_t off_lab() const { return off_idx() + a16(4ull * n); }
   __host__ __device__ uint64_t off_masks() const { return off_lab() + a16((uint64_t)attempts * n); }
   __host__ __device__ uint64_t off_pts() const { return off_masks() + a16(2ull * attempts * n); }
-  __host__ __device__ uint64_t off_cl() const { return off_pts() + a16(12ull * attempts * n); }
+  __host__ __device__ uint64_t off_dmin() const { return off_pts() + a16(12ull * attempts * n); }
+  __host__ __device__ uint64_t off_cl() const { return off_dmin() + a16(4ull * attempts * n); }
   __host__ __device__ uint64_t off_parent() const { return off_cl() + a16(n); }
-  __host__ __device__ uint64_t bytes() const { return (off_parent() + 4ull * n + 255) & ~255ull; }
+  __host__ __device__ uint64_t off_roots() const { return off_parent() + a16(4ull * n); }
+  __host__ __device__ uint64_t bytes() const { return (off_roots() + 4ull * n + 255) & ~255ull; }
   __device__ uint32_t* nf() const { return reinterpret_cast<uint32_t*>(base); }
   __device__ unsigned long long* compact() const { return reinterpret_cast<unsigned long long*>(base + 8); }
   __device__ uint32_t* idx() const { return reinterpret_cast<uint32_t*>(base + off_idx()); }
   __device__ uint8_t* lab(uint32_t a) const { return base + off_lab() + (uint64_t)a * n; }
   __device__ uint8_t* masks(uint32_t a) const { return base + off_masks() + 2ull * a * n; }
   __device__ Pt* pts(uint32_t a) const { return reinterpret_cast<Pt*>(base + off_pts() + 12ull * a * n); }
+  __device__ uint32_t* dmin(uint32_t a) const { return reinterpret_cast<uint32_t*>(base + off_dmin() + 4ull * a * n); }
   __device__ uint8_t* cl() const { return base + off_cl(); }
   __device__ uint32_t* parent() const { return reinterpret_cast<uint32_t*>(base + off_parent()); }
+  __device__ uint32_t* roots() const { return reinterpret_cast<uint32_t*>(base + off_roots()); }
 };
 
-constexpr uint32_t kPtsLds = 1024;  // feature points kept in LDS by an attempt at 1080p (12 KB, 5 workgroups/CU)
+// Both kernels are launched kTA lanes wide, which is what the field-sized sweeps (masks, morphology,
+// clears) want.  Once a frame's foreground count is known the workgroup keeps only the lanes that
+// count can feed: the rest of its waves end there (s_barrier counts surviving waves only), so the
+// hundreds of short barrier-separated k-means / labelling phases of a light frame run on one or four
+// waves while a heavy frame (a scene cut: most of the field is foreground) keeps all sixteen.
+constexpr uint32_t kTA = 1024;
 
-// Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
-// (cv::kmeans' `attempts`), so they run side by side instead of one after the other; each
-// rebuilds the (cheap) mask + foreground list for itself.
-// LDS_ARRAYS: the two byte masks live in dynamic LDS (2 B per MV block), else in the workspace.
-template <bool LDS_ARRAYS, uint32_t T>
-__global__ __launch_bounds__(T) void segment_attempt_kernel(SegArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-  __shared__ uint64_t s_scan[T / 64];
-  __shared__ int s_cint[kMaxK][3];
-  __shared__ double s_c[kMaxK][3];
-  __shared__ unsigned long long s_sum[kMaxK][3];
-  __shared__ uint32_t s_cnt[kMaxK];
-  __shared__ double s_shift[kMaxK];
-  __shared__ unsigned long long s_compact;
-  __shared__ uint32_t s_pick;
+__device__ __forceinline__ uint32_t lanes_for(uint32_t nf) { return nf <= 64 ? 64u : nf <= 1024 ? 256u : kTA; }
 
-  const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
-  const uint8_t* mask = a.mask + (size_t)frame * n;
-  const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
-  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
-  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  uint8_t* fg = LDS_ARRAYS ? dyn_lds : ws.masks(att);
-  uint8_t* tmp = LDS_ARRAYS ? dyn_lds + n4 : ws.masks(att) + n;
-  uint8_t* lab = ws.lab(att);
-  uint32_t* idx = ws.idx();
-  const uint64_t seed = a.seed + frame;
+struct KmLds {
+  uint64_t scan[kTA / 64];
+  int cint[kMaxK][3];
+  double c[kMaxK][3];
+  unsigned long long sum[kMaxK][3];
+  uint32_t cnt[kMaxK];
+  double shift[kMaxK];
+  unsigned long long compact;
+  uint32_t pick, bad;
+};
 
-  // ---- foreground mask, close, open (encoder.cpp:507-527) ---------------------------------
-  for (uint32_t i = tid; i < n; i += T) fg[i] = mask[i] ? 0 : 255;
-  __syncthreads();
-  morph_pass<T>(fg, tmp, a, true, tid);
-  morph_pass<T>(tmp, fg, a, false, tid);
-  morph_pass<T>(fg, tmp, a, false, tid);
-  morph_pass<T>(tmp, fg, a, true, tid);
+// A feature point in 32 bits: MV-block column (9 bits), row (9 bits), rounded mv.x (14 bits, signed).
+// Used when the field is at most 512 x 512 blocks and |mv.x| < 8192 -- every real frame.
+__device__ __forceinline__ uint32_t pack_pt(int mvx, uint32_t bx, uint32_t by) {
+  return bx | (by << 9) | ((uint32_t)mvx << 18);
+}
+__device__ __forceinline__ Pt unpack_pt(uint32_t v, uint32_t bw, uint32_t bh) {
+  Pt p;
+  p.f[0] = (int)v >> 18;
+  p.f[1] = (int)((v & 511u) * bw);
+  p.f[2] = (int)(((v >> 9) & 511u) * bh);
+  return p;
+}
 
-  // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
-  const uint32_t per = (n + T - 1) / T;
-  const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
-  uint32_t local = 0;
-  for (uint32_t i = c0; i < c1; ++i) local += fg[i] == 255 ? 1u : 0u;
-  uint64_t tot64;
-  uint32_t pos = (uint32_t)block_excl_scan<T>(local, s_scan, tid, &tot64);
-  const uint32_t nf = (uint32_t)tot64;
-  Pt* pts_lds = reinterpret_cast<Pt*>(dyn_lds + (LDS_ARRAYS ? 2 * n4 : 0));
-  Pt* pts = nf <= a.pts_lds_cap ? pts_lds : ws.pts(att);
-  for (uint32_t i = c0; i < c1; ++i)
-    if (fg[i] == 255) {
-      if (att == 0) idx[pos] = i;
-      pts[pos] = make_pt(mv, i, a.mfw, a.mv_bw, a.mv_bh);
-      ++pos;
-    }
-  if (att == 0 && tid == 0) *ws.nf() = nf;
-  __syncthreads();
-  if (nf == 0) return;
-  const uint32_t k = min(a.k, nf);  // :555
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
 
-  // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
-  const uint32_t pper = (nf + T - 1) / T;
-  const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
-  const uint64_t aseed = seed ^ ((uint64_t)att << 32);
+// One k-means attempt over packed points (the path every real frame takes).  `pk` and `dmin` are in
+// LDS when the foreground fits there, else in the workspace.  Returns the fixed-point compactness.
+__device__ __forceinline__ uint64_t kmeans_packed(const uint32_t* pk, uint32_t* dmin, uint8_t* lab, KmLds& L,
+                                                  const SegArgs& a, uint32_t nf, uint32_t k, uint64_t aseed,
+                                                  uint32_t tid, uint32_t te) {
+  const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t bw = a.mv_bw, bh = a.mv_bh;
   if (tid == 0) {
-    const uint32_t first = (uint32_t)(seg_hash(aseed) % nf);
-    const Pt p = pts[first];
-    s_cint[0][0] = p.f[0]; s_cint[0][1] = p.f[1]; s_cint[0][2] = p.f[2];
+    const Pt p = unpack_pt(pk[(uint32_t)(seg_hash(aseed) % nf)], bw, bh);
+    L.cint[0][0] = p.f[0]; L.cint[0][1] = p.f[1]; L.cint[0][2] = p.f[2];
   }
+  // k-means++: the next centre is drawn with probability ~ (distance to the nearest chosen centre)^2.
+  // Each point's running minimum is kept across steps, so a step costs ONE new distance per point.
+  // A wave owns a contiguous chunk of the list and its lanes interleave inside it (conflict-free LDS,
+  // coalesced global); the draw is located by wave totals first, then by a scan inside the one wave
+  // whose range holds it -- the same "first point whose inclusive prefix exceeds r" as a serial walk.
+  const uint32_t chunk = (((nf + nw - 1) / nw) + 63u) & ~63u;
+  const uint32_t w0 = min(nf, wave * chunk), w1 = min(nf, w0 + chunk);
+  for (uint32_t i = w0 + lane; i < w1; i += 64) dmin[i] = 0xFFFFFFFFu;
   __syncthreads();
-  // k-means++: the next centre is drawn with probability ~ (distance to the nearest chosen
-  // centre)^2.  Each point's running minimum is kept across steps (in the LDS that held the
-  // masks, which are dead now, or in the workspace), so a step costs ONE new distance per point;
-  // 32-bit arithmetic when the coordinates allow (same integers either way).
-  uint32_t* dmin32 = reinterpret_cast<uint32_t*>(LDS_ARRAYS && 4 * (size_t)nf <= 2 * n4 ? fg : ws.masks(att));
-  bool use32 = a.small_coords != 0 && 4 * (size_t)nf <= 2 * (size_t)n;  // workspace slot is 2n bytes too
-  {
-    bool ok = true;
-    for (uint32_t i = tid; i < nf; i += T) ok = ok && pts[i].f[0] > -8192 && pts[i].f[0] < 8192;
-    __shared__ uint32_t s_ok;
-    if (tid == 0) s_ok = 1;
-    __syncthreads();
-    if (!ok) s_ok = 0;
-    __syncthreads();
-    use32 = use32 && s_ok != 0;
-  }
-  if (use32)
-    for (uint32_t i = p0; i < p1; ++i) dmin32[i] = 0xFFFFFFFFu;
   for (uint32_t j = 1; j < k; ++j) {
+    const int c[3] = {L.cint[j - 1][0], L.cint[j - 1][1], L.cint[j - 1][2]};
     uint64_t lsum = 0;
-    if (use32) {
-      for (uint32_t i = p0; i < p1; ++i) {  // a lane only ever touches its own contiguous range
-        const uint32_t m = min(dmin32[i], dist2_u32(pts[i], s_cint[j - 1]));
-        dmin32[i] = m;
-        lsum += m;
-      }
-    } else {
-      for (uint32_t i = p0; i < p1; ++i) {
-        const Pt p = pts[i];
-        uint64_t m = ~0ull;
-        for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
-        lsum += m;
-      }
+    for (uint32_t i = w0 + lane; i < w1; i += 64) {  // a lane only ever touches its own entries of dmin
+      const uint32_t m = min(dmin[i], dist2_u32(unpack_pt(pk[i], bw, bh), c));
+      dmin[i] = m;
+      lsum += m;
     }
-    uint64_t total;
-    const uint64_t excl = block_excl_scan<T>(lsum, s_scan, tid, &total);
+    const uint64_t wtot = wave_sum_u64(lsum);
+    if (lane == 0) L.scan[wave] = wtot;
+    __syncthreads();
+    uint64_t woff = 0, total = 0;
+    for (uint32_t wv = 0; wv < nw; ++wv) {
+      const uint64_t t = L.scan[wv];
+      woff += wv < wave ? t : 0;
+      total += t;
+    }
     if (total == 0) {
-      if (tid == 0) s_pick = j < nf ? j : 0;
+      if (tid == 0) {
+        const Pt p = unpack_pt(pk[j < nf ? j : 0], bw, bh);
+        L.cint[j][0] = p.f[0]; L.cint[j][1] = p.f[1]; L.cint[j][2] = p.f[2];
+      }
     } else {
       const uint64_t r = seg_hash(aseed ^ j) % total;
-      if (r >= excl && r < excl + lsum) {  // exactly one lane owns the crossing
-        uint64_t acc = excl;
-        for (uint32_t i = p0; i < p1; ++i) {
-          uint64_t m;
-          if (use32) {
-            m = dmin32[i];
-          } else {
-            const Pt p = pts[i];
-            m = ~0ull;
-            for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, s_cint[q]));
+      if (r >= woff && r - woff < wtot) {  // wave-uniform: exactly one wave owns the crossing
+        uint64_t acc = woff;
+        for (uint32_t base = w0; base < w1; base += 64) {
+          const uint32_t i = base + lane;
+          const uint64_t incl = wave_incl_scan_u64(i < w1 ? dmin[i] : 0u, lane);
+          const unsigned long long bal = __ballot(acc + incl > r);
+          if (bal) {
+            if (lane == (uint32_t)__builtin_ctzll(bal)) {
+              const Pt p = unpack_pt(pk[i], bw, bh);
+              L.cint[j][0] = p.f[0]; L.cint[j][1] = p.f[1]; L.cint[j][2] = p.f[2];
+            }
+            break;
           }
-          acc += m;
-          if (acc > r) { s_pick = i; break; }
+          acc += readlane_u64(incl, 63);
         }
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      const Pt p = pts[s_pick];
-      s_cint[j][0] = p.f[0]; s_cint[j][1] = p.f[1]; s_cint[j][2] = p.f[2];
-    }
-    __syncthreads();
   }
   if (tid < k) {
-    s_c[tid][0] = (double)s_cint[tid][0];
-    s_c[tid][1] = (double)s_cint[tid][1];
-    s_c[tid][2] = (double)s_cint[tid][2];
+    L.c[tid][0] = (double)L.cint[tid][0];
+    L.c[tid][1] = (double)L.cint[tid][1];
+    L.c[tid][2] = (double)L.cint[tid][2];
   }
   __syncthreads();
 
   uint64_t compact = 0;
   for (uint32_t it = 0;; ++it) {  // Lloyd
-    if (tid < k) { s_sum[tid][0] = 0; s_sum[tid][1] = 0; s_sum[tid][2] = 0; s_cnt[tid] = 0; }
-    if (tid == 0) s_compact = 0;
+    if (tid < k) { L.sum[tid][0] = 0; L.sum[tid][1] = 0; L.sum[tid][2] = 0; L.cnt[tid] = 0; }
+    if (tid == 0) L.compact = 0;
+    __syncthreads();
+    uint64_t lc = 0;
+    for (uint32_t i0 = 0; i0 < nf; i0 += 2 * te) {  // wave-uniform trip count; two points per lane and trip
+      const uint32_t iA = i0 + tid, iB = iA + te;
+      const bool actA = iA < nf, actB = iB < nf;
+      const uint32_t vA = actA ? pk[iA] : 0u, vB = actB ? pk[iB] : 0u;
+      const Pt pA = unpack_pt(vA, bw, bh), pB = unpack_pt(vB, bw, bh);
+      double bestA = dist2_dbl(pA, L.c[0]), bestB = dist2_dbl(pB, L.c[0]);
+      uint32_t bjA = 0, bjB = 0;
+      for (uint32_t j = 1; j < k; ++j) {
+        const double c3[3] = {L.c[j][0], L.c[j][1], L.c[j][2]};
+        const double dA = dist2_dbl(pA, c3), dB = dist2_dbl(pB, c3);
+        if (dA < bestA) { bestA = dA; bjA = j; }
+        if (dB < bestB) { bestB = dB; bjB = j; }
+      }
+      if (actA) { lab[iA] = (uint8_t)bjA; lc += (unsigned long long)(bestA * 256.0); }
+      if (actB) { lab[iB] = (uint8_t)bjB; lc += (unsigned long long)(bestB * 256.0); }
+      // per-cluster sums of (1, mv.x + 8192, column, row): peel the clusters present in the wave one
+      // by one, reduce inside the wave by DPP (column and row share a word), ONE LDS atomic per wave,
+      // cluster and field.  All integers, so the order of the adds is immaterial.
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool act = h ? actB : actA;
+        const uint32_t bj = h ? bjB : bjA, v = h ? vB : vA;
+        const int xy = (int)((v & 511u) | (((v >> 9) & 511u) << 16)), mb = ((int)v >> 18) + 8192;
+        unsigned long long rem = __ballot(act);
+        while (rem) {
+          const uint32_t j = __builtin_amdgcn_readlane(bj, __builtin_ctzll(rem));
+          const bool mine = act && bj == j;
+          const unsigned long long bal = __ballot(mine);
+          rem &= ~bal;
+          const int sxy = wave_sum_i32(mine ? xy : 0), sm = wave_sum_i32(mine ? mb : 0);
+          if (lane == 0) {
+            atomicAdd(&L.cnt[j], (uint32_t)__popcll(bal));
+            atomicAdd(&L.sum[j][0], (unsigned long long)sm);
+            atomicAdd(&L.sum[j][1], (unsigned long long)(sxy & 0xFFFF));
+            atomicAdd(&L.sum[j][2], (unsigned long long)(sxy >> 16));
+          }
+        }
+      }
+    }
+    lc = wave_sum_u64(lc);
+    if (lane == 0) atomicAdd(&L.compact, (unsigned long long)lc);
+    __syncthreads();
+    compact = L.compact;
+    if (it + 1 >= a.max_iter) break;
+    if (tid < k) {
+      double s = 0.0;
+      const uint32_t cnt = L.cnt[tid];
+      if (cnt) {
+        const long long sums[3] = {(long long)L.sum[tid][0] - 8192ll * cnt, (long long)L.sum[tid][1] * bw,
+                                   (long long)L.sum[tid][2] * bh};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double nc = (double)sums[d] / (double)cnt;
+          const double t = nc - L.c[tid][d];
+          s = s + t * t;
+          L.c[tid][d] = nc;
+        }
+      }
+      L.shift[tid] = s;
+    }
+    __syncthreads();
+    double shift = 0.0;
+    for (uint32_t j = 0; j < k; ++j) shift = L.shift[j] > shift ? L.shift[j] : shift;
+    if (shift <= a.eps2) break;
+  }
+  return compact;
+}
+
+// The same attempt over unpacked 12-byte points in the workspace: fields larger than 512 x 512
+// blocks or |mv.x| >= 8192, which block matching never produces.  Kept simple: 64-bit distances,
+// every step recomputes the minimum over the chosen centres.
+__device__ __forceinline__ uint64_t kmeans_generic(const Pt* pts, uint8_t* lab, KmLds& L, const SegArgs& a,
+                                                   uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid,
+                                                   uint32_t te) {
+  const uint32_t nw = te >> 6, lane = tid & 63u;
+  const uint32_t pper = (nf + te - 1) / te;
+  const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
+  if (tid == 0) {
+    const Pt p = pts[(uint32_t)(seg_hash(aseed) % nf)];
+    L.cint[0][0] = p.f[0]; L.cint[0][1] = p.f[1]; L.cint[0][2] = p.f[2];
+  }
+  __syncthreads();
+  for (uint32_t j = 1; j < k; ++j) {
+    uint64_t lsum = 0;
+    for (uint32_t i = p0; i < p1; ++i) {
+      const Pt p = pts[i];
+      uint64_t m = ~0ull;
+      for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, L.cint[q]));
+      lsum += m;
+    }
+    uint64_t total;
+    const uint64_t excl = block_excl_scan(lsum, L.scan, tid, nw, &total);
+    if (total == 0) {
+      if (tid == 0) L.pick = j < nf ? j : 0;
+    } else {
+      const uint64_t r = seg_hash(aseed ^ j) % total;
+      if (r >= excl && r < excl + lsum) {  // exactly one lane owns the crossing
+        uint64_t acc = excl;
+        for (uint32_t i = p0; i < p1; ++i) {
+          const Pt p = pts[i];
+          uint64_t m = ~0ull;
+          for (uint32_t q = 0; q < j; ++q) m = min(m, dist2_int(p, L.cint[q]));
+          acc += m;
+          if (acc > r) { L.pick = i; break; }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const Pt p = pts[L.pick];
+      L.cint[j][0] = p.f[0]; L.cint[j][1] = p.f[1]; L.cint[j][2] = p.f[2];
+    }
+    __syncthreads();
+  }
+  if (tid < k) {
+    L.c[tid][0] = (double)L.cint[tid][0];
+    L.c[tid][1] = (double)L.cint[tid][1];
+    L.c[tid][2] = (double)L.cint[tid][2];
+  }
+  __syncthreads();
+
+  uint64_t compact = 0;
+  for (uint32_t it = 0;; ++it) {  // Lloyd
+    if (tid < k) { L.sum[tid][0] = 0; L.sum[tid][1] = 0; L.sum[tid][2] = 0; L.cnt[tid] = 0; }
+    if (tid == 0) L.compact = 0;
     __syncthreads();
     unsigned long long lc = 0;
-    const uint32_t lane = tid & 63u;
-    for (uint32_t i0 = 0; i0 < nf; i0 += T) {  // wave-uniform trip count
+    for (uint32_t i0 = 0; i0 < nf; i0 += te) {  // wave-uniform trip count
       const uint32_t i = i0 + tid;
       const bool active = i < nf;
       Pt p = {{0, 0, 0}};
       uint32_t bj = 0xFFFFFFFFu;
       if (active) {
         p = pts[i];
-        double best = dist2_dbl(p, s_c[0]);
+        double best = dist2_dbl(p, L.c[0]);
         bj = 0;
         for (uint32_t j = 1; j < k; ++j) {
-          const double d = dist2_dbl(p, s_c[j]);
+          const double d = dist2_dbl(p, L.c[j]);
           if (d < best) { best = d; bj = j; }
         }
         lab[i] = (uint8_t)bj;
         lc += (unsigned long long)(best * 256.0);
       }
-      // per-cluster sums: reduce inside the wave first (DPP, no LDS traffic: same-address LDS
-      // atomics from 64 lanes serialise, and shuffle reductions load the LDS crossbar), then ONE
-      // LDS atomic per wave and cluster; 64 lanes x |coord| fits int32 for |coord| < 2^24
-      for (uint32_t j = 0; j < k; ++j) {
+      for (uint32_t j = 0; j < k; ++j) {  // coordinates can be anything here: 64-bit sums per lane
         const bool mine = bj == j;
         const unsigned long long bal = __ballot(mine);
         if (bal == 0) continue;
-        const int sx = wave_sum_i32(mine ? p.f[0] : 0), sy = wave_sum_i32(mine ? p.f[1] : 0),
-                  sz = wave_sum_i32(mine ? p.f[2] : 0);
+        const uint64_t sx = wave_sum_u64(mine ? (uint64_t)(int64_t)p.f[0] : 0),
+                       sy = wave_sum_u64(mine ? (uint64_t)(int64_t)p.f[1] : 0),
+                       sz = wave_sum_u64(mine ? (uint64_t)(int64_t)p.f[2] : 0);
         if (lane == 0) {
-          atomicAdd(&s_cnt[j], (uint32_t)__popcll(bal));
-          atomicAdd(&s_sum[j][0], (unsigned long long)(long long)sx);
-          atomicAdd(&s_sum[j][1], (unsigned long long)(long long)sy);
-          atomicAdd(&s_sum[j][2], (unsigned long long)(long long)sz);
+          atomicAdd(&L.cnt[j], (uint32_t)__popcll(bal));
+          atomicAdd(&L.sum[j][0], (unsigned long long)sx);
+          atomicAdd(&L.sum[j][1], (unsigned long long)sy);
+          atomicAdd(&L.sum[j][2], (unsigned long long)sz);
         }
       }
     }
-    atomicAdd(&s_compact, lc);
+    atomicAdd(&L.compact, lc);
     __syncthreads();
-    compact = s_compact;
+    compact = L.compact;
     if (it + 1 >= a.max_iter) break;
     if (tid < k) {
       double s = 0.0;
-      if (s_cnt[tid]) {
+      if (L.cnt[tid]) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          const double nc = (double)(long long)s_sum[tid][d] / (double)s_cnt[tid];
-          const double t = nc - s_c[tid][d];
+          const double nc = (double)(long long)L.sum[tid][d] / (double)L.cnt[tid];
+          const double t = nc - L.c[tid][d];
           s = s + t * t;
-          s_c[tid][d] = nc;
+          L.c[tid][d] = nc;
         }
       }
-      s_shift[tid] = s;
+      L.shift[tid] = s;
     }
     __syncthreads();
     double shift = 0.0;
-    for (uint32_t j = 0; j < k; ++j) shift = s_shift[j] > shift ? s_shift[j] : shift;
+    for (uint32_t j = 0; j < k; ++j) shift = L.shift[j] > shift ? L.shift[j] : shift;
     if (shift <= a.eps2) break;
+  }
+  return compact;
+}
+
+// Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
+// (cv::kmeans' `attempts`), so they run side by side instead of one after the other; each
+// rebuilds the (cheap) mask + foreground list for itself.
+// LDS_ARRAYS: the two byte masks live in dynamic LDS (first and last n bytes of it) during the
+// build; afterwards the whole of it holds the packed points and, if they fit too, the running minima.
+template <bool LDS_ARRAYS>
+__global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+  __shared__ KmLds L;
+
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
+  const uint8_t* mask = a.mask + (size_t)frame * n;
+  const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
+  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+  uint8_t* tmp = LDS_ARRAYS ? dyn_lds : ws.masks(att) + n;
+  uint8_t* fg = LDS_ARRAYS ? dyn_lds + (a.lds_bytes - n4) : ws.masks(att);
+  uint8_t* lab = ws.lab(att);
+  uint32_t* idx = ws.idx();
+  const uint64_t seed = a.seed + frame;
+
+  // ---- foreground mask, close, open (encoder.cpp:507-527) ---------------------------------
+  if (tid == 0) L.bad = 0;
+  for (uint32_t i = tid; i < n; i += kTA) fg[i] = mask[i] ? 0 : 255;
+  __syncthreads();
+  morph_pass(fg, tmp, a, true, tid, kTA);
+  morph_pass(tmp, fg, a, false, tid, kTA);
+  morph_pass(fg, tmp, a, false, tid, kTA);
+  morph_pass(tmp, fg, a, true, tid, kTA);
+
+  // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
+  const uint32_t per = (n + kTA - 1) / kTA;
+  const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
+  uint32_t local = 0;
+  bool bad = false;
+  for (uint32_t i = c0; i < c1; ++i)
+    if (fg[i] == 255) {
+      ++local;
+      const float mx = mv[i].x;
+      bad = bad || !(mx > -8191.0f && mx < 8191.0f);
+    }
+  if (bad) L.bad = 1;
+  uint64_t tot64;
+  uint32_t pos = (uint32_t)block_excl_scan(local, L.scan, tid, kTA / 64, &tot64);
+  const uint32_t nf = (uint32_t)tot64;
+  const bool packed = a.packable != 0 && L.bad == 0;
+  const size_t build_cap = LDS_ARRAYS ? a.lds_bytes - n4 : a.lds_bytes;
+  const bool pk_lds = packed && 4 * (size_t)nf <= build_cap;
+  uint32_t* pk = pk_lds ? reinterpret_cast<uint32_t*>(dyn_lds) : reinterpret_cast<uint32_t*>(ws.pts(att));
+  Pt* pts = ws.pts(att);
+  {
+    uint32_t y = c0 / a.mfw, x = c0 - y * a.mfw;
+    for (uint32_t i = c0; i < c1; ++i) {
+      if (fg[i] == 255) {
+        if (att == 0) idx[pos] = i;
+        const float mx = mv[i].x;
+        const int r = (int)(mx < 0 ? mx - 0.5f : mx + 0.5f);
+        if (packed) {
+          pk[pos] = pack_pt(r, x, y);
+        } else {
+          Pt p;
+          p.f[0] = r; p.f[1] = (int)(x * a.mv_bw); p.f[2] = (int)(y * a.mv_bh);
+          pts[pos] = p;
+        }
+        ++pos;
+      }
+      if (++x == a.mfw) { x = 0; ++y; }
+    }
+  }
+  if (att == 0 && tid == 0) *ws.nf() = nf;
+  __syncthreads();
+  if (nf == 0) return;
+  const uint32_t te = lanes_for(nf);
+  if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
+  const uint32_t k = min(a.k, nf);  // :555
+
+  // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
+  const uint64_t aseed = seed ^ ((uint64_t)att << 32);
+  uint64_t compact;
+  if (packed) {
+    uint32_t* dmin = pk_lds && 8 * (size_t)nf <= a.lds_bytes ? reinterpret_cast<uint32_t*>(dyn_lds) + nf : ws.dmin(att);
+    compact = kmeans_packed(pk, dmin, lab, L, a, nf, k, aseed, tid, te);
+  } else {
+    compact = kmeans_generic(pts, lab, L, a, nf, k, aseed, tid, te);
   }
   if (tid == 0) ws.compact()[att] = compact;
 }
 
 // Kernel B: one workgroup per frame.  Takes the attempt with the smallest compactness (ties ->
 // the earlier attempt), then connected components per cluster, numbered as the reference
-// numbers them (:597-623).  LDS_PARENT / LDS_CL: union-find parents (4 B per block) and cluster
-// ids (1 B per block) in LDS; at 4K only the parents fit (130 KB).
-template <bool LDS_PARENT, bool LDS_CL, uint32_t T>
-__global__ __launch_bounds__(T) void segment_label_kernel(SegArgs a) {
+// numbers them (:597-623): inside a cluster by the raster position of a component's first block,
+// clusters stacked with `offset += count including label 0`.  Everything after the clears walks the
+// foreground list, not the field.  LDS_PARENT / LDS_CL: union-find parents (4 B per block) and
+// cluster ids (1 B per block) in LDS; at 4K only the parents fit (130 KB).
+template <bool LDS_PARENT, bool LDS_CL>
+__global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-  __shared__ uint64_t s_scan[T / 64];
+  __shared__ uint64_t s_scan[kTA / 64];
+  __shared__ uint32_t s_wcnt[kTA / 64][kMaxK];  // roots per (wave, cluster) in the current round
+  __shared__ uint32_t s_base[kMaxK];            // roots per cluster in earlier rounds; then the cluster's offset
   const uint32_t tid = threadIdx.x, frame = blockIdx.x, n = a.n;
   uint32_t* types = a.types + (size_t)frame * n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  uint32_t* label = LDS_PARENT ? reinterpret_cast<uint32_t*>(dyn_lds) : ws.parent();
+  uint32_t* parent = LDS_PARENT ? reinterpret_cast<uint32_t*>(dyn_lds) : ws.parent();
   uint8_t* cl = LDS_CL ? dyn_lds + 4 * n4 : ws.cl();
-  uint32_t* idx = ws.idx();
+  const uint32_t* idx = ws.idx();
+  uint32_t* roots = ws.roots();
   const uint32_t nf = *ws.nf();
 
-  for (uint32_t i = tid; i < n; i += T) { types[i] = 0; cl[i] = 255; label[i] = i; }  // :549-551
+  for (uint32_t i = tid; i < n; i += kTA) { types[i] = 0; cl[i] = 255; }  // :549-551
   if (nf == 0) return;
+  const uint32_t te = lanes_for(nf);
+  if (tid >= te) {  // the clears above must be visible to the lanes that stay
+    __syncthreads();
+    return;
+  }
+  const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
   const uint32_t k = min(a.k, nf);
   uint32_t best = 0;
   unsigned long long best_c = ws.compact()[0];
@@ -447,45 +667,98 @@ __global__ __launch_bounds__(T) void segment_label_kernel(SegArgs a) {
     if (c < best_c) { best_c = c; best = t; }
   }
   const uint8_t* best_lab = ws.lab(best);
+  for (uint32_t j = tid; j < (kTA / 64) * kMaxK; j += te) (&s_wcnt[0][0])[j] = 0;
+  if (tid < kMaxK) s_base[tid] = 0;
   __syncthreads();
-  for (uint32_t i = tid; i < nf; i += T) cl[idx[i]] = best_lab[i];
+  for (uint32_t i = tid; i < nf; i += te) {
+    const uint32_t b = idx[i];
+    cl[b] = best_lab[i];
+    parent[b] = b;
+  }
   __syncthreads();
-  // merge every block with its already-visited neighbours of the same cluster, then flatten
-  for (uint32_t i = tid; i < n; i += T) {
+  // merge every foreground block with its already-visited neighbours of the same cluster, then flatten
+  for (uint32_t q = tid; q < nf; q += te) {
+    const uint32_t i = idx[q];
     const uint8_t c = cl[i];
-    if (c == 255) continue;
     const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
-    if (x > 0 && cl[i - 1] == c) uf_unite(label, i, i - 1);
+    if (x > 0 && cl[i - 1] == c) uf_unite(parent, i, i - 1);
     if (y > 0) {
-      if (cl[i - a.mfw] == c) uf_unite(label, i, i - a.mfw);
+      if (cl[i - a.mfw] == c) uf_unite(parent, i, i - a.mfw);
       if (a.conn == 8) {
-        if (x > 0 && cl[i - a.mfw - 1] == c) uf_unite(label, i, i - a.mfw - 1);
-        if (x + 1 < (int)a.mfw && cl[i - a.mfw + 1] == c) uf_unite(label, i, i - a.mfw + 1);
+        if (x > 0 && cl[i - a.mfw - 1] == c) uf_unite(parent, i, i - a.mfw - 1);
+        if (x + 1 < (int)a.mfw && cl[i - a.mfw + 1] == c) uf_unite(parent, i, i - a.mfw + 1);
       }
     }
   }
   __syncthreads();
-  for (uint32_t i = tid; i < n; i += T)
-    if (cl[i] != 255) {
-      const uint32_t r = uf_find(label, i);
-      if (r != i) label[i] = r;  // still an ancestor for any concurrent walker; roots are never rewritten
-    }
+  for (uint32_t q = tid; q < nf; q += te) {
+    const uint32_t i = idx[q];
+    const uint32_t r = uf_find(parent, i);
+    if (r != i) parent[i] = r;  // still an ancestor for any concurrent walker; roots are never rewritten
+  }
   __syncthreads();
-  const uint32_t per = (n + T - 1) / T;
-  const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
-  uint32_t offset = 0;  // BLOCK_TYPE_BACKGROUND, libs/codec.hpp:6
-  for (uint32_t cid = 0; cid < k; ++cid) {
-    uint32_t roots = 0;
-    for (uint32_t i = c0; i < c1; ++i) roots += (cl[i] == cid && label[i] == i) ? 1u : 0u;
-    uint64_t total;
-    uint32_t rank = (uint32_t)block_excl_scan<T>(roots, s_scan, tid, &total);
-    for (uint32_t i = c0; i < c1; ++i)
-      if (cl[i] == cid && label[i] == i) idx[i] = ++rank;  // idx is free now: component number of a root
+  // component roots, compacted in raster order (lane-contiguous ranges of the list + one block scan)
+  const uint32_t pper = (nf + te - 1) / te;
+  const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
+  uint32_t nroots = 0;
+  for (uint32_t q = p0; q < p1; ++q) {
+    const uint32_t i = idx[q];
+    nroots += parent[i] == i ? 1u : 0u;
+  }
+  uint64_t total_roots;
+  uint32_t rpos = (uint32_t)block_excl_scan(nroots, s_scan, tid, nw, &total_roots);
+  for (uint32_t q = p0; q < p1; ++q) {
+    const uint32_t i = idx[q];
+    if (parent[i] == i) roots[rpos++] = i;
+  }
+  __syncthreads();
+  // number the roots inside their cluster, te roots per round: rank inside the wave by ballots over
+  // the clusters present, across waves and rounds by the small per-(wave, cluster) table.  A root's
+  // parent entry becomes 0x80000000 | its 1-based number (nobody walks the forest any more).
+  const uint32_t R = (uint32_t)total_roots;
+  for (uint32_t r0 = 0; r0 < R; r0 += te) {
+    const uint32_t q = r0 + tid;
+    const bool act = q < R;
+    const uint32_t b = act ? roots[q] : 0u;
+    const uint32_t cid = act ? cl[b] : 0xFFFFFFFFu;
+    uint32_t in_wave = 0;
+    unsigned long long rem = __ballot(act);
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    while (rem) {
+      const uint32_t j = __builtin_amdgcn_readlane(cid, __builtin_ctzll(rem));
+      const unsigned long long bal = __ballot(cid == j);
+      rem &= ~bal;
+      if (cid == j) in_wave = (uint32_t)__popcll(bal & lt);
+      if (lane == 0) s_wcnt[wave][j] = (uint32_t)__popcll(bal);
+    }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += T)
-      if (cl[i] == cid) types[i] = idx[label[i]] + offset;  // :617
-    offset += (uint32_t)total + 1;  // :620, the count includes label 0
+    if (act) {
+      uint32_t before = s_base[cid];
+      for (uint32_t wv = 0; wv < wave; ++wv) before += s_wcnt[wv][cid];
+      parent[b] = 0x80000000u | (before + in_wave + 1);
+    }
     __syncthreads();
+    if (tid < k) {
+      uint32_t s = 0;
+      for (uint32_t wv = 0; wv < nw; ++wv) { s += s_wcnt[wv][tid]; s_wcnt[wv][tid] = 0; }
+      s_base[tid] += s;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {  // BLOCK_TYPE_BACKGROUND = 0 (libs/codec.hpp:6); :620, the count includes label 0
+    uint32_t offset = 0;
+    for (uint32_t cid = 0; cid < k; ++cid) {
+      const uint32_t cnt = s_base[cid];
+      s_base[cid] = offset;
+      offset += cnt + 1;
+    }
+  }
+  __syncthreads();
+  for (uint32_t q = tid; q < nf; q += te) {
+    const uint32_t i = idx[q];
+    uint32_t pv = parent[i];
+    if (!(pv & 0x80000000u)) pv = parent[pv];
+    types[i] = (pv & 0x7FFFFFFFu) + s_base[cl[i]];  // :617
   }
 }
 
@@ -501,6 +774,8 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
     return fail(SVC_ERR_UNSUPPORTED, "segment: cluster_count %u exceeds %u", p.cluster_count, kMaxK);
   if (p.attempt_count > kMaxAttempts)
     return fail(SVC_ERR_UNSUPPORTED, "segment: attempt_count %u exceeds %u", p.attempt_count, kMaxAttempts);
+  if ((uint64_t)mfw * mfh >= (1ull << 31))
+    return fail(SVC_ERR_UNSUPPORTED, "segment: motion field of %u x %u blocks is too large", mfw, mfh);
   SegArgs a;
   a.mask = d_mask;
   a.mv = d_mv;
@@ -515,26 +790,23 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   a.k = p.cluster_count; a.attempts = p.attempt_count; a.max_iter = p.max_iter_count;
   a.conn = p.connectivity;
   const size_t n4 = ((size_t)a.n + 3) & ~(size_t)3;
-  const size_t pts_lds = (size_t)kPtsLds * sizeof(Pt);
   const dim3 grid_a(n_frames, p.attempt_count);
-  a.small_coords = ((uint64_t)mfw * mv_bw < (1u << 14) && (uint64_t)mfh * mv_bh < (1u << 14)) ? 1u : 0u;
-  constexpr size_t kLdsMax = 152 * 1024;  // of the CU's 160 KB; statics take ~4 KB
-  a.pts_lds_cap = kPtsLds;
-  if (5 * n4 <= 100 * 1024) {  // small fields (1080p: 8 160 blocks): everything in LDS, 256 lanes
-    hipLaunchKernelGGL((segment_attempt_kernel<true, 256>), grid_a, dim3(256), 2 * n4 + pts_lds, stream, a);
-    hipLaunchKernelGGL((segment_label_kernel<true, true, 256>), dim3(n_frames), dim3(256), 5 * n4, stream, a);
-  } else {  // big fields (4K: 32 400 blocks): 1024 lanes, LDS for whatever fits
-    if (2 * n4 + pts_lds <= kLdsMax) {  // one workgroup per CU anyway: give the points the rest of the LDS
-      a.pts_lds_cap = (uint32_t)((kLdsMax - 2 * n4) / sizeof(Pt));
-      hipLaunchKernelGGL((segment_attempt_kernel<true, 1024>), grid_a, dim3(1024), 2 * n4 + a.pts_lds_cap * sizeof(Pt), stream, a);
-    } else {
-      hipLaunchKernelGGL((segment_attempt_kernel<false, 1024>), grid_a, dim3(1024), pts_lds, stream, a);
-    }
-    if (4 * n4 <= kLdsMax - 4096)
-      hipLaunchKernelGGL((segment_label_kernel<true, false, 1024>), dim3(n_frames), dim3(1024), 4 * n4, stream, a);
-    else
-      hipLaunchKernelGGL((segment_label_kernel<false, false, 1024>), dim3(n_frames), dim3(1024), 0, stream, a);
+  const bool small_coords = (uint64_t)mfw * mv_bw < (1u << 14) && (uint64_t)mfh * mv_bh < (1u << 14);
+  a.packable = (small_coords && mfw <= 512 && mfh <= 512) ? 1u : 0u;
+  constexpr size_t kLdsBig = 144 * 1024;  // of the CU's 160 KB; the static part takes ~5 KB
+  if (6 * n4 <= 96 * 1024) {  // small fields (1080p: 8 160 blocks, 48 KB): masks, points and minima all in LDS
+    a.lds_bytes = (uint32_t)(6 * n4);
+    hipLaunchKernelGGL((segment_attempt_kernel<true>), grid_a, dim3(kTA), a.lds_bytes, stream, a);
+  } else {  // big fields (4K: 32 400 blocks): masks in the workspace, LDS for the packed points (+ minima)
+    a.lds_bytes = (uint32_t)kLdsBig;
+    hipLaunchKernelGGL((segment_attempt_kernel<false>), grid_a, dim3(kTA), a.lds_bytes, stream, a);
   }
+  if (5 * n4 <= kLdsBig)
+    hipLaunchKernelGGL((segment_label_kernel<true, true>), dim3(n_frames), dim3(kTA), 5 * n4, stream, a);
+  else if (4 * n4 <= kLdsBig)
+    hipLaunchKernelGGL((segment_label_kernel<true, false>), dim3(n_frames), dim3(kTA), 4 * n4, stream, a);
+  else
+    hipLaunchKernelGGL((segment_label_kernel<false, false>), dim3(n_frames), dim3(kTA), 0, stream, a);
   return check_launch("segment kernels");
 }
 

@@ -67,12 +67,38 @@ def test_segment_edge_cases(native, oracle):
     assert e.value.status == native.SVC_ERR_INVALID_ARG
 
 
-def test_segment_unpacked_accumulator_path(native, oracle):
-    """|mv.x| > 1023 (never produced by block matching) takes the shuffle-based accumulation path."""
+@pytest.mark.parametrize("mfw,mfh,density", [(120, 68, 0.45), (120, 68, 0.7), (120, 68, 0.93), (120, 68, 1.0),
+                                             (240, 135, 0.6), (240, 135, 0.97), (33, 31, 0.8)])
+def test_segment_heavy_frames(native, oracle, mfw, mfh, density):
+    """Scene-cut-like frames: most of the field is foreground (all sixteen waves stay; the running minima
+    and, at 4K, the points spill from LDS to the workspace), next to a light and an empty frame."""
+    rng = np.random.default_rng(int(density * 100) + mfw)
+    n = mfw * mfh
+    yy, xx = np.mgrid[0:mfh, 0:mfw]
+    masks, mvs = [], []
+    for f in range(3):
+        d = (density, 0.02, 0.0)[f]
+        blob = (rng.random((mfh, mfw)) < d)
+        mask = (~blob).astype(np.uint8).reshape(-1)
+        mv = np.stack([np.round(6 * np.sin(xx / 17.0 + f) + rng.integers(-2, 3, (mfh, mfw))),
+                       rng.integers(-9, 10, (mfh, mfw))], -1).astype(np.float32).reshape(n, 2)
+        masks.append(mask); mvs.append(mv)
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh, seed=77).cpu().numpy()
+    for f in range(3):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=77 + f)
+        assert np.array_equal(got[f].astype(np.uint32), want), f"frame {f}: {(got[f] != want).sum()} blocks differ"
+    assert (got[0] != 0).sum() > 0.3 * n * density
+
+
+@pytest.mark.parametrize("mfw,mfh", [(600, 5), (40, 30)])
+def test_segment_unpacked_points_path(native, oracle, mfw, mfh):
+    """Fields wider than 512 blocks, or |mv.x| >= 8192 (never produced by block matching), take the
+    unpacked 64-bit path."""
     rng = np.random.default_rng(17)
-    mfw, mfh = 40, 30
     mask, mv = _scene(rng, mfw, mfh, 3, 0.02)
-    mv[mask == 0, 0] *= 400.0
+    if mfw <= 512:
+        mv[mask == 0, 0] *= 1000.0
     got = native.segment_frames(torch.from_numpy(mask[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh,
                                 seed=21).cpu().numpy()[0]
     assert np.array_equal(got.astype(np.uint32), oracle.segment(mask, mv, mfw, mfh, seed=21))

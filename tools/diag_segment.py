@@ -5,7 +5,7 @@ import torch
 from scalable_video_codec_amd import configs, native, pipeline, synth
 name = sys.argv[1] if len(sys.argv) > 1 else "C3-1080p-3L-dct8-quant"
 cfg = configs.ALL[name]
-n = min(cfg.frames, 64)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else min(cfg.frames, 64)
 dev = torch.device("cuda")
 clip = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
 pw, ph = cfg.padded
