@@ -33,6 +33,7 @@ struct SegArgs {
   uint32_t mfw, mfh, n, mv_bw, mv_bh;
   uint32_t morph_w, morph_h, k, attempts, max_iter, conn;
   uint32_t lds_bytes;    // dynamic LDS of the attempt kernel
+  uint32_t bits_bytes;   // ... of which the bit fields at its start
   uint32_t packable;     // host check: field <= 512 x 512 blocks and x_px, y_px < 2^14 (32-bit distances)
 };
 
@@ -164,41 +165,53 @@ __device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t 
   }
 }
 
-__device__ __forceinline__ void morph_pass(const uint8_t* src, uint8_t* dst, const SegArgs& a, bool dilate,
-                                           uint32_t tid, uint32_t T) {
-  const int ax = (int)a.morph_w / 2, ay = (int)a.morph_h / 2;
-  if (a.morph_w == 3 && a.morph_h == 3) {  // the default element: branch-free, loads in flight together
-    const int W = (int)a.mfw, H = (int)a.mfh;
-    const int pad = dilate ? 0 : 255;
-    for (uint32_t i = tid; i < a.n; i += T) {
-      const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
-      int v = pad;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int sx = x + dx, sy = y + dy;
-          const bool in = sx >= 0 && sy >= 0 && sx < W && sy < H;
-          const int p = src[in ? sy * W + sx : (int)i];
-          const int q = in ? p : pad;
-          v = dilate ? max(v, q) : min(v, q);
-        }
-      dst[i] = (uint8_t)v;
+constexpr uint32_t kTA = 1024;  // lanes both kernels are launched with
+
+// ---- morphology on bit rows ------------------------------------------------------------------
+// The field is kept as one bit per MV block, each row starting at a word boundary (W32 words per
+// row, bit x & 31 of word x >> 5; bits past the row's end are 0).  A rectangular structuring
+// element separates into a horizontal and a vertical pass; positions outside the field are
+// ignored, exactly like the byte version this replaces (dilate pads with 0, erode with 1).
+struct BitField {
+  uint32_t W32, H, NW, last_valid;  // words per row, rows, W32 * H, valid bits of a row's last word
+};
+
+__device__ __forceinline__ uint32_t bit_row_word(const uint32_t* row, int w, const BitField& bf, bool erode) {
+  if (w < 0 || w >= (int)bf.W32) return erode ? ~0u : 0u;
+  uint32_t v = row[w];
+  if (erode && w == (int)bf.W32 - 1) v |= ~bf.last_valid;
+  return v;
+}
+
+// dst = (erode ? AND : OR) over the kw x kh rectangle anchored at (kw / 2, kh / 2); tmp is scratch
+__device__ __forceinline__ void bit_morph(const uint32_t* src, uint32_t* tmp, uint32_t* dst, const BitField& bf,
+                                          uint32_t kw, uint32_t kh, bool erode, uint32_t tid) {
+  const int ax = (int)kw / 2, ay = (int)kh / 2;
+  for (uint32_t q = tid; q < bf.NW; q += kTA) {
+    const uint32_t y = q / bf.W32;
+    const int w = (int)(q - y * bf.W32);
+    const uint32_t* row = src + y * bf.W32;
+    uint32_t acc = erode ? ~0u : 0u;
+    for (int kx = 0; kx < (int)kw; ++kx) {
+      const int s = kx - ax, o = s >> 5, b = s & 31;  // out bit x takes in bit x + s = 32 o + b further on
+      const uint32_t lo = bit_row_word(row, w + o, bf, erode);
+      const uint32_t v = b ? (lo >> b) | (bit_row_word(row, w + o + 1, bf, erode) << (32 - b)) : lo;
+      acc = erode ? acc & v : acc | v;
     }
-    __syncthreads();
-    return;
+    tmp[q] = w == (int)bf.W32 - 1 ? acc & bf.last_valid : acc;
   }
-  for (uint32_t i = tid; i < a.n; i += T) {
-    const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
-    int v = dilate ? 0 : 255;
-    for (int ky = 0; ky < (int)a.morph_h; ++ky)
-      for (int kx = 0; kx < (int)a.morph_w; ++kx) {
-        const int sx = x + kx - ax, sy = y + ky - ay;
-        if (sx < 0 || sy < 0 || sx >= (int)a.mfw || sy >= (int)a.mfh) continue;
-        const int p = src[sy * (int)a.mfw + sx];
-        v = dilate ? max(v, p) : min(v, p);
-      }
-    dst[i] = (uint8_t)v;
+  __syncthreads();
+  for (uint32_t q = tid; q < bf.NW; q += kTA) {
+    const int y = (int)(q / bf.W32);
+    uint32_t acc = erode ? ~0u : 0u;
+    for (int ky = 0; ky < (int)kh; ++ky) {
+      const int sy = y + ky - ay;
+      if (sy < 0 || sy >= (int)bf.H) continue;
+      const uint32_t v = tmp[(int)q + (ky - ay) * (int)bf.W32];
+      acc = erode ? acc & v : acc | v;
+    }
+    const uint32_t w = q - (uint32_t)y * bf.W32;
+    dst[q] = w == bf.W32 - 1 ? acc & bf.last_valid : acc;
   }
   __syncthreads();
 }
@@ -207,10 +220,9 @@ __device__ __forceinline__ void morph_pass(const uint8_t* src, uint8_t* dst, con
 //   [0, 256)            header: u32 nf at 0; u64 compactness[attempt] at 8 + 8 * attempt
 //   idx      [n]  u32   foreground list, raster order (written by attempt 0's workgroup)
 //   lab      [A][n] u8  labels of each k-means attempt
-//   masks    [A][2n] u8 byte masks of an attempt when they do not fit LDS
 //   pts      [A][n] Pt  feature points of an attempt when they do not fit LDS (packed points use the
 //                       first 4n bytes of the slot)
-//   dmin     [A][n] u32 k-means++ running minima when they do not fit LDS
+//   dmin     [A][n] u32 k-means++ running minima when they do not fit registers or LDS
 //   cl [n] u8, parent [n] u32: connected-components arrays when they do not fit LDS
 //   roots    [n] u32    component roots in raster order
 constexpr uint32_t kMaxAttempts = 16;
@@ -221,8 +233,7 @@ struct Workspace {
   __host__ __device__ static uint64_t a16(uint64_t v) { return (v + 15) & ~15ull; }
   __host__ __device__ uint64_t off_idx() const { return 256; }
   __host__ __device__ uint64_t off_lab() const { return off_idx() + a16(4ull * n); }
-  __host__ __device__ uint64_t off_masks() const { return off_lab() + a16((uint64_t)attempts * n); }
-  __host__ __device__ uint64_t off_pts() const { return off_masks() + a16(2ull * attempts * n); }
+  __host__ __device__ uint64_t off_pts() const { return off_lab() + a16((uint64_t)attempts * n); }
   __host__ __device__ uint64_t off_dmin() const { return off_pts() + a16(12ull * attempts * n); }
   __host__ __device__ uint64_t off_cl() const { return off_dmin() + a16(4ull * attempts * n); }
   __host__ __device__ uint64_t off_parent() const { return off_cl() + a16(n); }
@@ -232,7 +243,6 @@ struct Workspace {
   __device__ unsigned long long* compact() const { return reinterpret_cast<unsigned long long*>(base + 8); }
   __device__ uint32_t* idx() const { return reinterpret_cast<uint32_t*>(base + off_idx()); }
   __device__ uint8_t* lab(uint32_t a) const { return base + off_lab() + (uint64_t)a * n; }
-  __device__ uint8_t* masks(uint32_t a) const { return base + off_masks() + 2ull * a * n; }
   __device__ Pt* pts(uint32_t a) const { return reinterpret_cast<Pt*>(base + off_pts() + 12ull * a * n); }
   __device__ uint32_t* dmin(uint32_t a) const { return reinterpret_cast<uint32_t*>(base + off_dmin() + 4ull * a * n); }
   __device__ uint8_t* cl() const { return base + off_cl(); }
@@ -240,23 +250,32 @@ struct Workspace {
   __device__ uint32_t* roots() const { return reinterpret_cast<uint32_t*>(base + off_roots()); }
 };
 
-// Both kernels are launched kTA lanes wide, which is what the field-sized sweeps (masks, morphology,
-// clears) want.  Once a frame's foreground count is known the workgroup keeps only the lanes that
-// count can feed: the rest of its waves end there (s_barrier counts surviving waves only), so the
-// hundreds of short barrier-separated k-means / labelling phases of a light frame run on one or four
-// waves while a heavy frame (a scene cut: most of the field is foreground) keeps all sixteen.
-constexpr uint32_t kTA = 1024;
+#ifdef SVC_SEG_TIMING  // diagnostic build only (tools/diag_segment_phases.py): shader-clock stamps of the phases
+#define SEG_STAMP(slot) do { if (tid == 0) stamps[slot] = (unsigned long long)clock64(); } while (0)
+#else
+#define SEG_STAMP(slot) do { } while (0)
+#endif
 
+// Both kernels are launched kTA lanes wide, which is what the field-sized sweeps (bitmap, clears)
+// want.  Once a frame's foreground count is known the workgroup keeps only the lanes that count can
+// feed: the rest of its waves end there (s_barrier counts surviving waves only), so the hundreds of
+// short barrier-separated k-means / labelling phases of a light frame run on one or four waves
+// while a heavy frame (a scene cut: most of the field is foreground) keeps all sixteen.
 __device__ __forceinline__ uint32_t lanes_for(uint32_t nf) { return nf <= 64 ? 64u : nf <= 1024 ? 256u : kTA; }
+
+constexpr uint32_t kRegPts = 8;  // points a lane keeps in registers through one k-means attempt
 
 struct KmLds {
   uint64_t scan[kTA / 64];
   int cint[kMaxK][3];
   double c[kMaxK][3];
-  unsigned long long sum[kMaxK][3];
+  unsigned long long sum[kMaxK][3];  // unpacked path
   uint32_t cnt[kMaxK];
+  unsigned long long acc[kMaxK][4];  // packed paths: see lloyd_quad
   double shift[kMaxK];
-  unsigned long long compact;
+  unsigned long long compact;      // unpacked path
+  unsigned long long compact2[2];  // packed paths: iteration it adds into [it & 1]
+  uint64_t draw;
   uint32_t pick, bad;
 };
 
@@ -272,6 +291,10 @@ __device__ __forceinline__ Pt unpack_pt(uint32_t v, uint32_t bw, uint32_t bh) {
   p.f[2] = (int)(((v >> 9) & 511u) * bh);
   return p;
 }
+__device__ __forceinline__ void set_centre(KmLds& L, uint32_t j, uint32_t v, uint32_t bw, uint32_t bh) {
+  const Pt p = unpack_pt(v, bw, bh);
+  L.cint[j][0] = p.f[0]; L.cint[j][1] = p.f[1]; L.cint[j][2] = p.f[2];
+}
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -282,22 +305,234 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
-// One k-means attempt over packed points (the path every real frame takes).  `pk` and `dmin` are in
-// LDS when the foreground fits there, else in the workspace.  Returns the fixed-point compactness.
+// ---- Lloyd iteration pieces shared by the packed paths -----------------------------------------
+// Four points of a lane against all centres: nearest centre (strict <: the lowest index wins ties),
+// fixed-point compactness, and the correction of the per-cluster sums.  The sums of (1, mv.x + 8192,
+// column, row) are all integers, so they are kept across iterations and only corrected for the
+// points whose label changed: after the first couple of iterations few lanes have anything to add.
+// A cluster has four 64-bit accumulators, two fields each: everything that ever entered it
+// (count | mv.x sum << 32, column sum | row sum << 32) and everything that ever left it; the fields
+// only grow between two centre updates (which re-base them), so the low ones stay far below 2^32; the
+// high ones may wrap, and entered - left per field mod 2^32 is the exact current sum.  oldj = 0xFF: no
+// label yet.
+__device__ __forceinline__ void lloyd_quad(const uint32_t (&v)[4], const bool (&act)[4], const uint32_t (&oldj)[4],
+                                           uint32_t (&bj)[4], uint64_t& lc, KmLds& L, uint32_t k, uint32_t bw,
+                                           uint32_t bh, uint32_t lane) {
+  double px[4], py[4], pz[4], best[4];
+  {
+    const double c0 = L.c[0][0], c1 = L.c[0][1], c2 = L.c[0][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const Pt p = unpack_pt(v[u], bw, bh);
+      px[u] = (double)p.f[0]; py[u] = (double)p.f[1]; pz[u] = (double)p.f[2];
+      const double dx = px[u] - c0, dy = py[u] - c1, dz = pz[u] - c2;
+      double d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      best[u] = d;
+      bj[u] = 0;
+    }
+  }
+  // four independent chains per centre; the next centre is fetched from LDS while this one is used
+  double n0 = L.c[k > 1 ? 1 : 0][0], n1 = L.c[k > 1 ? 1 : 0][1], n2 = L.c[k > 1 ? 1 : 0][2];
+  for (uint32_t j = 1; j < k; ++j) {
+    const double a0 = n0, a1 = n1, a2 = n2;
+    const uint32_t jn = j + 1 < k ? j + 1 : j;
+    n0 = L.c[jn][0]; n1 = L.c[jn][1]; n2 = L.c[jn][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double ax = px[u] - a0, ay = py[u] - a1, az = pz[u] - a2;
+      double da = ax * ax;
+      da = da + ay * ay;
+      da = da + az * az;
+      if (da < best[u]) { best[u] = da; bj[u] = j; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (act[u]) lc += (unsigned long long)(best[u] * 256.0);
+    if (act[u] && bj[u] != oldj[u]) {
+      const unsigned long long wa = 1ull | ((unsigned long long)(uint32_t)(((int)v[u] >> 18) + 8192) << 32);
+      const unsigned long long wb = (unsigned long long)(v[u] & 511u) | ((unsigned long long)((v[u] >> 9) & 511u) << 32);
+      atomicAdd(&L.acc[bj[u]][0], wa);
+      atomicAdd(&L.acc[bj[u]][1], wb);
+      if (oldj[u] != 0xFFu) {
+        atomicAdd(&L.acc[oldj[u]][2], wa);
+        atomicAdd(&L.acc[oldj[u]][3], wb);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void lloyd_begin(KmLds& L, uint32_t k, uint32_t tid) {
+  if (tid < k) {
+    L.c[tid][0] = (double)L.cint[tid][0];
+    L.c[tid][1] = (double)L.cint[tid][1];
+    L.c[tid][2] = (double)L.cint[tid][2];
+    L.acc[tid][0] = 0; L.acc[tid][1] = 0; L.acc[tid][2] = 0; L.acc[tid][3] = 0;
+  }
+  if (tid == 0) { L.compact2[0] = 0; L.compact2[1] = 0; }
+  __syncthreads();
+}
+
+// Closes iteration `it`: publishes the compactness, moves the centres to the means of their clusters;
+// true when the attempt is over (iteration cap, or no centre moved further than epsilon).
+__device__ __forceinline__ bool lloyd_end_iter(uint64_t lc, uint64_t& compact, uint32_t it, KmLds& L, const SegArgs& a,
+                                               uint32_t k, uint32_t tid, uint32_t lane) {
+  lc = wave_sum_u64(lc);
+  if (lane == 0) atomicAdd(&L.compact2[it & 1], (unsigned long long)lc);
+  __syncthreads();
+  compact = L.compact2[it & 1];
+  if (it + 1 >= a.max_iter) return true;
+  if (tid == 0) L.compact2[(it + 1) & 1] = 0;  // last read one iteration ago
+  if (tid < k) {
+    double s = 0.0;
+    const unsigned long long ia = L.acc[tid][0], ib = L.acc[tid][1], oa = L.acc[tid][2], ob = L.acc[tid][3];
+    const uint32_t cnt = (uint32_t)ia - (uint32_t)oa;
+    const uint32_t smv = (uint32_t)(ia >> 32) - (uint32_t)(oa >> 32), sbx = (uint32_t)ib - (uint32_t)ob,
+                   sby = (uint32_t)(ib >> 32) - (uint32_t)(ob >> 32);
+    // re-base, so that the low fields never grow past two iterations' worth whatever max_iter is
+    L.acc[tid][0] = (unsigned long long)cnt | ((unsigned long long)smv << 32);
+    L.acc[tid][1] = (unsigned long long)sbx | ((unsigned long long)sby << 32);
+    L.acc[tid][2] = 0;
+    L.acc[tid][3] = 0;
+    if (cnt) {
+      const long long sums[3] = {(long long)smv - 8192ll * cnt, (long long)sbx * a.mv_bw, (long long)sby * a.mv_bh};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double nc = (double)sums[d] / (double)cnt;
+        const double t = nc - L.c[tid][d];
+        s = s + t * t;
+        L.c[tid][d] = nc;
+      }
+    }
+    L.shift[tid] = s;
+  }
+  __syncthreads();
+  double shift = 0.0;
+  for (uint32_t j = 0; j < k; ++j) shift = L.shift[j] > shift ? L.shift[j] : shift;
+  return shift <= a.eps2;
+}
+
+// One k-means attempt with the lane's points in registers: lane t owns the list entries
+// [t * pper, (t + 1) * pper), pper <= kRegPts -- every frame of at most 8 192 foreground blocks.
+// `pk` (LDS or workspace) is only read once, and for the drawn centres.
+__device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab, KmLds& L, const SegArgs& a,
+                                                uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te,
+                                                unsigned long long* stamps) {
+  const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t bw = a.mv_bw, bh = a.mv_bh;
+  (void)stamps;
+  const uint32_t pper = (nf + te - 1) / te;  // block-uniform, <= kRegPts
+  const uint32_t p0 = tid * pper;
+  uint32_t v[kRegPts], dm[kRegPts];
+#pragma unroll
+  for (uint32_t t = 0; t < kRegPts; ++t) {
+    v[t] = (t < pper && p0 + t < nf) ? pk[p0 + t] : 0u;
+    dm[t] = 0xFFFFFFFFu;
+  }
+  if (tid == 0) set_centre(L, 0, pk[(uint32_t)(seg_hash(aseed) % nf)], bw, bh);
+  __syncthreads();
+  // k-means++: the next centre is drawn with probability ~ (distance to the nearest chosen centre)^2;
+  // each point's running minimum stays in its register, so a step costs ONE new distance per point.
+  // The draw is "the first point whose inclusive prefix exceeds r", found by one scan over the lanes'
+  // sums and a walk through the one lane whose range holds it.
+  for (uint32_t j = 1; j < k; ++j) {
+    const int c[3] = {L.cint[j - 1][0], L.cint[j - 1][1], L.cint[j - 1][2]};
+    uint64_t lsum = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < kRegPts; ++t)
+      if (t < pper) {
+        const uint32_t m = p0 + t < nf ? min(dm[t], dist2_u32(unpack_pt(v[t], bw, bh), c)) : 0u;
+        dm[t] = m;
+        lsum += m;
+      }
+    // wave totals by DPP (two 32-bit halves: a lane's sum is below 2^33), the draw by wave 0, the
+    // scan over the lanes only inside the wave that owns the draw
+    const uint64_t wtot = (uint64_t)(uint32_t)wave_sum_i32((int)(lsum & 0xFFFFFFu)) +
+                          ((uint64_t)(uint32_t)wave_sum_i32((int)(lsum >> 24)) << 24);
+    if (lane == 0) L.scan[wave] = wtot;
+    __syncthreads();
+    if (wave == 0) {
+      uint64_t total = 0;
+      for (uint32_t wv = 0; wv < nw; ++wv) total += L.scan[wv];
+      if (total == 0) {
+        if (tid == 0) {
+          set_centre(L, j, pk[j < nf ? j : 0], bw, bh);
+          L.pick = 0xFFFFFFFFu;
+        }
+      } else {
+        uint64_t r = seg_hash(aseed ^ j) % total;
+        uint32_t owner = 0;
+        for (; owner + 1 < nw && r >= L.scan[owner]; ++owner) r -= L.scan[owner];
+        if (tid == 0) { L.pick = owner; L.draw = r; }  // r is now relative to the owner's first point
+      }
+    }
+    __syncthreads();
+    if (L.pick == wave) {
+      const uint64_t r = L.draw;
+      const uint64_t excl = wave_incl_scan_u64(lsum, lane) - lsum;
+      if (r >= excl && r - excl < lsum) {  // exactly one lane owns the crossing
+        uint64_t acc = excl;
+        bool found = false;
+#pragma unroll
+        for (uint32_t t = 0; t < kRegPts; ++t)
+          if (t < pper) {
+            acc += dm[t];
+            if (!found && acc > r) { found = true; set_centre(L, j, v[t], bw, bh); }
+          }
+      }
+    }
+    __syncthreads();
+  }
+  lloyd_begin(L, k, tid);
+  SEG_STAMP(4);
+
+  uint32_t oldpack[kRegPts / 4];  // the points' current labels, a byte each
+#pragma unroll
+  for (uint32_t g = 0; g < kRegPts / 4; ++g) oldpack[g] = 0xFFFFFFFFu;
+  uint64_t compact = 0;
+  for (uint32_t it = 0;; ++it) {
+    uint64_t lc = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < kRegPts / 4; ++g)
+      if (4 * g < pper) {
+        uint32_t vq[4], oldj[4], bj[4];
+        bool act[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t t = 4 * g + u;
+          vq[u] = v[t];
+          act[u] = t < pper && p0 + t < nf;
+          oldj[u] = (oldpack[g] >> (8 * u)) & 0xFFu;
+        }
+        lloyd_quad(vq, act, oldj, bj, lc, L, k, bw, bh, lane);
+        uint32_t np = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) np |= (act[u] ? bj[u] : 0xFFu) << (8 * u);
+        oldpack[g] = np;
+      }
+    SEG_STAMP(5 + 2 * it);
+    const bool done = lloyd_end_iter(lc, compact, it, L, a, k, tid, lane);
+    SEG_STAMP(6 + 2 * it);
+    if (done) break;
+  }
+#pragma unroll
+  for (uint32_t t = 0; t < kRegPts; ++t)
+    if (t < pper && p0 + t < nf) lab[p0 + t] = (uint8_t)((oldpack[t / 4] >> (8 * (t & 3))) & 0xFFu);
+  return compact;
+}
+
+// The same attempt for more than kRegPts points per lane (4K / 8K scene cuts): points and running
+// minima are read from `pk` / `dmin` (LDS when they fit, else the workspace) each time.  A wave owns a
+// contiguous chunk of the list and its lanes interleave inside it (conflict-free LDS, coalesced
+// global); the draw is located by wave totals first, then by a scan inside the one wave that holds it.
 __device__ __forceinline__ uint64_t kmeans_packed(const uint32_t* pk, uint32_t* dmin, uint8_t* lab, KmLds& L,
                                                   const SegArgs& a, uint32_t nf, uint32_t k, uint64_t aseed,
                                                   uint32_t tid, uint32_t te) {
   const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
   const uint32_t bw = a.mv_bw, bh = a.mv_bh;
-  if (tid == 0) {
-    const Pt p = unpack_pt(pk[(uint32_t)(seg_hash(aseed) % nf)], bw, bh);
-    L.cint[0][0] = p.f[0]; L.cint[0][1] = p.f[1]; L.cint[0][2] = p.f[2];
-  }
-  // k-means++: the next centre is drawn with probability ~ (distance to the nearest chosen centre)^2.
-  // Each point's running minimum is kept across steps, so a step costs ONE new distance per point.
-  // A wave owns a contiguous chunk of the list and its lanes interleave inside it (conflict-free LDS,
-  // coalesced global); the draw is located by wave totals first, then by a scan inside the one wave
-  // whose range holds it -- the same "first point whose inclusive prefix exceeds r" as a serial walk.
+  if (tid == 0) set_centre(L, 0, pk[(uint32_t)(seg_hash(aseed) % nf)], bw, bh);
   const uint32_t chunk = (((nf + nw - 1) / nw) + 63u) & ~63u;
   const uint32_t w0 = min(nf, wave * chunk), w1 = min(nf, w0 + chunk);
   for (uint32_t i = w0 + lane; i < w1; i += 64) dmin[i] = 0xFFFFFFFFu;
@@ -320,10 +555,7 @@ __device__ __forceinline__ uint64_t kmeans_packed(const uint32_t* pk, uint32_t* 
       total += t;
     }
     if (total == 0) {
-      if (tid == 0) {
-        const Pt p = unpack_pt(pk[j < nf ? j : 0], bw, bh);
-        L.cint[j][0] = p.f[0]; L.cint[j][1] = p.f[1]; L.cint[j][2] = p.f[2];
-      }
+      if (tid == 0) set_centre(L, j, pk[j < nf ? j : 0], bw, bh);
     } else {
       const uint64_t r = seg_hash(aseed ^ j) % total;
       if (r >= woff && r - woff < wtot) {  // wave-uniform: exactly one wave owns the crossing
@@ -333,10 +565,7 @@ __device__ __forceinline__ uint64_t kmeans_packed(const uint32_t* pk, uint32_t* 
           const uint64_t incl = wave_incl_scan_u64(i < w1 ? dmin[i] : 0u, lane);
           const unsigned long long bal = __ballot(acc + incl > r);
           if (bal) {
-            if (lane == (uint32_t)__builtin_ctzll(bal)) {
-              const Pt p = unpack_pt(pk[i], bw, bh);
-              L.cint[j][0] = p.f[0]; L.cint[j][1] = p.f[1]; L.cint[j][2] = p.f[2];
-            }
+            if (lane == (uint32_t)__builtin_ctzll(bal)) set_centre(L, j, pk[i], bw, bh);
             break;
           }
           acc += readlane_u64(incl, 63);
@@ -345,83 +574,27 @@ __device__ __forceinline__ uint64_t kmeans_packed(const uint32_t* pk, uint32_t* 
     }
     __syncthreads();
   }
-  if (tid < k) {
-    L.c[tid][0] = (double)L.cint[tid][0];
-    L.c[tid][1] = (double)L.cint[tid][1];
-    L.c[tid][2] = (double)L.cint[tid][2];
-  }
-  __syncthreads();
+  lloyd_begin(L, k, tid);
 
   uint64_t compact = 0;
-  for (uint32_t it = 0;; ++it) {  // Lloyd
-    if (tid < k) { L.sum[tid][0] = 0; L.sum[tid][1] = 0; L.sum[tid][2] = 0; L.cnt[tid] = 0; }
-    if (tid == 0) L.compact = 0;
-    __syncthreads();
+  for (uint32_t it = 0;; ++it) {
     uint64_t lc = 0;
-    for (uint32_t i0 = 0; i0 < nf; i0 += 2 * te) {  // wave-uniform trip count; two points per lane and trip
-      const uint32_t iA = i0 + tid, iB = iA + te;
-      const bool actA = iA < nf, actB = iB < nf;
-      const uint32_t vA = actA ? pk[iA] : 0u, vB = actB ? pk[iB] : 0u;
-      const Pt pA = unpack_pt(vA, bw, bh), pB = unpack_pt(vB, bw, bh);
-      double bestA = dist2_dbl(pA, L.c[0]), bestB = dist2_dbl(pB, L.c[0]);
-      uint32_t bjA = 0, bjB = 0;
-      for (uint32_t j = 1; j < k; ++j) {
-        const double c3[3] = {L.c[j][0], L.c[j][1], L.c[j][2]};
-        const double dA = dist2_dbl(pA, c3), dB = dist2_dbl(pB, c3);
-        if (dA < bestA) { bestA = dA; bjA = j; }
-        if (dB < bestB) { bestB = dB; bjB = j; }
-      }
-      if (actA) { lab[iA] = (uint8_t)bjA; lc += (unsigned long long)(bestA * 256.0); }
-      if (actB) { lab[iB] = (uint8_t)bjB; lc += (unsigned long long)(bestB * 256.0); }
-      // per-cluster sums of (1, mv.x + 8192, column, row): peel the clusters present in the wave one
-      // by one, reduce inside the wave by DPP (column and row share a word), ONE LDS atomic per wave,
-      // cluster and field.  All integers, so the order of the adds is immaterial.
+    for (uint32_t i0 = 0; i0 < nf; i0 += 4 * te) {  // wave-uniform trip count
+      uint32_t vq[4], oldj[4], bj[4];
+      bool act[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const bool act = h ? actB : actA;
-        const uint32_t bj = h ? bjB : bjA, v = h ? vB : vA;
-        const int xy = (int)((v & 511u) | (((v >> 9) & 511u) << 16)), mb = ((int)v >> 18) + 8192;
-        unsigned long long rem = __ballot(act);
-        while (rem) {
-          const uint32_t j = __builtin_amdgcn_readlane(bj, __builtin_ctzll(rem));
-          const bool mine = act && bj == j;
-          const unsigned long long bal = __ballot(mine);
-          rem &= ~bal;
-          const int sxy = wave_sum_i32(mine ? xy : 0), sm = wave_sum_i32(mine ? mb : 0);
-          if (lane == 0) {
-            atomicAdd(&L.cnt[j], (uint32_t)__popcll(bal));
-            atomicAdd(&L.sum[j][0], (unsigned long long)sm);
-            atomicAdd(&L.sum[j][1], (unsigned long long)(sxy & 0xFFFF));
-            atomicAdd(&L.sum[j][2], (unsigned long long)(sxy >> 16));
-          }
-        }
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * te + tid;
+        act[u] = i < nf;
+        vq[u] = act[u] ? pk[i] : 0u;
+        oldj[u] = (it && act[u]) ? lab[i] : 0xFFu;
       }
-    }
-    lc = wave_sum_u64(lc);
-    if (lane == 0) atomicAdd(&L.compact, (unsigned long long)lc);
-    __syncthreads();
-    compact = L.compact;
-    if (it + 1 >= a.max_iter) break;
-    if (tid < k) {
-      double s = 0.0;
-      const uint32_t cnt = L.cnt[tid];
-      if (cnt) {
-        const long long sums[3] = {(long long)L.sum[tid][0] - 8192ll * cnt, (long long)L.sum[tid][1] * bw,
-                                   (long long)L.sum[tid][2] * bh};
+      lloyd_quad(vq, act, oldj, bj, lc, L, k, bw, bh, lane);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const double nc = (double)sums[d] / (double)cnt;
-          const double t = nc - L.c[tid][d];
-          s = s + t * t;
-          L.c[tid][d] = nc;
-        }
-      }
-      L.shift[tid] = s;
+      for (uint32_t u = 0; u < 4; ++u)
+        if (act[u] && bj[u] != oldj[u]) lab[i0 + u * te + tid] = (uint8_t)bj[u];
     }
-    __syncthreads();
-    double shift = 0.0;
-    for (uint32_t j = 0; j < k; ++j) shift = L.shift[j] > shift ? L.shift[j] : shift;
-    if (shift <= a.eps2) break;
+    if (lloyd_end_iter(lc, compact, it, L, a, k, tid, lane)) break;
   }
   return compact;
 }
@@ -544,75 +717,115 @@ __device__ __forceinline__ uint64_t kmeans_generic(const Pt* pts, uint8_t* lab, 
 // Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
 // (cv::kmeans' `attempts`), so they run side by side instead of one after the other; each
 // rebuilds the (cheap) mask + foreground list for itself.
-// LDS_ARRAYS: the two byte masks live in dynamic LDS (first and last n bytes of it) during the
-// build; afterwards the whole of it holds the packed points and, if they fit too, the running minima.
-template <bool LDS_ARRAYS>
+// Dynamic LDS: two bit fields + the flat bitmap they are built from (a.bits_bytes), then the list /
+// packed points (and the running minima of the large-frame path) in whatever is left.
 __global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
   __shared__ KmLds L;
 
   const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint8_t* mask = a.mask + (size_t)frame * n;
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
-  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  uint8_t* tmp = LDS_ARRAYS ? dyn_lds : ws.masks(att) + n;
-  uint8_t* fg = LDS_ARRAYS ? dyn_lds + (a.lds_bytes - n4) : ws.masks(att);
   uint8_t* lab = ws.lab(att);
   uint32_t* idx = ws.idx();
   const uint64_t seed = a.seed + frame;
+#ifdef SVC_SEG_TIMING
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(lab + ((n - 256) & ~7u));
+#else
+  unsigned long long* stamps = nullptr;
+#endif
+  SEG_STAMP(0);
 
-  // ---- foreground mask, close, open (encoder.cpp:507-527) ---------------------------------
+  BitField bf;
+  bf.W32 = (a.mfw + 31) / 32; bf.H = a.mfh; bf.NW = bf.W32 * bf.H;
+  bf.last_valid = (a.mfw & 31u) ? ((1u << (a.mfw & 31u)) - 1u) : ~0u;
+  uint32_t* bitA = reinterpret_cast<uint32_t*>(dyn_lds);
+  uint32_t* bitB = bitA + bf.NW;
+  uint32_t* flat = bitB + bf.NW;
+  uint32_t* lst_lds = reinterpret_cast<uint32_t*>(dyn_lds + a.bits_bytes);
+  const size_t lds_cap = a.lds_bytes - a.bits_bytes;
+
+  // ---- foreground = complement of the inliers (encoder.cpp:507-513), one bit per block ---------
+  const uint32_t trips = (n + kTA - 1) / kTA;
+  for (uint32_t t = 0; t < trips; ++t) {
+    const uint32_t i = t * kTA + tid;
+    const unsigned long long bal = __ballot(i < n && mask[i] == 0);
+    if (lane == 0) {
+      flat[2 * (t * (kTA / 64) + wave)] = (uint32_t)bal;
+      flat[2 * (t * (kTA / 64) + wave) + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+  if (tid < 2) flat[trips * (kTA / 32) + tid] = 0;
   if (tid == 0) L.bad = 0;
-  for (uint32_t i = tid; i < n; i += kTA) fg[i] = mask[i] ? 0 : 255;
   __syncthreads();
-  morph_pass(fg, tmp, a, true, tid, kTA);
-  morph_pass(tmp, fg, a, false, tid, kTA);
-  morph_pass(fg, tmp, a, false, tid, kTA);
-  morph_pass(tmp, fg, a, true, tid, kTA);
+  for (uint32_t q = tid; q < bf.NW; q += kTA) {
+    const uint32_t y = q / bf.W32, w = q - y * bf.W32;
+    const uint32_t o = y * a.mfw + 32 * w, fw = o >> 5, fb = o & 31u;
+    const uint32_t v = fb ? (flat[fw] >> fb) | (flat[fw + 1] << (32 - fb)) : flat[fw];
+    bitA[q] = w == bf.W32 - 1 ? v & bf.last_valid : v;
+  }
+  __syncthreads();
+  // ---- close, open (:515-527) --------------------------------------------------------------------
+  bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, false, tid);
+  bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, true, tid);
+  bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, true, tid);
+  bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, false, tid);
+  SEG_STAMP(1);
 
   // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
-  const uint32_t per = (n + kTA - 1) / kTA;
-  const uint32_t c0 = min(n, tid * per), c1 = min(n, c0 + per);
+  const uint32_t wper = (bf.NW + kTA - 1) / kTA;
+  const uint32_t q0 = min(bf.NW, tid * wper), q1 = min(bf.NW, q0 + wper);
   uint32_t local = 0;
-  bool bad = false;
-  for (uint32_t i = c0; i < c1; ++i)
-    if (fg[i] == 255) {
-      ++local;
+  for (uint32_t q = q0; q < q1; ++q) local += __popc(bitA[q]);
+  uint64_t tot64;
+  const uint32_t pos0 = (uint32_t)block_excl_scan(local, L.scan, tid, kTA / 64, &tot64);
+  const uint32_t nf = (uint32_t)tot64;
+  if (nf == 0) {
+    if (att == 0 && tid == 0) *ws.nf() = 0;
+    return;
+  }
+  uint32_t* lst = 4 * (size_t)nf <= lds_cap ? lst_lds : reinterpret_cast<uint32_t*>(ws.pts(att));
+  if (a.packable) {
+    uint32_t pos = pos0;
+    for (uint32_t q = q0; q < q1; ++q) {
+      const uint32_t y = q / bf.W32, base = y * a.mfw + 32 * (q - y * bf.W32);
+      for (uint32_t bits = bitA[q]; bits; bits &= bits - 1) lst[pos++] = base + (uint32_t)__builtin_ctz(bits);
+    }
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t q = tid; q < nf; q += kTA) {
+      const uint32_t i = lst[q];
+      const uint32_t y = i / a.mfw, x = i - y * a.mfw;
       const float mx = mv[i].x;
       bad = bad || !(mx > -8191.0f && mx < 8191.0f);
+      lst[q] = pack_pt((int)(mx < 0 ? mx - 0.5f : mx + 0.5f), x, y);
+      if (att == 0) idx[q] = i;
     }
-  if (bad) L.bad = 1;
-  uint64_t tot64;
-  uint32_t pos = (uint32_t)block_excl_scan(local, L.scan, tid, kTA / 64, &tot64);
-  const uint32_t nf = (uint32_t)tot64;
+    if (bad) L.bad = 1;
+    __syncthreads();
+  }
   const bool packed = a.packable != 0 && L.bad == 0;
-  const size_t build_cap = LDS_ARRAYS ? a.lds_bytes - n4 : a.lds_bytes;
-  const bool pk_lds = packed && 4 * (size_t)nf <= build_cap;
-  uint32_t* pk = pk_lds ? reinterpret_cast<uint32_t*>(dyn_lds) : reinterpret_cast<uint32_t*>(ws.pts(att));
   Pt* pts = ws.pts(att);
-  {
-    uint32_t y = c0 / a.mfw, x = c0 - y * a.mfw;
-    for (uint32_t i = c0; i < c1; ++i) {
-      if (fg[i] == 255) {
-        if (att == 0) idx[pos] = i;
+  if (!packed) {  // never for block-matching output: serial per word, straight to the workspace
+    uint32_t pos = pos0;
+    for (uint32_t q = q0; q < q1; ++q) {
+      const uint32_t y = q / bf.W32, x0 = 32 * (q - y * bf.W32);
+      for (uint32_t bits = bitA[q]; bits; bits &= bits - 1) {
+        const uint32_t x = x0 + (uint32_t)__builtin_ctz(bits), i = y * a.mfw + x;
         const float mx = mv[i].x;
-        const int r = (int)(mx < 0 ? mx - 0.5f : mx + 0.5f);
-        if (packed) {
-          pk[pos] = pack_pt(r, x, y);
-        } else {
-          Pt p;
-          p.f[0] = r; p.f[1] = (int)(x * a.mv_bw); p.f[2] = (int)(y * a.mv_bh);
-          pts[pos] = p;
-        }
+        Pt p;
+        p.f[0] = (int)(mx < 0 ? mx - 0.5f : mx + 0.5f); p.f[1] = (int)(x * a.mv_bw); p.f[2] = (int)(y * a.mv_bh);
+        pts[pos] = p;
+        if (att == 0) idx[pos] = i;
         ++pos;
       }
-      if (++x == a.mfw) { x = 0; ++y; }
     }
   }
   if (att == 0 && tid == 0) *ws.nf() = nf;
   __syncthreads();
-  if (nf == 0) return;
+  SEG_STAMP(2);
   const uint32_t te = lanes_for(nf);
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
   const uint32_t k = min(a.k, nf);  // :555
@@ -620,13 +833,17 @@ __global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
   // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
   const uint64_t aseed = seed ^ ((uint64_t)att << 32);
   uint64_t compact;
-  if (packed) {
-    uint32_t* dmin = pk_lds && 8 * (size_t)nf <= a.lds_bytes ? reinterpret_cast<uint32_t*>(dyn_lds) + nf : ws.dmin(att);
-    compact = kmeans_packed(pk, dmin, lab, L, a, nf, k, aseed, tid, te);
+  SEG_STAMP(3);
+  if (packed && nf <= kRegPts * te) {
+    compact = kmeans_regs(lst, lab, L, a, nf, k, aseed, tid, te, stamps);
+  } else if (packed) {
+    uint32_t* dmin = (lst == lst_lds && 8 * (size_t)nf <= lds_cap) ? lst_lds + nf : ws.dmin(att);
+    compact = kmeans_packed(lst, dmin, lab, L, a, nf, k, aseed, tid, te);
   } else {
     compact = kmeans_generic(pts, lab, L, a, nf, k, aseed, tid, te);
   }
   if (tid == 0) ws.compact()[att] = compact;
+  SEG_STAMP(31);
 }
 
 // Kernel B: one workgroup per frame.  Takes the attempt with the smallest compactness (ties ->
@@ -650,15 +867,13 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   const uint32_t* idx = ws.idx();
   uint32_t* roots = ws.roots();
   const uint32_t nf = *ws.nf();
+#ifdef SVC_SEG_TIMING
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(roots + ((n - 64) & ~1u));
+#endif
+  SEG_STAMP(0);
 
   for (uint32_t i = tid; i < n; i += kTA) { types[i] = 0; cl[i] = 255; }  // :549-551
   if (nf == 0) return;
-  const uint32_t te = lanes_for(nf);
-  if (tid >= te) {  // the clears above must be visible to the lanes that stay
-    __syncthreads();
-    return;
-  }
-  const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
   const uint32_t k = min(a.k, nf);
   uint32_t best = 0;
   unsigned long long best_c = ws.compact()[0];
@@ -667,36 +882,69 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
     if (c < best_c) { best_c = c; best = t; }
   }
   const uint8_t* best_lab = ws.lab(best);
-  for (uint32_t j = tid; j < (kTA / 64) * kMaxK; j += te) (&s_wcnt[0][0])[j] = 0;
+  for (uint32_t j = tid; j < (kTA / 64) * kMaxK; j += kTA) (&s_wcnt[0][0])[j] = 0;
   if (tid < kMaxK) s_base[tid] = 0;
   __syncthreads();
-  for (uint32_t i = tid; i < nf; i += te) {
-    const uint32_t b = idx[i];
-    cl[b] = best_lab[i];
-    parent[b] = b;
-  }
+  for (uint32_t i = tid; i < nf; i += kTA) cl[idx[i]] = best_lab[i];
   __syncthreads();
-  // merge every foreground block with its already-visited neighbours of the same cluster, then flatten
+  SEG_STAMP(1);
+  // Horizontal runs first, without a single union: a wave looks at 64 consecutive blocks, one ballot
+  // says which of them continue the run of their left neighbour, and every block of a run is pointed
+  // straight at the run's first block inside the window (the smallest index, as the forest wants).
+  {
+    const uint32_t step_x = kTA % a.mfw, step_y = kTA / a.mfw;
+    uint32_t y = tid / a.mfw, x = tid - y * a.mfw;
+    const uint32_t lane = tid & 63u;
+    for (uint32_t i0 = 0; i0 < n; i0 += kTA) {
+      const uint32_t i = i0 + tid;
+      const uint32_t c = i < n ? cl[i] : 255u;
+      const bool same_left = c != 255u && x > 0 && cl[i - 1] == c;
+      const unsigned long long sbits = __ballot(same_left);
+      if (c != 255u) {
+        const unsigned long long z = ~sbits & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        parent[i] = i - lane + (z ? 63u - (uint32_t)__builtin_clzll(z) : 0u);
+      }
+      x += step_x; y += step_y;
+      if (x >= a.mfw) { x -= a.mfw; ++y; }
+    }
+  }
+  const uint32_t te = lanes_for(nf);
+  __syncthreads();
+  if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
+  const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
+  // Then only the unions the runs do not already imply: a run that crosses a window boundary, and a
+  // block with the row above -- skipped where the left neighbour provably made the same connection
+  // (its own vertical link plus the run in the row above), which is everywhere inside a blob.
   for (uint32_t q = tid; q < nf; q += te) {
     const uint32_t i = idx[q];
-    const uint8_t c = cl[i];
-    const int y = (int)(i / a.mfw), x = (int)(i - (uint32_t)y * a.mfw);
-    if (x > 0 && cl[i - 1] == c) uf_unite(parent, i, i - 1);
+    const uint32_t c = cl[i];
+    const uint32_t y = i / a.mfw, x = i - y * a.mfw;
+    const bool left = x > 0 && cl[i - 1] == c;
+    if (left && (i & 63u) == 0) uf_unite(parent, i, i - 1);
     if (y > 0) {
-      if (cl[i - a.mfw] == c) uf_unite(parent, i, i - a.mfw);
-      if (a.conn == 8) {
-        if (x > 0 && cl[i - a.mfw - 1] == c) uf_unite(parent, i, i - a.mfw - 1);
-        if (x + 1 < (int)a.mfw && cl[i - a.mfw + 1] == c) uf_unite(parent, i, i - a.mfw + 1);
+      const bool up = cl[i - a.mfw] == c;
+      const bool upleft = x > 0 && cl[i - a.mfw - 1] == c;
+      if (a.conn == 4) {
+        if (up && !(left && upleft)) uf_unite(parent, i, i - a.mfw);
+      } else if (up) {  // up-left and up-right sit in up's run
+        if (!(left && upleft)) uf_unite(parent, i, i - a.mfw);
+      } else {
+        if (upleft && !left) uf_unite(parent, i, i - a.mfw - 1);  // else the left neighbour is linked to it
+        const bool upright = x + 1 < a.mfw && cl[i - a.mfw + 1] == c;
+        const bool right = x + 1 < a.mfw && cl[i + 1] == c;
+        if (upright && !right) uf_unite(parent, i, i - a.mfw + 1);  // else the right neighbour links to it
       }
     }
   }
   __syncthreads();
+  SEG_STAMP(2);
   for (uint32_t q = tid; q < nf; q += te) {
     const uint32_t i = idx[q];
     const uint32_t r = uf_find(parent, i);
     if (r != i) parent[i] = r;  // still an ancestor for any concurrent walker; roots are never rewritten
   }
   __syncthreads();
+  SEG_STAMP(3);
   // component roots, compacted in raster order (lane-contiguous ranges of the list + one block scan)
   const uint32_t pper = (nf + te - 1) / te;
   const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
@@ -716,6 +964,7 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   // the clusters present, across waves and rounds by the small per-(wave, cluster) table.  A root's
   // parent entry becomes 0x80000000 | its 1-based number (nobody walks the forest any more).
   const uint32_t R = (uint32_t)total_roots;
+  SEG_STAMP(4);
   for (uint32_t r0 = 0; r0 < R; r0 += te) {
     const uint32_t q = r0 + tid;
     const bool act = q < R;
@@ -745,6 +994,7 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
     }
     __syncthreads();
   }
+  SEG_STAMP(5);
   if (tid == 0) {  // BLOCK_TYPE_BACKGROUND = 0 (libs/codec.hpp:6); :620, the count includes label 0
     uint32_t offset = 0;
     for (uint32_t cid = 0; cid < k; ++cid) {
@@ -760,6 +1010,10 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
     if (!(pv & 0x80000000u)) pv = parent[pv];
     types[i] = (pv & 0x7FFFFFFFu) + s_base[cl[i]];  // :617
   }
+  SEG_STAMP(6);
+#ifdef SVC_SEG_TIMING
+  if (tid == 0) stamps[7] = R;
+#endif
 }
 
 uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts) {
@@ -794,13 +1048,13 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   const bool small_coords = (uint64_t)mfw * mv_bw < (1u << 14) && (uint64_t)mfh * mv_bh < (1u << 14);
   a.packable = (small_coords && mfw <= 512 && mfh <= 512) ? 1u : 0u;
   constexpr size_t kLdsBig = 144 * 1024;  // of the CU's 160 KB; the static part takes ~5 KB
-  if (6 * n4 <= 96 * 1024) {  // small fields (1080p: 8 160 blocks, 48 KB): masks, points and minima all in LDS
-    a.lds_bytes = (uint32_t)(6 * n4);
-    hipLaunchKernelGGL((segment_attempt_kernel<true>), grid_a, dim3(kTA), a.lds_bytes, stream, a);
-  } else {  // big fields (4K: 32 400 blocks): masks in the workspace, LDS for the packed points (+ minima)
-    a.lds_bytes = (uint32_t)kLdsBig;
-    hipLaunchKernelGGL((segment_attempt_kernel<false>), grid_a, dim3(kTA), a.lds_bytes, stream, a);
-  }
+  // two bit fields (rows padded to words) + the flat bitmap (whole 1024-bit trips + 2 words)
+  const size_t bit_words = 2 * (size_t)((mfw + 31) / 32) * mfh + (size_t)((a.n + kTA - 1) / kTA) * (kTA / 32) + 2;
+  a.bits_bytes = (uint32_t)((4 * bit_words + 15) & ~(size_t)15);
+  if (a.bits_bytes + 4096 > kLdsBig)
+    return fail(SVC_ERR_UNSUPPORTED, "segment: motion field of %u x %u blocks is too large", mfw, mfh);
+  a.lds_bytes = (uint32_t)(a.bits_bytes + 4 * n4 <= kLdsBig ? a.bits_bytes + 4 * n4 : kLdsBig);
+  hipLaunchKernelGGL(segment_attempt_kernel, grid_a, dim3(kTA), a.lds_bytes, stream, a);
   if (5 * n4 <= kLdsBig)
     hipLaunchKernelGGL((segment_label_kernel<true, true>), dim3(n_frames), dim3(kTA), 5 * n4, stream, a);
   else if (4 * n4 <= kLdsBig)
