@@ -1,5 +1,5 @@
-// segment.hip -- RANSAC inliers + motion field -> region id per MV block, batched:
-// one wavefront per frame.  Reference: libs/encoder.cpp:507-623.
+// segment.hip -- RANSAC inliers + motion field -> region id per MV block, batched over frames.
+// Reference: libs/encoder.cpp:507-623.
 //
 // The in-repo steps are the reference's (foreground = complement of the inliers :507-513,
 // raster-order foreground list :538-546, BuildMvFeatures' (0, mv.x, x_px, y_px) with its
@@ -7,17 +7,21 @@
 // connected components numbered with `offset += count including label 0` :597-623).
 // The OpenCV steps (morphologyEx close/open, kmeans, connectedComponents) cannot be pinned
 // offline; they follow this repo's deterministic definitions, stated in
-// oracle/svc_segment.c, which this kernel reproduces bit for bit.  Everything that could
+// oracle/svc_segment.c, which these kernels reproduce bit for bit.  Everything that could
 // depend on a summation order is exact integer arithmetic (k-means++ weights, centre sums,
 // fixed-point compactness), so the parallel reductions here are order-free; the remaining
 // floating point is per-element f64 in a fixed operation order (FP contraction is off).
 //
-// The work is latency-bound (hundreds of short barrier-separated phases over a small field), so it
-// is cut to shorten the chain: kernel A runs every k-means attempt of every frame as its own
-// workgroup (grid = frames x attempts); kernel B picks the best attempt per frame and does the
-// connected components (a lock-free union-find: one merge sweep + one flatten sweep).  Byte
-// masks, feature points and union-find parents sit in LDS when they fit, otherwise in the
-// caller-provided global workspace (L2-resident).
+// The work is latency-bound (hundreds of short barrier-separated phases over a small field) and
+// very uneven (most frames have a few hundred foreground blocks, a scene cut has most of the
+// field), so it is cut into kernels that each get the width they need:
+//   P  one workgroup per frame, 1024 lanes: mask -> bit rows, close/open as word operations,
+//      foreground list + feature points packed into 32 bits;
+//   A  one workgroup per (frame, k-means attempt), launched 256 lanes wide for the light frames
+//      and 1024 wide for the heavy ones, the points of a lane in registers throughout;
+//   B  one workgroup per frame: best attempt, connected components (horizontal runs by ballot,
+//      then a lock-free union-find over the few links the runs do not imply), numbering.
+// Lists, labels and whatever does not fit LDS sit in the caller-provided workspace (L2-resident).
 #include "svc_common.hpp"
 
 namespace svc {
@@ -217,11 +221,11 @@ __device__ __forceinline__ void bit_morph(const uint32_t* src, uint32_t* tmp, ui
 }
 
 // ---- workspace layout (per frame) -----------------------------------------------------------
-//   [0, 256)            header: u32 nf at 0; u64 compactness[attempt] at 8 + 8 * attempt
-//   idx      [n]  u32   foreground list, raster order (written by attempt 0's workgroup)
+//   [0, 256)            header: u32 nf at 0; u32 "points are packed" at 4; u64 compactness[attempt] at 8 + 8 * attempt
+//   idx      [n]  u32   foreground list, raster order
+//   pk       [n]  u32   packed feature points, list order
 //   lab      [A][n] u8  labels of each k-means attempt
-//   pts      [A][n] Pt  feature points of an attempt when they do not fit LDS (packed points use the
-//                       first 4n bytes of the slot)
+//   pts      [n] Pt     unpacked feature points (only for frames whose points cannot be packed)
 //   dmin     [A][n] u32 k-means++ running minima when they do not fit registers or LDS
 //   cl [n] u8, parent [n] u32: connected-components arrays when they do not fit LDS
 //   roots    [n] u32    component roots in raster order
@@ -232,18 +236,21 @@ struct Workspace {
   uint32_t n, attempts;
   __host__ __device__ static uint64_t a16(uint64_t v) { return (v + 15) & ~15ull; }
   __host__ __device__ uint64_t off_idx() const { return 256; }
-  __host__ __device__ uint64_t off_lab() const { return off_idx() + a16(4ull * n); }
+  __host__ __device__ uint64_t off_pk() const { return off_idx() + a16(4ull * n); }
+  __host__ __device__ uint64_t off_lab() const { return off_pk() + a16(4ull * n); }
   __host__ __device__ uint64_t off_pts() const { return off_lab() + a16((uint64_t)attempts * n); }
-  __host__ __device__ uint64_t off_dmin() const { return off_pts() + a16(12ull * attempts * n); }
+  __host__ __device__ uint64_t off_dmin() const { return off_pts() + a16(12ull * n); }
   __host__ __device__ uint64_t off_cl() const { return off_dmin() + a16(4ull * attempts * n); }
   __host__ __device__ uint64_t off_parent() const { return off_cl() + a16(n); }
   __host__ __device__ uint64_t off_roots() const { return off_parent() + a16(4ull * n); }
   __host__ __device__ uint64_t bytes() const { return (off_roots() + 4ull * n + 255) & ~255ull; }
   __device__ uint32_t* nf() const { return reinterpret_cast<uint32_t*>(base); }
+  __device__ uint32_t* packed() const { return reinterpret_cast<uint32_t*>(base + 4); }
   __device__ unsigned long long* compact() const { return reinterpret_cast<unsigned long long*>(base + 8); }
   __device__ uint32_t* idx() const { return reinterpret_cast<uint32_t*>(base + off_idx()); }
+  __device__ uint32_t* pk() const { return reinterpret_cast<uint32_t*>(base + off_pk()); }
   __device__ uint8_t* lab(uint32_t a) const { return base + off_lab() + (uint64_t)a * n; }
-  __device__ Pt* pts(uint32_t a) const { return reinterpret_cast<Pt*>(base + off_pts() + 12ull * a * n); }
+  __device__ Pt* pts() const { return reinterpret_cast<Pt*>(base + off_pts()); }
   __device__ uint32_t* dmin(uint32_t a) const { return reinterpret_cast<uint32_t*>(base + off_dmin() + 4ull * a * n); }
   __device__ uint8_t* cl() const { return base + off_cl(); }
   __device__ uint32_t* parent() const { return reinterpret_cast<uint32_t*>(base + off_parent()); }
@@ -256,14 +263,11 @@ struct Workspace {
 #define SEG_STAMP(slot) do { } while (0)
 #endif
 
-// Both kernels are launched kTA lanes wide, which is what the field-sized sweeps (bitmap, clears)
-// want.  Once a frame's foreground count is known the workgroup keeps only the lanes that count can
-// feed: the rest of its waves end there (s_barrier counts surviving waves only), so the hundreds of
-// short barrier-separated k-means / labelling phases of a light frame run on one or four waves
-// while a heavy frame (a scene cut: most of the field is foreground) keeps all sixteen.
+// The labelling kernel is launched kTA lanes wide, which is what its field-sized sweeps (clears, runs)
+// want; once those are done the workgroup keeps only the lanes the frame's foreground count can feed:
+// the rest of its waves end there (s_barrier counts surviving waves only).
 __device__ __forceinline__ uint32_t lanes_for(uint32_t nf) { return nf <= 64 ? 64u : nf <= 1024 ? 256u : kTA; }
 
-constexpr uint32_t kRegPts = 8;  // points a lane keeps in registers through one k-means attempt
 
 struct KmLds {
   uint64_t scan[kTA / 64];
@@ -415,19 +419,19 @@ __device__ __forceinline__ bool lloyd_end_iter(uint64_t lc, uint64_t& compact, u
 }
 
 // One k-means attempt with the lane's points in registers: lane t owns the list entries
-// [t * pper, (t + 1) * pper), pper <= kRegPts -- every frame of at most 8 192 foreground blocks.
-// `pk` (LDS or workspace) is only read once, and for the drawn centres.
+// [t * pper, (t + 1) * pper), pper <= P.  `pk` is only read once, and for the drawn centres.
+template <uint32_t P>
 __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab, KmLds& L, const SegArgs& a,
                                                 uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te,
                                                 unsigned long long* stamps) {
   const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
   const uint32_t bw = a.mv_bw, bh = a.mv_bh;
   (void)stamps;
-  const uint32_t pper = (nf + te - 1) / te;  // block-uniform, <= kRegPts
+  const uint32_t pper = (nf + te - 1) / te;  // block-uniform, <= P
   const uint32_t p0 = tid * pper;
-  uint32_t v[kRegPts], dm[kRegPts];
+  uint32_t v[P], dm[P];
 #pragma unroll
-  for (uint32_t t = 0; t < kRegPts; ++t) {
+  for (uint32_t t = 0; t < P; ++t) {
     v[t] = (t < pper && p0 + t < nf) ? pk[p0 + t] : 0u;
     dm[t] = 0xFFFFFFFFu;
   }
@@ -441,7 +445,7 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
     const int c[3] = {L.cint[j - 1][0], L.cint[j - 1][1], L.cint[j - 1][2]};
     uint64_t lsum = 0;
 #pragma unroll
-    for (uint32_t t = 0; t < kRegPts; ++t)
+    for (uint32_t t = 0; t < P; ++t)
       if (t < pper) {
         const uint32_t m = p0 + t < nf ? min(dm[t], dist2_u32(unpack_pt(v[t], bw, bh), c)) : 0u;
         dm[t] = m;
@@ -476,7 +480,7 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
         uint64_t acc = excl;
         bool found = false;
 #pragma unroll
-        for (uint32_t t = 0; t < kRegPts; ++t)
+        for (uint32_t t = 0; t < P; ++t)
           if (t < pper) {
             acc += dm[t];
             if (!found && acc > r) { found = true; set_centre(L, j, v[t], bw, bh); }
@@ -488,14 +492,14 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
   lloyd_begin(L, k, tid);
   SEG_STAMP(4);
 
-  uint32_t oldpack[kRegPts / 4];  // the points' current labels, a byte each
+  uint32_t oldpack[P / 4];  // the points' current labels, a byte each
 #pragma unroll
-  for (uint32_t g = 0; g < kRegPts / 4; ++g) oldpack[g] = 0xFFFFFFFFu;
+  for (uint32_t g = 0; g < P / 4; ++g) oldpack[g] = 0xFFFFFFFFu;
   uint64_t compact = 0;
   for (uint32_t it = 0;; ++it) {
     uint64_t lc = 0;
 #pragma unroll
-    for (uint32_t g = 0; g < kRegPts / 4; ++g)
+    for (uint32_t g = 0; g < P / 4; ++g)
       if (4 * g < pper) {
         uint32_t vq[4], oldj[4], bj[4];
         bool act[4];
@@ -518,7 +522,7 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
     if (done) break;
   }
 #pragma unroll
-  for (uint32_t t = 0; t < kRegPts; ++t)
+  for (uint32_t t = 0; t < P; ++t)
     if (t < pper && p0 + t < nf) lab[p0 + t] = (uint8_t)((oldpack[t / 4] >> (8 * (t & 3))) & 0xFFu);
   return compact;
 }
@@ -714,27 +718,22 @@ __device__ __forceinline__ uint64_t kmeans_generic(const Pt* pts, uint8_t* lab, 
   return compact;
 }
 
-// Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
-// (cv::kmeans' `attempts`), so they run side by side instead of one after the other; each
-// rebuilds the (cheap) mask + foreground list for itself.
-// Dynamic LDS: two bit fields + the flat bitmap they are built from (a.bits_bytes), then the list /
-// packed points (and the running minima of the large-frame path) in whatever is left.
-__global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
+// Kernel P: one workgroup per frame.  Foreground mask, close, open, the foreground list in raster
+// order and the feature points (encoder.cpp:507-546, :300-321), shared by the frame's k-means attempts.
+// Dynamic LDS: two bit fields + the flat bitmap they are built from (a.bits_bytes), then the list.
+__global__ __launch_bounds__(kTA) void segment_prepare_kernel(SegArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-  __shared__ KmLds L;
+  __shared__ uint64_t s_scan[kTA / 64];
+  __shared__ uint32_t s_bad;
 
-  const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, n = a.n;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint8_t* mask = a.mask + (size_t)frame * n;
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
-  uint8_t* lab = ws.lab(att);
   uint32_t* idx = ws.idx();
-  const uint64_t seed = a.seed + frame;
 #ifdef SVC_SEG_TIMING
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(lab + ((n - 256) & ~7u));
-#else
-  unsigned long long* stamps = nullptr;
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws.dmin(0) + ((n - 64) & ~1u));
 #endif
   SEG_STAMP(0);
 
@@ -747,18 +746,27 @@ __global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
   uint32_t* lst_lds = reinterpret_cast<uint32_t*>(dyn_lds + a.bits_bytes);
   const size_t lds_cap = a.lds_bytes - a.bits_bytes;
 
-  // ---- foreground = complement of the inliers (encoder.cpp:507-513), one bit per block ---------
+  // ---- foreground = complement of the inliers (:507-513), one bit per block: 64 blocks per ballot,
+  // eight loads in flight per lane
   const uint32_t trips = (n + kTA - 1) / kTA;
-  for (uint32_t t = 0; t < trips; ++t) {
-    const uint32_t i = t * kTA + tid;
-    const unsigned long long bal = __ballot(i < n && mask[i] == 0);
-    if (lane == 0) {
-      flat[2 * (t * (kTA / 64) + wave)] = (uint32_t)bal;
-      flat[2 * (t * (kTA / 64) + wave) + 1] = (uint32_t)(bal >> 32);
+  for (uint32_t t0 = 0; t0 < trips; t0 += 8) {
+    uint8_t m[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t i = (t0 + u) * kTA + tid;
+      m[u] = i < n ? mask[i] : 1;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const unsigned long long bal = __ballot(m[u] == 0);
+      if (lane == 0 && t0 + u < trips) {
+        flat[2 * ((t0 + u) * (kTA / 64) + wave)] = (uint32_t)bal;
+        flat[2 * ((t0 + u) * (kTA / 64) + wave) + 1] = (uint32_t)(bal >> 32);
+      }
     }
   }
   if (tid < 2) flat[trips * (kTA / 32) + tid] = 0;
-  if (tid == 0) L.bad = 0;
+  if (tid == 0) s_bad = 0;
   __syncthreads();
   for (uint32_t q = tid; q < bf.NW; q += kTA) {
     const uint32_t y = q / bf.W32, w = q - y * bf.W32;
@@ -780,14 +788,13 @@ __global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
   uint32_t local = 0;
   for (uint32_t q = q0; q < q1; ++q) local += __popc(bitA[q]);
   uint64_t tot64;
-  const uint32_t pos0 = (uint32_t)block_excl_scan(local, L.scan, tid, kTA / 64, &tot64);
+  const uint32_t pos0 = (uint32_t)block_excl_scan(local, s_scan, tid, kTA / 64, &tot64);
   const uint32_t nf = (uint32_t)tot64;
-  if (nf == 0) {
-    if (att == 0 && tid == 0) *ws.nf() = 0;
-    return;
-  }
-  uint32_t* lst = 4 * (size_t)nf <= lds_cap ? lst_lds : reinterpret_cast<uint32_t*>(ws.pts(att));
+  if (tid == 0) *ws.nf() = nf;
+  if (nf == 0) return;
+  uint32_t* pk = ws.pk();
   if (a.packable) {
+    uint32_t* lst = 4 * (size_t)nf <= lds_cap ? lst_lds : idx;  // else expand straight into the workspace
     uint32_t pos = pos0;
     for (uint32_t q = q0; q < q1; ++q) {
       const uint32_t y = q / bf.W32, base = y * a.mfw + 32 * (q - y * bf.W32);
@@ -795,20 +802,34 @@ __global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
     }
     __syncthreads();
     bool bad = false;
-    for (uint32_t q = tid; q < nf; q += kTA) {
-      const uint32_t i = lst[q];
-      const uint32_t y = i / a.mfw, x = i - y * a.mfw;
-      const float mx = mv[i].x;
-      bad = bad || !(mx > -8191.0f && mx < 8191.0f);
-      lst[q] = pack_pt((int)(mx < 0 ? mx - 0.5f : mx + 0.5f), x, y);
-      if (att == 0) idx[q] = i;
+    for (uint32_t q0b = 0; q0b < nf; q0b += 4 * kTA) {  // four independent index -> mv chains per lane
+      uint32_t bi[4];
+      float mx[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t q = q0b + u * kTA + tid;
+        bi[u] = q < nf ? lst[q] : 0u;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) mx[u] = mv[bi[u]].x;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t q = q0b + u * kTA + tid;
+        if (q < nf) {
+          const uint32_t y = bi[u] / a.mfw, x = bi[u] - y * a.mfw;
+          bad = bad || !(mx[u] > -8191.0f && mx[u] < 8191.0f);
+          pk[q] = pack_pt((int)(mx[u] < 0 ? mx[u] - 0.5f : mx[u] + 0.5f), x, y);
+          if (lst != idx) idx[q] = bi[u];
+        }
+      }
     }
-    if (bad) L.bad = 1;
+    if (bad) s_bad = 1;
     __syncthreads();
   }
-  const bool packed = a.packable != 0 && L.bad == 0;
-  Pt* pts = ws.pts(att);
-  if (!packed) {  // never for block-matching output: serial per word, straight to the workspace
+  const bool packed = a.packable != 0 && s_bad == 0;
+  if (tid == 0) *ws.packed() = packed ? 1u : 0u;
+  if (!packed) {  // never for block-matching output: serial per word, unpacked points
+    Pt* pts = ws.pts();
     uint32_t pos = pos0;
     for (uint32_t q = q0; q < q1; ++q) {
       const uint32_t y = q / bf.W32, x0 = 32 * (q - y * bf.W32);
@@ -818,29 +839,66 @@ __global__ __launch_bounds__(kTA) void segment_attempt_kernel(SegArgs a) {
         Pt p;
         p.f[0] = (int)(mx < 0 ? mx - 0.5f : mx + 0.5f); p.f[1] = (int)(x * a.mv_bw); p.f[2] = (int)(y * a.mv_bh);
         pts[pos] = p;
-        if (att == 0) idx[pos] = i;
+        idx[pos] = i;
         ++pos;
       }
     }
   }
-  if (att == 0 && tid == 0) *ws.nf() = nf;
-  __syncthreads();
   SEG_STAMP(2);
-  const uint32_t te = lanes_for(nf);
+}
+
+// Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
+// (cv::kmeans' `attempts`), so they run side by side instead of one after the other.  Launched twice:
+// T = 256 lanes takes the frames of at most kLightMax foreground blocks (nearly all of them: four
+// waves per workgroup, several workgroups per CU, and the hundreds of short barrier-separated phases
+// of a light frame stay cheap; one wave when at most 64), T = 1024 the heavy ones (a scene cut: most of the field is
+// foreground); a workgroup whose frame belongs to the other launch ends at once.
+// Dynamic LDS (fields that can have more than kRegPts points per lane only): the packed points and,
+// if they fit too, the running minima of the path that does not keep them in registers.
+constexpr uint32_t kLightMax = 2048;
+constexpr uint32_t kRegPts = 8;  // points a lane keeps in registers through an attempt; frames with more per lane
+                                 // (> 8 192 blocks at 1 024 lanes) go through LDS / the workspace
+
+template <uint32_t T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void segment_attempt_kernel(SegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+  __shared__ KmLds L;
+
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
+  const uint32_t nf = *ws.nf();
+  if (nf == 0 || (nf > kLightMax) != (T == kTA)) return;
+  const uint32_t te = T == kTA ? kTA : nf <= 64 ? 64u : 256u;
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
+  uint8_t* lab = ws.lab(att);
+#ifdef SVC_SEG_TIMING
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(lab + ((n - 256) & ~7u));
+#else
+  unsigned long long* stamps = nullptr;
+#endif
+  SEG_STAMP(3);
   const uint32_t k = min(a.k, nf);  // :555
+  const bool packed = *ws.packed() != 0;
 
   // ---- one k-means attempt on (mv.x, x_px, y_px) (:557-578) --------------------------------
-  const uint64_t aseed = seed ^ ((uint64_t)att << 32);
+  const uint64_t aseed = (a.seed + frame) ^ ((uint64_t)att << 32);
   uint64_t compact;
-  SEG_STAMP(3);
   if (packed && nf <= kRegPts * te) {
-    compact = kmeans_regs(lst, lab, L, a, nf, k, aseed, tid, te, stamps);
+    compact = kmeans_regs<kRegPts>(ws.pk(), lab, L, a, nf, k, aseed, tid, te, stamps);
   } else if (packed) {
-    uint32_t* dmin = (lst == lst_lds && 8 * (size_t)nf <= lds_cap) ? lst_lds + nf : ws.dmin(att);
-    compact = kmeans_packed(lst, dmin, lab, L, a, nf, k, aseed, tid, te);
+    const size_t lds_cap = T == kTA ? a.lds_bytes : 8 * kLightMax;
+    uint32_t* pk = ws.pk();
+    uint32_t* dmin = ws.dmin(att);
+    if (4 * (size_t)nf <= lds_cap) {
+      uint32_t* pk_lds = reinterpret_cast<uint32_t*>(dyn_lds);
+      for (uint32_t i = tid; i < nf; i += te) pk_lds[i] = pk[i];
+      pk = pk_lds;
+      if (8 * (size_t)nf <= lds_cap) dmin = pk_lds + nf;
+      __syncthreads();
+    }
+    compact = kmeans_packed(pk, dmin, lab, L, a, nf, k, aseed, tid, te);
   } else {
-    compact = kmeans_generic(pts, lab, L, a, nf, k, aseed, tid, te);
+    compact = kmeans_generic(ws.pts(), lab, L, a, nf, k, aseed, tid, te);
   }
   if (tid == 0) ws.compact()[att] = compact;
   SEG_STAMP(31);
@@ -1054,7 +1112,14 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   if (a.bits_bytes + 4096 > kLdsBig)
     return fail(SVC_ERR_UNSUPPORTED, "segment: motion field of %u x %u blocks is too large", mfw, mfh);
   a.lds_bytes = (uint32_t)(a.bits_bytes + 4 * n4 <= kLdsBig ? a.bits_bytes + 4 * n4 : kLdsBig);
-  hipLaunchKernelGGL(segment_attempt_kernel, grid_a, dim3(kTA), a.lds_bytes, stream, a);
+  hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);
+  a.lds_bytes = 0;
+  hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), a.n > kRegPts * 256 ? 8 * kLightMax : 0, stream, a);
+  if (a.n > kLightMax) {
+    // more than kRegPts points per lane are possible: LDS for the large-frame path
+    if (a.n > kRegPts * kTA) a.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
+    hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), a.lds_bytes, stream, a);
+  }
   if (5 * n4 <= kLdsBig)
     hipLaunchKernelGGL((segment_label_kernel<true, true>), dim3(n_frames), dim3(kTA), 5 * n4, stream, a);
   else if (4 * n4 <= kLdsBig)
