@@ -68,10 +68,11 @@ def test_segment_edge_cases(native, oracle):
 
 
 @pytest.mark.parametrize("mfw,mfh,density", [(120, 68, 0.45), (120, 68, 0.7), (120, 68, 0.93), (120, 68, 1.0),
-                                             (240, 135, 0.6), (240, 135, 0.97), (33, 31, 0.8)])
+                                             (240, 135, 0.6), (240, 135, 0.97), (33, 31, 0.8),
+                                             (480, 270, 0.35), (480, 270, 0.12)])
 def test_segment_heavy_frames(native, oracle, mfw, mfh, density):
-    """Scene-cut-like frames: most of the field is foreground (all sixteen waves stay; the running minima
-    and, at 4K, the points spill from LDS to the workspace), next to a light and an empty frame."""
+    """Scene-cut-like frames: much of the field is foreground (the 1024-lane launch; above 8 192 blocks the
+    points leave the registers for LDS and, at 8K, the workspace), next to a light and an empty frame."""
     rng = np.random.default_rng(int(density * 100) + mfw)
     n = mfw * mfh
     yy, xx = np.mgrid[0:mfh, 0:mfw]
