@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 
   const uint32_t tid = threadIdx.x;
   const uint32_t sc_local = tid / N, j = tid % N;
-  const uint32_t gsc = blockIdx.x * kSegPerWg + sc_local;
+  // a workgroup's place in the clip follows the XCD it runs on: the 2 KiB row pieces that neighbouring
+  // workgroups write land in the same L2 and leave it as longer runs (stores alone: 1.33 -> 1.25 ms)
+  const uint32_t gsc = xcd_contiguous_block(blockIdx.x, gridDim.x) * kSegPerWg + sc_local;
   if (gsc >= a.total_segcols) return;  // whole N-lane groups leave together
   const uint32_t band_g = gsc / a.segs_per_band, seg = gsc - band_g * a.segs_per_band;
   const uint32_t frame = band_g / a.bands_per_frame, band = band_g - frame * a.bands_per_frame;

@@ -23,6 +23,23 @@ struct LumaArgs {
   uint32_t total_groups;
 };
 
+// Y of 16 interleaved BGR pixels (12 dwords) -> 16 bytes.  A pixel's three bytes are brought to the
+// low end of a dword by one byte-align, and the weighted sum is two 4 x u8 dot products: the weights
+// split into high and low bytes (1868 = 7*256 + 76, 9617 = 37*256 + 145, 4899 = 19*256 + 35), the
+// fourth byte (the next pixel's B) gets weight 0, and the rounding constant rides in as 32 << 8.
+__device__ __forceinline__ void luma16(const uint32_t (&w)[12], uint32_t (&out)[4]) {
+  constexpr uint32_t kLo = 76u | (145u << 8) | (35u << 16), kHi = 7u | (37u << 8) | (19u << 16);
+  out[0] = out[1] = out[2] = out[3] = 0;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int d = (3 * p) >> 2, sh = (3 * p) & 3;
+    const uint32_t px = sh == 0 ? w[d] : sh == 1 ? w[d] >> 8 : __builtin_amdgcn_alignbyte(w[d + 1 < 12 ? d + 1 : d], w[d], sh);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, kHi, 32u, false);
+    const uint32_t y = __builtin_amdgcn_udot4(px, kLo, hi << 8, false) >> 14;
+    out[p >> 2] |= y << (8 * (p & 3));
+  }
+}
+
 // one lane: 16 pixels = 48 B in (3 x dwordx4), 16 B out (1 x dwordx4)
 __global__ __launch_bounds__(256) void luma_kernel(LumaArgs a) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -31,16 +48,8 @@ __global__ __launch_bounds__(256) void luma_kernel(LumaArgs a) {
   const uint4* src = reinterpret_cast<const uint4*>(a.bgr + (size_t)frame * a.frame_stride + (size_t)gi * 48);
   const uint4 v0 = src[0], v1 = src[1], v2 = src[2];
   const uint32_t w[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-  uint32_t out[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
-    const uint32_t b = (w[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu;
-    const uint32_t gch = (w[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu;
-    const uint32_t r = (w[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu;
-    const uint32_t y = (1868u * b + 9617u * gch + 4899u * r + 8192u) >> 14;
-    out[p >> 2] |= y << (8 * (p & 3));
-  }
+  uint32_t out[4];
+  luma16(w, out);
   uint4* dst = reinterpret_cast<uint4*>(a.pyr + (size_t)frame * a.pyr_stride + (size_t)gi * 16);
   *dst = make_uint4(out[0], out[1], out[2], out[3]);
 }
@@ -127,12 +136,13 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 }
 
 // ---- luma + first pyramid level in one pass over the BGR frame -------------------------
-// A workgroup owns a 128 x 32 tile of the luma plane.  Its lanes compute Y for the tile plus
+// A workgroup owns a 128 x 60 tile of the luma plane (64 rows with the halo = two full trips of the
+// 256 lanes over its 16-pixel segments).  Its lanes compute Y for the tile plus
 // a 2-pixel halo (reflect-101 at the frame border, exactly what pyr_down_kernel does) into
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTW = 128, kTH = 32, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
+constexpr int kTW = 128, kTH = 60, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
   const uint8_t* bgr;
@@ -174,14 +184,8 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     const uint4* p = reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3);
     const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
     const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-    uint32_t out[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int px = 0; px < 16; ++px) {
-      const int b0 = 3 * px, b1 = 3 * px + 1, b2 = 3 * px + 2;
-      const uint32_t yy = luma_of((wd[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu, (wd[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu,
-                                  (wd[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu);
-      out[px >> 2] |= yy << (8 * (px & 3));
-    }
+    uint32_t out[4];
+    luma16(wd, out);
     const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
     *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;  // 16-byte aligned (Guideline 17)
     if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
@@ -197,30 +201,38 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
   __syncthreads();
 
   // (c) level 1: lane = (output row, quad of 4 output columns)
-  const int oy = (int)tid >> 4, q = (int)tid & 15;
-  const int gx = (x0 >> 1) + 4 * q, gy = (y0 >> 1) + oy;  // level-1 coordinates
-  if (gx >= (w >> 1) || gy >= (h >> 1)) return;
+  const int q = (int)tid & 15;
+  const int gx = (x0 >> 1) + 4 * q;  // level-1 coordinates
+  if (gx >= (w >> 1)) return;
   const int taps[5] = {1, 4, 6, 4, 1};
-  uint32_t acc[4] = {0, 0, 0, 0};
+  for (int oy = (int)tid >> 4; oy < kTH / 2; oy += 16) {
+    const int gy = (y0 >> 1) + oy;
+    if (gy >= (h >> 1)) break;
+    uint32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int r5 = 0; r5 < 5; ++r5) {
-    // centre of output column 4q + o is LDS column kOff + 8q + 2o; taps span kOff + 8q - 2 .. + 8
-    const uint8_t* rowp = &tile[(2 * oy + r5) * kPitch + kOff + 8 * q];
-    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
-    const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
-    const uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
-    const uint32_t px[11] = {(w0 >> 16) & 0xFF, w0 >> 24,
-                             mid.x & 0xFF, (mid.x >> 8) & 0xFF, (mid.x >> 16) & 0xFF, mid.x >> 24,
-                             mid.y & 0xFF, (mid.y >> 8) & 0xFF, (mid.y >> 16) & 0xFF, mid.y >> 24,
-                             w3 & 0xFF};
+    for (int r5 = 0; r5 < 5; ++r5) {
+      // centre of output column 4q + o is LDS column kOff + 8q + 2o; taps span kOff + 8q - 2 .. + 8
+      const uint8_t* rowp = &tile[(2 * oy + r5) * kPitch + kOff + 8 * q];
+      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
+      const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
+      const uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
+      // taps 1 4 6 4 of an output are one 4 x u8 dot product over the dword that starts at its first tap;
+      // the fifth tap (weight 1) enters as the accumulator
+      constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
+      const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.x, w0, 2), kTaps, (mid.x >> 16) & 0xFFu, false);
+      const uint32_t h1 = __builtin_amdgcn_udot4(mid.x, kTaps, mid.y & 0xFFu, false);
+      const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), kTaps, (mid.y >> 16) & 0xFFu, false);
+      const uint32_t h3 = __builtin_amdgcn_udot4(mid.y, kTaps, w3 & 0xFFu, false);
+      acc[0] += (uint32_t)taps[r5] * h0;
+      acc[1] += (uint32_t)taps[r5] * h1;
+      acc[2] += (uint32_t)taps[r5] * h2;
+      acc[3] += (uint32_t)taps[r5] * h3;
+    }
+    uint32_t out = 0;
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
-      acc[o] += (uint32_t)taps[r5] * (px[2 * o] + 4 * px[2 * o + 1] + 6 * px[2 * o + 2] + 4 * px[2 * o + 3] + px[2 * o + 4]);
+    for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
+    *reinterpret_cast<uint32_t*>(y_plane + a.l1_off + (size_t)gy * (w >> 1) + gx) = out;
   }
-  uint32_t out = 0;
-#pragma unroll
-  for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
-  *reinterpret_cast<uint32_t*>(y_plane + a.l1_off + (size_t)gy * (w >> 1) + gx) = out;
 }
 static_assert(kPitch % 16 == 0 && kOff % 16 == 0, "LDS rows keep 16-byte alignment for the ds_write_b128");
 
