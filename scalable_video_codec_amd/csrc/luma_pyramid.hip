@@ -136,13 +136,13 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 }
 
 // ---- luma + first pyramid level in one pass over the BGR frame -------------------------
-// A workgroup owns a 128 x 60 tile of the luma plane (64 rows with the halo = two full trips of the
+// A workgroup owns a 256 x 60 tile of the luma plane (64 rows with the halo = four full trips of the
 // 256 lanes over its 16-pixel segments).  Its lanes compute Y for the tile plus
 // a 2-pixel halo (reflect-101 at the frame border, exactly what pyr_down_kernel does) into
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTW = 128, kTH = 60, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
+constexpr int kTW = 256, kTH = 60, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
   const uint8_t* bgr;
@@ -201,11 +201,12 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
   __syncthreads();
 
   // (c) level 1: lane = (output row, quad of 4 output columns)
-  const int q = (int)tid & 15;
+  constexpr int kQuads = kTW / 8;  // quads of level-1 columns per tile row
+  const int q = (int)tid % kQuads;
   const int gx = (x0 >> 1) + 4 * q;  // level-1 coordinates
   if (gx >= (w >> 1)) return;
   const int taps[5] = {1, 4, 6, 4, 1};
-  for (int oy = (int)tid >> 4; oy < kTH / 2; oy += 16) {
+  for (int oy = (int)tid / kQuads; oy < kTH / 2; oy += 256 / kQuads) {
     const int gy = (y0 >> 1) + oy;
     if (gy >= (h >> 1)) break;
     uint32_t acc[4] = {0, 0, 0, 0};

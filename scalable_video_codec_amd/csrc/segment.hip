@@ -55,15 +55,6 @@ __device__ __forceinline__ uint64_t seg_hash(uint64_t x) {  // splitmix64 finali
 
 struct Pt { int f[3]; };
 
-__device__ __forceinline__ Pt make_pt(const float2* mv, uint32_t b, uint32_t mfw, uint32_t bw, uint32_t bh) {
-  Pt p;
-  const float mx = mv[b].x;
-  p.f[0] = (int)(mx < 0 ? mx - 0.5f : mx + 0.5f);
-  p.f[1] = (int)((b % mfw) * bw);
-  p.f[2] = (int)((b / mfw) * bh);
-  return p;
-}
-
 __device__ __forceinline__ uint64_t dist2_int(const Pt& a, const int* c) {
   uint64_t s = 0;
 #pragma unroll
@@ -74,12 +65,12 @@ __device__ __forceinline__ uint64_t dist2_int(const Pt& a, const int* c) {
   return s;
 }
 
-// Same value with 32-bit arithmetic: valid when every coordinate difference is < 2^15 in
-// magnitude and |mv.x| differences < 2^15 too (three squares < 2^30 each... the host checks the
-// frame size, the kernel checks mv.x), which covers every real frame.
+// Same value with 32-bit arithmetic, for packed points: every coordinate difference is below 2^15
+// in magnitude (x_px, y_px < 2^14 checked on the host, |mv.x| < 2^13 by the kernel that packs), so
+// the squares are full-rate 24-bit multiplies and their sum stays below 2^32.
 __device__ __forceinline__ uint32_t dist2_u32(const Pt& a, const int* c) {
   const int dx = a.f[0] - c[0], dy = a.f[1] - c[1], dz = a.f[2] - c[2];
-  return (uint32_t)(dx * dx) + (uint32_t)(dy * dy) + (uint32_t)(dz * dz);
+  return (uint32_t)__mul24(dx, dx) + (uint32_t)__mul24(dy, dy) + (uint32_t)__mul24(dz, dz);
 }
 
 __device__ __forceinline__ double dist2_dbl(const Pt& p, const double* c) {
