@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kTA) void segment_prepare_kernel(SegArgs a) {
 // (cv::kmeans' `attempts`), so they run side by side instead of one after the other.  Launched twice:
 // T = 256 lanes takes the frames of at most kLightMax foreground blocks (nearly all of them: four
 // waves per workgroup, several workgroups per CU, and the hundreds of short barrier-separated phases
-// of a light frame stay cheap; one wave when at most 64), T = 1024 the heavy ones (a scene cut: most of the field is
+// of a light frame stay cheap; a single wave up to 256 blocks), T = 1024 the heavy ones (a scene cut: most of the field is
 // foreground); a workgroup whose frame belongs to the other launch ends at once.
 // Dynamic LDS (fields that can have more than kRegPts points per lane only): the packed points and,
 // if they fit too, the running minima of the path that does not keep them in registers.
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const uint32_t nf = *ws.nf();
   if (nf == 0 || (nf > kLightMax) != (T == kTA)) return;
-  const uint32_t te = T == kTA ? kTA : nf <= 64 ? 64u : 256u;
+  const uint32_t te = T == kTA ? kTA : nf <= 256 ? 64u : 256u;  // one wave: no barrier ever waits
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
   uint8_t* lab = ws.lab(att);
 #ifdef SVC_SEG_TIMING
