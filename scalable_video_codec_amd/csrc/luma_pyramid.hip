@@ -136,13 +136,14 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 }
 
 // ---- luma + first pyramid level in one pass over the BGR frame -------------------------
-// A workgroup owns a 256 x 60 tile of the luma plane (64 rows with the halo = four full trips of the
-// 256 lanes over its 16-pixel segments).  Its lanes compute Y for the tile plus
+// A workgroup owns a 128 x 32 tile of the luma plane.  (Taller / wider tiles -- 128 x 60, 256 x 60 --
+// run no faster and push the tiles in flight per XCD past its L2, so the halo re-reads start to
+// miss: FETCH_SIZE 2.37 GB against 1.85 GB with this shape, which is the algorithmic figure.)  Its lanes compute Y for the tile plus
 // a 2-pixel halo (reflect-101 at the frame border, exactly what pyr_down_kernel does) into
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTW = 256, kTH = 60, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
+constexpr int kTW = 128, kTH = 32, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
   const uint8_t* bgr;
