@@ -56,26 +56,27 @@ __device__ __forceinline__ void serial_sum2(const float2* st, uint32_t n, float&
 }
 
 __device__ __forceinline__ void serial_sum1(const float* st, uint32_t n, float& acc) {
-  // One lane, strictly in index order.  The next 32 values are fetched from LDS while the
-  // current 32 are being added, so the chain runs at the dependent-add rate, not at LDS latency.
-  uint32_t i = 0;
-  if (n >= 32) {
-    float4 cur[8], nxt[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) cur[k] = *reinterpret_cast<const float4*>(st + 4 * k);
-    for (; i + 64 <= n; i += 32) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) nxt[k] = *reinterpret_cast<const float4*>(st + i + 32 + 4 * k);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { acc += cur[k].x; acc += cur[k].y; acc += cur[k].z; acc += cur[k].w; }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+  // One lane, strictly in index order.  Two register blocks of 32 values alternate: while one is
+  // being added the other is in flight from LDS, and no value is ever copied between registers, so
+  // the chain runs at the dependent-add issue rate (4 cycles per term) instead of at LDS latency.
+  const uint32_t nb = n / 32;
+  if (nb) {
+    float4 A[8], B[8];
+#define SVC_LOAD32(X, off) _Pragma("unroll") for (int k = 0; k < 8; ++k) X[k] = *reinterpret_cast<const float4*>(st + (off) + 4 * k)
+#define SVC_ADD32(X) _Pragma("unroll") for (int k = 0; k < 8; ++k) { acc += X[k].x; acc += X[k].y; acc += X[k].z; acc += X[k].w; }
+    SVC_LOAD32(A, 0);
+    uint32_t b = 0;
+    for (; b + 2 <= nb; b += 2) {
+      SVC_LOAD32(B, (b + 1) * 32);
+      SVC_ADD32(A);
+      if (b + 2 < nb) SVC_LOAD32(A, (b + 2) * 32);
+      SVC_ADD32(B);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { acc += cur[k].x; acc += cur[k].y; acc += cur[k].z; acc += cur[k].w; }
-    i += 32;
+    if (b < nb) SVC_ADD32(A);
+#undef SVC_LOAD32
+#undef SVC_ADD32
   }
-  for (; i < n; ++i) acc += st[i];
+  for (uint32_t i = nb * 32; i < n; ++i) acc += st[i];
 }
 
 constexpr uint32_t kModelsPerPass = 8;  // iteration models scored per pass over the field
@@ -245,6 +246,200 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
   }
 }
 
+// ---- the same, with the motion field in registers ---------------------------------------------
+// The kernel above walks the field in L2 half a dozen times and pays a block-wide reduction (two
+// barriers) per model.  For fields of up to 32 x T blocks every lane keeps ITS blocks (i = u * T + tid)
+// in registers for the whole kernel: the models of a pass are scored against registers, their
+// counts reduced inside the wave and summed across waves by one lane after ONE barrier, and the
+// mask / mean / RMSE passes never touch memory for the field again.  Out-of-range slots hold
+// +inf, which no model accepts.  Same arithmetic, same order: bit-identical results.
+constexpr uint32_t kPassModels = 16;
+
+template <uint32_t T, uint32_t PER>
+__global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
+  __shared__ __attribute__((aligned(16))) float2 s_stage[kChunk];
+  __shared__ float s_model[kPassModels][2];
+  __shared__ uint32_t s_cnt[2][T / 64][kPassModels];
+  __shared__ int s_isum[2];
+  __shared__ uint32_t s_flag, s_mag, s_bestn, s_bestit;
+  __shared__ float s_gm[2];
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * a.blocks;
+  const uint32_t* samples = a.samples + (size_t)frame * a.iters * a.subset;
+  uint8_t* mask = a.mask + (size_t)frame * a.blocks;
+  const float t2 = a.thresh * a.thresh;
+
+  float2 m[PER];
+#pragma unroll
+  for (uint32_t u = 0; u < PER; ++u) {
+    const uint32_t i = u * T + tid;
+    m[u] = i < a.blocks ? mv[i] : make_float2(__builtin_inff(), __builtin_inff());
+  }
+
+  // ---- iterations (motion.cpp:210-238), kPassModels at a time ---------------------------------
+  uint32_t best_n = 0, best_it = 0;  // tracked by thread 0, published below
+  float bgx = 0.f, bgy = 0.f;
+  uint32_t par = 0;
+  for (uint32_t it0 = 0; it0 < a.iters; it0 += kPassModels, par ^= 1u) {
+    const uint32_t nm = min(kPassModels, a.iters - it0);
+    if (tid < nm) {
+      float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
+      for (uint32_t i = 0; i < a.subset; ++i) {
+        const float2 s = mv[samples[(size_t)(it0 + tid) * a.subset + i]];
+        sx = sx + s.x;
+        sy = sy + s.y;
+      }
+      const float inv = 1.0f / (float)a.subset;
+      s_model[tid][0] = sx * inv;
+      s_model[tid][1] = sy * inv;
+    }
+    __syncthreads();
+    float gx[kPassModels], gy[kPassModels];
+#pragma unroll
+    for (uint32_t k = 0; k < kPassModels; ++k) {
+      gx[k] = s_model[k < nm ? k : 0][0];
+      gy[k] = s_model[k < nm ? k : 0][1];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kPassModels; ++k) {
+      if (k >= nm) break;  // block-uniform
+      uint32_t c = 0;
+#pragma unroll
+      for (uint32_t u = 0; u < PER; ++u) c += is_inlier(gx[k], gy[k], m[u].x, m[u].y, t2) ? 1u : 0u;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+      if (lane == 0) s_cnt[par][wave][k] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (uint32_t k = 0; k < nm; ++k) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < T / 64; ++w) total += s_cnt[par][w][k];
+        if (total >= best_n) {  // motion.cpp:233, in iteration order: ties -> later
+          best_n = total;
+          best_it = it0 + k;
+          bgx = gx[k];
+          bgy = gy[k];
+        }
+      }
+    }
+    // s_model is rewritten by the next pass only after every lane has read it (the reads sit before
+    // the barrier above); s_cnt alternates between two copies
+  }
+  if (tid == 0) { s_bestn = best_n; s_bestit = best_it; s_gm[0] = bgx; s_gm[1] = bgy; s_flag = 1u; s_isum[0] = 0; s_isum[1] = 0; s_mag = 0; }
+  __syncthreads();
+  best_n = s_bestn; best_it = s_bestit; bgx = s_gm[0]; bgy = s_gm[1];
+  const bool any_iter = a.iters > 0;
+
+  if (best_n < a.subset) {
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+      const uint32_t i = u * T + tid;
+      if (i < a.blocks) mask[i] = (any_iter && is_inlier(bgx, bgy, m[u].x, m[u].y, t2)) ? 1 : 0;
+    }
+    // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
+    if (tid == 0) {
+      const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
+      float acc = 0.f;
+      for (uint32_t i = 0; i < a.subset; ++i) {
+        const float2 s = mv[samples[(size_t)best_it * a.subset + i]];
+        const float dx = s.x - ix, dy = s.y - iy;
+        acc += dx * dx + dy * dy;
+      }
+      a.gm[2 * frame] = bgx;
+      a.gm[2 * frame + 1] = bgy;
+      a.rmse[frame] = sqrtf(acc / (float)a.subset);
+      a.count[frame] = best_n;
+    }
+    return;
+  }
+
+  // ---- inlier mask (== best_inliers, motion.cpp:244-253) and the final model = mean of the
+  // inliers (motion.cpp:255-256); integer fast path as in ransac_kernel
+  uint64_t inl = 0;  // bit u: block u * T + tid is an inlier
+  {
+    bool ok = true;
+    int ix = 0, iy = 0;
+    uint32_t mag = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+      const uint32_t i = u * T + tid;
+      const bool in = is_inlier(bgx, bgy, m[u].x, m[u].y, t2);
+      if (i < a.blocks) mask[i] = in ? 1 : 0;
+      if (!in) continue;
+      inl |= 1ull << u;
+      ok = ok && m[u].x == truncf(m[u].x) && m[u].y == truncf(m[u].y) && fabsf(m[u].x) <= 32768.f && fabsf(m[u].y) <= 32768.f;
+      if (ok) {
+        ix += (int)m[u].x; iy += (int)m[u].y;
+        mag += (uint32_t)fabsf(m[u].x) + (uint32_t)fabsf(m[u].y);
+      }
+    }
+    if (!ok || mag >= (1u << 24)) s_flag = 0u;
+    mag &= 0xFFFFFFu;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      ix += __shfl_xor(ix, off, 64);
+      iy += __shfl_xor(iy, off, 64);
+      mag += __shfl_xor(mag, off, 64);
+    }
+    if (lane == 0) {
+      if (mag >= (1u << 24)) { s_flag = 0u; mag = 0; }  // a wave's 64 addends fit; T / 64 clamped ones cannot wrap s_mag
+      atomicAdd(&s_isum[0], ix);
+      atomicAdd(&s_isum[1], iy);
+      atomicAdd(&s_mag, mag);
+    }
+  }
+  __syncthreads();
+  const bool exact_int = s_flag != 0u && s_mag < (1u << 24);
+  float sx = 0.f, sy = 0.f;
+  if (exact_int) {
+    sx = (float)s_isum[0];
+    sy = (float)s_isum[1];
+  } else {
+    for (uint32_t base = 0; base < a.blocks; base += kChunk) {
+      const uint32_t n = min(kChunk, a.blocks - base);
+#pragma unroll
+      for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * T + tid;
+        if (i >= base && i < base + n) s_stage[i - base] = ((inl >> u) & 1ull) ? m[u] : make_float2(0.f, 0.f);
+      }
+      __syncthreads();
+      if (tid == 0) serial_sum2(s_stage, n, sx, sy);
+      __syncthreads();
+    }
+    if (tid == 0) { s_gm[0] = sx; s_gm[1] = sy; }
+    __syncthreads();
+    sx = s_gm[0];
+    sy = s_gm[1];
+  }
+  const float inv = 1.0f / (float)best_n;
+  const float out_gx = sx * inv, out_gy = sy * inv;
+
+  // ---- RMSE (motion.cpp:258-259, :165-180): terms in parallel, the sum in order -----
+  float acc = 0.f;
+  float* terms = reinterpret_cast<float*>(s_stage);
+  for (uint32_t base = 0; base < a.blocks; base += 2 * kChunk) {
+    const uint32_t n = min(2 * kChunk, a.blocks - base);
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+      const uint32_t i = u * T + tid;
+      if (i >= base && i < base + n) {
+        const float dx = m[u].x - out_gx, dy = m[u].y - out_gy;
+        terms[i - base] = ((inl >> u) & 1ull) ? dx * dx + dy * dy : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) serial_sum1(terms, n, acc);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.gm[2 * frame] = out_gx;
+    a.gm[2 * frame + 1] = out_gy;
+    a.rmse[frame] = sqrtf(acc / (float)best_n);
+    a.count[frame] = best_n;
+  }
+}
+
 // libs/encoder.cpp:507-513 + :549-551 (the in-repo part of the segmentation glue):
 // the foreground mask is the complement of the RANSAC inliers and every block starts
 // as BLOCK_TYPE_BACKGROUND (0, libs/codec.hpp:6).  Until the OpenCV-side clustering
@@ -278,7 +473,14 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ran
   a.rmse = d_rmse;
   a.mask = d_mask;
   a.count = d_count;
-  hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), 0, stream, a);
+  if (blocks <= 8 * 256)
+    hipLaunchKernelGGL((ransac_reg_kernel<256, 8>), dim3(n_frames), dim3(256), 0, stream, a);
+  else if (blocks <= 8 * 1024)
+    hipLaunchKernelGGL((ransac_reg_kernel<1024, 8>), dim3(n_frames), dim3(1024), 0, stream, a);
+  else if (blocks <= 32 * 1024)
+    hipLaunchKernelGGL((ransac_reg_kernel<1024, 32>), dim3(n_frames), dim3(1024), 0, stream, a);
+  else
+    hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), 0, stream, a);
   return check_launch("ransac_kernel");
 }
 
