@@ -71,68 +71,71 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i >= n ? 2 * (n - 1) - i : i;
 }
 
-// One lane: 4 destination pixels (one dword store) from a 5 x 11 source patch.
-// Two launches per level keep every wave convergent: BORDER = false covers the quads
-// whose patch lies inside the row (one unaligned dwordx4 per source row, all five in
-// flight together); BORDER = true covers the first and last quad of each row with
-// reflected byte loads (2 quads per row: noise).
-template <bool BORDER>
+// One lane: 4 destination pixels of TWO consecutive rows (two dword stores) from a 7 x 11 source
+// patch -- the rows share 3 of their 5 source rows, so 7 unaligned dwordx4 loads, all in flight
+// together, feed 8 outputs.  Taps 1 4 6 4 of an output are one 4 x u8 dot product over the dword that
+// starts at its first tap, the fifth tap rides in as the accumulator.  The first and last quad of a row
+// reflect (BORDER_REFLECT_101) and gather their bytes one by one -- 2 lanes in 120 at the level this
+// runs on, in the same launch.
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
-  // consecutive output rows share 3 of their 5 source rows: keep them on one XCD's L2
+  // consecutive output rows share source rows: keep them on one XCD's L2
   const uint32_t q = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (q >= a.total) return;
-  const uint32_t lanes_per_row = BORDER ? 2u : a.quads_per_row - 2u;
-  const uint32_t per_frame = a.dh * lanes_per_row;
+  const uint32_t pairs = (a.dh + 1) / 2, per_frame = pairs * a.quads_per_row;
   const uint32_t frame = q / per_frame, rem = q - frame * per_frame;
-  const uint32_t dy = rem / lanes_per_row, k = rem - dy * lanes_per_row;
-  const uint32_t dq = BORDER ? (k == 0 ? 0u : a.quads_per_row - 1u) : k + 1u;
+  const uint32_t dp = rem / a.quads_per_row, dq = rem - dp * a.quads_per_row;
+  const uint32_t dy = 2 * dp;
   const uint8_t* src = a.pyr + (size_t)frame * a.pyr_stride + a.src_off;
   const int sx0 = (int)dq * 8;  // source column of the first output's centre
-  constexpr bool interior = !BORDER;
+  const bool border = dq == 0 || dq + 1 == a.quads_per_row;
 
-  uint32_t acc[4] = {0, 0, 0, 0};
-  const int taps[5] = {1, 4, 6, 4, 1};
-  const uint8_t* rows[5];
+  uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+  const uint32_t taps[5] = {1, 4, 6, 4, 1};
+  const uint8_t* rows[7];
 #pragma unroll
-  for (int r = 0; r < 5; ++r)
-    rows[r] = src + (size_t)reflect101((int)dy * 2 + r - 2, (int)a.sh) * a.sw;
+  for (int r = 0; r < 7; ++r)  // rows past the plane only feed the (discarded) second output of an odd last pair
+    rows[r] = src + (size_t)reflect101(min((int)dy * 2 + r - 2, 2 * (int)a.sh - 2), (int)a.sh) * a.sw;
+  constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
 
-  auto accumulate = [&](int r, const uint32_t (&px)[11]) {
+  uint32_t h[7][4];
+  if (!border) {
+    u32x4_a4 w[7];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const uint32_t hsum = px[2 * o] + 4 * px[2 * o + 1] + 6 * px[2 * o + 2] + 4 * px[2 * o + 3] + px[2 * o + 4];
-      acc[o] += (uint32_t)taps[r] * hsum;
-    }
-  };
-
-  if (interior) {
-    // all five row loads are issued before the first use: one memory round trip, not five
-    u32x4_a4 w[5];
+    for (int r = 0; r < 7; ++r) w[r] = *reinterpret_cast<const u32x4_a4*>(rows[r] + sx0 - 4);
 #pragma unroll
-    for (int r = 0; r < 5; ++r) w[r] = *reinterpret_cast<const u32x4_a4*>(rows[r] + sx0 - 4);
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const uint32_t w0 = w[r].x, w1 = w[r].y, w2 = w[r].z, w3 = w[r].w;
-      const uint32_t px[11] = {(w0 >> 16) & 0xFF, w0 >> 24,
-                               w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 0xFF, w1 >> 24,
-                               w2 & 0xFF, (w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24,
-                               w3 & 0xFF};  // source columns sx0 - 2 .. sx0 + 8
-      accumulate(r, px);
+    for (int r = 0; r < 7; ++r) {
+      const uint32_t w0 = w[r].x, w1 = w[r].y, w2 = w[r].z, w3 = w[r].w;  // source columns sx0 - 4 .. sx0 + 11
+      h[r][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), kTaps, (w1 >> 16) & 0xFFu, false);
+      h[r][1] = __builtin_amdgcn_udot4(w1, kTaps, w2 & 0xFFu, false);
+      h[r][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), kTaps, (w2 >> 16) & 0xFFu, false);
+      h[r][3] = __builtin_amdgcn_udot4(w2, kTaps, w3 & 0xFFu, false);
     }
   } else {
-    uint32_t pb[5][11];
 #pragma unroll
-    for (int r = 0; r < 5; ++r)
+    for (int r = 0; r < 7; ++r) {
+      uint32_t px[11];
 #pragma unroll
-      for (int i = 0; i < 11; ++i) pb[r][i] = rows[r][reflect101(sx0 - 2 + i, (int)a.sw)];
+      for (int i = 0; i < 11; ++i) px[i] = rows[r][reflect101(sx0 - 2 + i, (int)a.sw)];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) accumulate(r, pb[r]);
+      for (int o = 0; o < 4; ++o) h[r][o] = px[2 * o] + 4 * px[2 * o + 1] + 6 * px[2 * o + 2] + 4 * px[2 * o + 3] + px[2 * o + 4];
+    }
   }
-  uint32_t out = 0;
 #pragma unroll
-  for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (r < 5) acc0[o] += taps[r] * h[r][o];
+      if (r >= 2) acc1[o] += taps[r - 2] * h[r][o];
+    }
+  uint32_t out0 = 0, out1 = 0;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    out0 |= ((acc0[o] + 128u) >> 8) << (8 * o);
+    out1 |= ((acc1[o] + 128u) >> 8) << (8 * o);
+  }
   uint8_t* dst = a.pyr + (size_t)frame * a.pyr_stride + a.dst_off;
-  *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dw + dq * 4) = out;
+  *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dw + dq * 4) = out0;
+  if (dy + 1 < a.dh) *reinterpret_cast<uint32_t*>(dst + (size_t)(dy + 1) * a.dw + dq * 4) = out1;
 }
 
 // ---- luma + first pyramid level in one pass over the BGR frame -------------------------
@@ -292,12 +295,10 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     pa.quads_per_row = pa.dw / 4;
     if (l < first_plain_level) continue;  // produced by luma_pyr1_kernel
     if (pa.quads_per_row < 2) return fail(SVC_ERR_UNSUPPORTED, "pyramid: level %u is narrower than 16 pixels", l);
-    const uint64_t tot = (uint64_t)n_frames * pa.dh * (pa.quads_per_row - 2);
+    const uint64_t tot = (uint64_t)n_frames * ((pa.dh + 1) / 2) * pa.quads_per_row;
     if (tot > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many pixels for one launch");
     pa.total = (uint32_t)tot;
-    if (pa.total) hipLaunchKernelGGL(pyr_down_kernel<false>, dim3(div_up(pa.total, 256)), dim3(256), 0, stream, pa);
-    pa.total = n_frames * pa.dh * 2;
-    hipLaunchKernelGGL(pyr_down_kernel<true>, dim3(div_up(pa.total, 256)), dim3(256), 0, stream, pa);
+    hipLaunchKernelGGL(pyr_down_kernel, dim3(div_up(pa.total, 256)), dim3(256), 0, stream, pa);
     rc = check_launch("pyr_down_kernel");
     if (rc) return rc;
   }
