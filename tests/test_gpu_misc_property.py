@@ -67,6 +67,36 @@ def test_segment_random_fields(native, oracle, mfw, mfh, density, seed, conn, k,
     assert np.array_equal(got.astype(np.uint32), want), (mfw, mfh, density, conn, k, attempts)
 
 
+@settings(max_examples=60, **_S)
+@given(mfw=st.integers(50, 140), mfh=st.integers(30, 75), density=st.floats(0.05, 1.0), blobs=st.integers(0, 4),
+       seed=st.integers(0, 2 ** 31 - 1), conn=st.sampled_from([4, 8]), k=st.integers(2, 14), attempts=st.integers(1, 3),
+       mw=st.integers(1, 5), mh=st.integers(1, 5), iters=st.integers(1, 12))
+def test_segment_random_large_fields(native, oracle, mfw, mfh, density, blobs, seed, conn, k, attempts, mw, mh, iters):
+    """1080p-sized fields with anything from a sprinkle to a scene cut's worth of foreground: the 64-, 256- and
+    1024-lane k-means paths, arbitrary morphology rectangles, two frames per call (heavy next to light)."""
+    rng = np.random.default_rng(seed)
+    n = mfw * mfh
+    yy, xx = np.mgrid[0:mfh, 0:mfw]
+    masks, mvs = [], []
+    for f in range(2):
+        fg = rng.random((mfh, mfw)) < (density if f == 0 else 0.03)
+        for _ in range(blobs):
+            h, w = rng.integers(2, mfh // 2), rng.integers(2, mfw // 2)
+            y, x = rng.integers(0, mfh - h), rng.integers(0, mfw - w)
+            fg[y:y + h, x:x + w] = True
+        mv = np.stack([np.round(5 * np.sin(xx / 11.0 + seed % 7) + 3 * (yy > mfh // 2) + rng.integers(-1, 2, (mfh, mfw))),
+                       rng.integers(-9, 10, (mfh, mfw))], -1).astype(np.float32).reshape(n, 2)
+        masks.append((~fg).astype(np.uint8).reshape(-1)); mvs.append(mv)
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh, seed=seed & 0xFFFF,
+                                connectivity=conn, cluster_count=k, attempt_count=attempts, morph_rect_w=mw, morph_rect_h=mh,
+                                max_iter_count=iters).cpu().numpy()
+    for f in range(2):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, connectivity=conn, cluster_count=k, attempts=attempts,
+                              morph_w=mw, morph_h=mh, max_iter=iters, seed=(seed & 0xFFFF) + f)
+        assert np.array_equal(got[f].astype(np.uint32), want), (f, mfw, mfh, density, blobs, conn, k, attempts, mw, mh, iters)
+
+
 @settings(max_examples=25, **_S)
 @given(kx=st.integers(1, 6), ky=st.integers(1, 5), block=st.sampled_from([8, 16]), cut=st.integers(0, 1),
        seed=st.integers(0, 2 ** 31 - 1), quant=st.booleans())
