@@ -1,0 +1,79 @@
+// stream_encoder.hpp -- the hot path for a clip that lives in HOST memory, batched and overlapped
+// with PCIe: the C++ entry point a host application uses instead of calling the reference's
+// one-frame-per-call functions (include/svc/motion.hpp) in a loop.
+//
+// What it runs per encoded frame is the middle of Encoder::operator() (reference
+// libs/encoder.cpp:449-650): pad, luma + pyramid, EstimateMotionHierarchical,
+// EstimateGlobalMotionRansac, the segmentation glue -> region ids, Dct (+ the decoder's quant
+// lines), optionally SerializeEncodedFrame -- every stage through the C ABI of include/svc_hip.h.
+// Frames go pinned -> device on a copy stream while the previous batch is in the kernels and the
+// one before is on its way back; the one-frame overlap between batches is copied on the device.
+//
+// RANSAC's draws (the reference seeds std::random_device, libs/motion.cpp:186-187) and the k-means
+// seeds are a deterministic function of `seed` and the frame index, so a clip encodes to the same
+// result whatever the batch size.
+#ifndef SVC_STREAM_ENCODER_HPP
+#define SVC_STREAM_ENCODER_HPP
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+
+#include "svc_hip.h"
+
+namespace svc {
+
+struct StreamEncoderConfig {
+  uint32_t width = 0, height = 0;  // source frame size; padded as libs/encoder.cpp:164-168 does
+  uint32_t levels = 3;             // pyr-lvl-count
+  uint32_t mv_block = 16;          // apps/encoder.cpp:28-58 defaults from here on
+  uint32_t search_range = 8;
+  uint32_t dct_block = 8;          // transform block, 8 or 16
+  uint32_t fg_step = 1, bg_step = 640;  // apps/decoder.cpp:22-23
+  bool wire = false;               // serialised records (libs/encoder.cpp:222-269) instead of planes
+  uint32_t batch = 16;             // encoded frames per batch
+  uint32_t depth = 3;              // batches in flight
+  uint64_t seed = 0;
+  svc_ransac_params ransac{1, 7.5f, 0.99f, 0.5f};
+  svc_segment_params segment{3, 3, 10, 3, 10, 1.0f, 4};
+};
+
+// One finished batch; the pointers are pinned host memory owned by the encoder and stay valid
+// until depth - 1 more batches have been delivered.
+struct EncodedBatch {
+  uint32_t first_frame = 0;  // clip index of the batch's first encoded frame (frame 0 is tracked-only)
+  uint32_t count = 0;
+  uint32_t padded_w = 0, padded_h = 0, mv_field_w = 0, mv_field_h = 0;
+  const float* mv_xy = nullptr;          // [count][blocks][2]
+  const float* global_motion = nullptr;  // [count][2]
+  const uint32_t* block_types = nullptr; // [count][blocks], 0 = background
+  const float* coeffs = nullptr;         // [count][3][padded_h][padded_w], planes B,G,R (wire == false)
+  const uint8_t* records = nullptr;      // [count][record_bytes] (wire == true)
+  uint64_t record_bytes = 0;
+};
+
+class StreamEncoder {
+ public:
+  using Sink = std::function<void(const EncodedBatch&)>;
+
+  // Allocates every buffer; throws std::runtime_error with the C ABI's message on failure.
+  explicit StreamEncoder(const StreamEncoderConfig& config);
+  ~StreamEncoder();
+  StreamEncoder(const StreamEncoder&) = delete;
+  StreamEncoder& operator=(const StreamEncoder&) = delete;
+
+  // Encodes a clip of n_frames >= 2 unpadded B,G,R u8 frames (height x width x 3, tightly packed,
+  // anywhere in host memory); sink is called once per batch, in clip order, from this thread.
+  void Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& sink);
+
+  uint32_t padded_width() const;
+  uint32_t padded_height() const;
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> p_;
+};
+
+}  // namespace svc
+
+#endif  // SVC_STREAM_ENCODER_HPP

@@ -73,13 +73,23 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB_HIP
 
 
+STREAM_SRC = os.path.join(CSRC, "host", "stream_encoder.cpp")
+
+
 def build_motion(force: bool = False) -> str:
+    """The C++ layer above the C ABI: the reference's motion.hpp entry points (plain C++, g++) and the
+    batched host-memory encoder (uses the HIP runtime for buffers, streams and events: hipcc, host only)."""
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(INCLUDE, "svc", h) for h in ("motion.hpp", "math.hpp", "types.hpp")]
+    deps = srcs + [STREAM_SRC, os.path.join(INCLUDE, "svc_hip.h")] + \
+        [os.path.join(INCLUDE, "svc", h) for h in ("motion.hpp", "math.hpp", "types.hpp", "stream_encoder.hpp")]
     if force or not _newer(LIB_MOTION, deps + [LIB_HIP]):
         cxx = shutil.which("g++") or "g++"
+        stream_obj = os.path.join(OBJ, "stream_encoder.o")
+        _run([_hipcc(), "-std=c++17", "-O2", "-fPIC", "-Wall", f"-I{INCLUDE}", "-c", STREAM_SRC, "-o", stream_obj])
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
         _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", f"-I{INCLUDE}", f"-I{os.path.join(INCLUDE, 'svc')}",
-              "-o", LIB_MOTION, *srcs, f"-L{PKG}", "-lsvc_hip", "-Wl,-rpath,$ORIGIN"])
+              "-o", LIB_MOTION, *srcs, stream_obj, f"-L{PKG}", "-lsvc_hip", f"-L{rocm_lib}", "-lamdhip64",
+              "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{rocm_lib}"])
     return LIB_MOTION
 
 
@@ -103,6 +113,13 @@ def build_dropin(force: bool = False) -> List[str]:
             _run([cxx, "-std=c++17", "-O2", "-msse2", f"-I{inc}", *extra, "-o", exe, DROPIN_SRC, f"-L{PKG}",
                   "-lsvc_motion", "-lsvc_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd"])
         out.append(exe)
+    # a host application written against include/svc/stream_encoder.hpp only
+    exe = os.path.join(os.path.dirname(DROPIN_SRC), "stream_main")
+    src = os.path.join(os.path.dirname(DROPIN_SRC), "stream_main.cpp")
+    if force or not _newer(exe, [src, LIB_MOTION, os.path.join(INCLUDE, "svc", "stream_encoder.hpp")]):
+        _run([cxx, "-std=c++17", "-O2", f"-I{INCLUDE}", "-o", exe, src, f"-L{PKG}", "-lsvc_motion", "-lsvc_hip",
+              f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd", "-Wl,--allow-shlib-undefined"])
+    out.append(exe)
     return out
 
 

@@ -36,3 +36,38 @@ def test_stream_equals_resident(native, batch, wire):
             assert np.array_equal(out["coeffs"], ref.coeffs[a:a + c].cpu().numpy())
         seen += c
     assert seen == n - 1
+
+
+@pytest.mark.parametrize("batch,wire", [(6, False), (16, True)])
+def test_cpp_stream_encoder_equals_resident(native, tmp_path, batch, wire):
+    """The C++ host application (tests/dropin/stream_main.cpp against include/svc/stream_encoder.hpp) on a raw clip
+    file: every output equals the resident path's."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "dropin", "stream_main")
+    if not os.path.exists(exe):
+        pytest.fail("tests/dropin/stream_main is not built (python -m scalable_video_codec_amd.build)")
+    cfg = configs.ALL["C2-720p-3L-dct8"]
+    n = 21
+    dev = torch.device("cuda")
+    clip = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
+    frames = [clip.frame_bgr(t) for t in range(n)]
+    pw, ph = cfg.padded
+    ref = pipeline.ClipEncoder(cfg, n, dev, wire=wire)
+    ref.load_frames([synth.pad_frame(f, pw, ph) for f in frames])
+    ref.step()
+    torch.cuda.synchronize()
+    raw = tmp_path / "clip.raw"
+    torch.stack(frames).cpu().numpy().tofile(raw)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, str(raw), str(cfg.width), str(cfg.height), str(n), str(cfg.levels), str(cfg.dct_block),
+                        "1" if wire else "0", str(batch), str(cfg.seed), prefix], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    p = n - 1
+    assert np.array_equal(np.fromfile(prefix + ".mv", np.float32).reshape(p, cfg.blocks, 2), ref.mv.cpu().numpy())
+    assert np.array_equal(np.fromfile(prefix + ".types", np.int32).reshape(p, cfg.blocks), ref.types.cpu().numpy())
+    assert np.array_equal(np.fromfile(prefix + ".gm", np.float32).reshape(p, 2), ref.gm.cpu().numpy())
+    if wire:
+        assert np.array_equal(np.fromfile(prefix + ".big", np.uint8).reshape(p, -1), ref.records.cpu().numpy())
+    else:
+        assert np.array_equal(np.fromfile(prefix + ".big", np.float32).reshape(p, 3, ph, pw), ref.coeffs.cpu().numpy())

@@ -18,3 +18,15 @@ for wire in (False, True):
         dt = time.perf_counter() - t0
         print(f"wire={wire} batch={batch}: {got / dt:.0f} frames/s PCIe-inclusive ({got} frames in {dt * 1e3:.0f} ms)", flush=True)
         del enc
+
+# the same schedule as a C++ host application (tests/dropin/stream_main.cpp, include/svc/stream_encoder.hpp)
+import subprocess, tempfile
+exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "dropin", "stream_main")
+if os.path.exists(exe):
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "clip.raw")
+        host[:193].tofile(raw)
+        for wire in (0, 1):
+            r = subprocess.run([exe, raw, str(cfg.width), str(cfg.height), "193", str(cfg.levels), str(cfg.dct_block), str(wire), "16",
+                                str(cfg.seed), os.path.join(d, "out")], capture_output=True, text=True)
+            print(f"C++ StreamEncoder wire={wire} batch=16:", (r.stdout + r.stderr).strip(), flush=True)
