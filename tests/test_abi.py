@@ -43,6 +43,15 @@ def test_motion_library_exports_reference_symbols():
     ctypes.CDLL(native.MOTION_LIB_PATH)  # resolves its libsvc_hip.so dependency via $ORIGIN
 
 
+def test_motion_library_exports_stream_encoder():
+    """include/svc/stream_encoder.hpp: the batched host-memory encoder is part of the C++ layer."""
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", native.MOTION_LIB_PATH], text=True)
+    for sym in ("svc::StreamEncoder::StreamEncoder(svc::StreamEncoderConfig const&)", "svc::StreamEncoder::~StreamEncoder()",
+                "svc::StreamEncoder::Encode(unsigned char const*, unsigned int, std::function<void (svc::EncodedBatch const&)> const&)",
+                "svc::StreamEncoder::padded_width() const", "svc::StreamEncoder::padded_height() const"):
+        assert sym in out, sym
+
+
 def test_pyramid_bytes_and_iter_count():
     assert native.pyramid_bytes(1920, 1088, 3) == 2741760      # SURVEY.md section 8 table
     assert native.pyramid_bytes(3840, 2160, 4) == 11016000
