@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
     if (tid < nm) {
       float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 m = mv[samples[(size_t)(it0 + tid) * a.subset + i]];
+        const float2 m = mv[min(samples[(size_t)(it0 + tid) * a.subset + i], a.blocks)];  // [0, N]: N is the reference's off-by-one (svc_hip.h)
         sx = sx + m.x;
         sy = sy + m.y;
       }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
       const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
       float acc = 0.f;
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 m = mv[samples[(size_t)best_it * a.subset + i]];
+        const float2 m = mv[min(samples[(size_t)best_it * a.subset + i], a.blocks)];
         const float dx = m.x - ix, dy = m.y - iy;
         acc += dx * dx + dy * dy;
       }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
     if (tid < nm) {
       float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 s = mv[samples[(size_t)(it0 + tid) * a.subset + i]];
+        const float2 s = mv[min(samples[(size_t)(it0 + tid) * a.subset + i], a.blocks)];  // [0, N]: N is the reference's off-by-one (svc_hip.h)
         sx = sx + s.x;
         sy = sy + s.y;
       }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
       const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
       float acc = 0.f;
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 s = mv[samples[(size_t)best_it * a.subset + i]];
+        const float2 s = mv[min(samples[(size_t)best_it * a.subset + i], a.blocks)];
         const float dx = s.x - ix, dy = s.y - iy;
         acc += dx * dx + dy * dy;
       }
