@@ -139,6 +139,38 @@ def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 12.0):
     }
 
 
+def hbm_streaming_rates(device) -> dict:
+    """What a plain streaming kernel (svc_hip_probe_stream: dwordx4 per lane, contiguous) reaches on THIS GPU, in GB/s,
+    for the read/write mixes of the three HBM-bound kernels.  Measured after the timed region (N = 1 only), with
+    HIP events around three launches each over 2 GiB buffers."""
+    n = 2 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.fill_(1)
+    out = {}
+    for name, r, w in (("read_only", 3, 0), ("write_only", 0, 1), ("3_read_1_write", 3, 1), ("1_read_4_write", 1, 4)):
+        native.probe_stream(a, b, r, w)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            native.probe_stream(a, b, r, w)
+        e1.record()
+        torch.cuda.synchronize()
+        iters = n // (16 * max(r, w))
+        out[name] = iters * 16 * (r + w) / (e0.elapsed_time(e1) / 3 * 1e-3) / 1e9
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b.fill_(0)
+    e0.record()
+    for _ in range(3):
+        b.fill_(0)
+    e1.record()
+    torch.cuda.synchronize()
+    out["write_only_torch_fill"] = n / (e0.elapsed_time(e1) / 3 * 1e-3) / 1e9
+    del a, b
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +323,11 @@ def main() -> None:
             out.pop("roofline_dct")
         if "hbma_wave" in (enc.hbma_kernel_name or ""):
             out["roofline"]["kernel"] = "hbma_wave_level_kernel (LDS-staged wave-per-block search)"
+        if world == 1:
+            # context for the roofline fractions: what plain streaming kernels get from this box's HBM
+            rates = hbm_streaming_rates(dev)
+            out["hbm_streaming_measured"] = {"unit": "GB/s", **rates,
+                                             "note": "svc_hip_probe_stream on this GPU; the MAD kernel is read-only, luma+pyramid 3:1, DCT+quant 1:4"}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, frames)
             if out["cpu_baseline"]["value"]:

@@ -72,6 +72,13 @@ const char* svc_hip_last_error(void);
 int svc_hip_abi_version(void);
 int svc_hip_device_count(int* count);
 
+/* Measurement aid, not part of the hot path: one launch of a plain streaming kernel (dwordx4 per lane,
+ * contiguous across the workgroup) that per iteration reads `reads` x 16 B from d_in and writes `writes` x
+ * 16 B to d_out, over buffers of `bytes` each.  Mixes: 1:0, 3:0, 0:1, 1:1, 3:1, 1:4.  bench.py times it
+ * next to the kernels it reports: what a memory-bound kernel can reach differs from box to box. */
+int svc_hip_probe_stream(const void* d_in, void* d_out, uint64_t bytes, uint32_t reads,
+                         uint32_t writes, void* stream);
+
 /* Bytes of one packed pyramid. */
 uint64_t svc_hip_pyramid_bytes(uint32_t frame_w, uint32_t frame_h, uint32_t level_count);
 

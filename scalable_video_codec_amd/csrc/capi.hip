@@ -105,6 +105,12 @@ int svc_hip_device_count(int* count) {
   return SVC_OK;
 }
 
+int svc_hip_probe_stream(const void* d_in, void* d_out, uint64_t bytes, uint32_t reads, uint32_t writes, void* stream) {
+  SVC_REQUIRE(d_in && d_out, "probe: null pointer");
+  SVC_REQUIRE(aligned(d_in, 16) && aligned(d_out, 16), "probe: buffers must be 16-byte aligned");
+  return launch_stream_probe(d_in, d_out, bytes, reads, writes, static_cast<hipStream_t>(stream));
+}
+
 uint64_t svc_hip_pyramid_bytes(uint32_t w, uint32_t h, uint32_t levels) { return pyramid_bytes(w, h, levels); }
 
 int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride_bytes,

@@ -62,6 +62,8 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------
 
+int launch_stream_probe(const void* d_in, void* d_out, uint64_t bytes, uint32_t reads, uint32_t writes, hipStream_t stream);
+
 int launch_hbma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
                 uint32_t n_pairs, uint32_t levels, uint32_t w, uint32_t h, uint32_t range,
                 uint32_t bw, uint32_t bh, float* d_mv, float* d_mad, uint32_t flags,

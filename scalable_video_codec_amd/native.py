@@ -60,6 +60,7 @@ SIGNATURES = {
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
+    "svc_hip_probe_stream": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp]),
     "svc_hip_segment_workspace_bytes": (_u64, [_u32, _u32, _u32, _u32]),
     "svc_hip_segment_frames": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, SegmentParams, _u64, _vp, _u64, _vp, _vp]),
     "svc_hip_wire_header": (C.c_int, [_u32] * 8 + [C.POINTER(WireHeader)]),
@@ -182,6 +183,12 @@ def block_types_frames(mask: torch.Tensor, out: Optional[torch.Tensor] = None) -
         out = torch.empty((frames, blocks), dtype=torch.int32, device=mask.device)
     _check(load().svc_hip_block_types_frames(_dev(mask, torch.uint8), blocks, frames, _dev(out, torch.int32), _stream()))
     return out
+
+
+def probe_stream(src: torch.Tensor, dst: torch.Tensor, reads: int, writes: int) -> None:
+    """One launch of the plain streaming kernel (measurement aid): reads x 16 B in, writes x 16 B out per lane and iteration."""
+    _check(load().svc_hip_probe_stream(_dev(src, torch.uint8), _dev(dst, torch.uint8), min(src.numel(), dst.numel()),
+                                       reads, writes, _stream()))
 
 
 def segment_workspace_bytes(mfw: int, mfh: int, frames: int, attempts: int = 3) -> int:

@@ -8,9 +8,11 @@
 // each lane: R dwordx4 loads and W dwordx4 stores per iteration, contiguous across the workgroup
 template <int R, int W>
 __global__ __launch_bounds__(256) void stream(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16, uint32_t magic) {
-  const size_t stride = (size_t)gridDim.x * 256;
+  // a workgroup walks its own contiguous slice, as the library's svc_hip_probe_stream does
+  const size_t iters = n16 / (R > W ? R : W), per_wg = (iters + gridDim.x - 1) / gridDim.x;
+  const size_t i0 = (size_t)blockIdx.x * per_wg, i1 = i0 + per_wg < iters ? i0 + per_wg : iters;
   uint4 acc = make_uint4(magic, 0, 0, 0);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + (size_t)(R > W ? R : W) * stride <= n16 + stride - 1 && i < n16 / (R > W ? R : W); i += stride) {
+  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint4 v = in[i * R + r];  // a lane's R loads are adjacent; lanes are R * 16 B apart (the BGR pattern for R = 3)
