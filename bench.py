@@ -328,6 +328,9 @@ def main() -> None:
             rates = hbm_streaming_rates(dev)
             out["hbm_streaming_measured"] = {"unit": "GB/s", **rates,
                                              "note": "svc_hip_probe_stream on this GPU; the MAD kernel is read-only, luma+pyramid 3:1, DCT+quant 1:4"}
+            out["roofline"]["frac_of_streaming_read_rate"] = hbma_gbps / rates["read_only"]
+            if has_dct:
+                out["roofline_dct"]["frac_of_streaming_fill_rate"] = dct_gbps / rates["write_only_torch_fill"]
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, frames)
             if out["cpu_baseline"]["value"]:
