@@ -1065,6 +1065,27 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
 #endif
 }
 
+// One side stream + fork/join events per host thread and device, created on first use and kept.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+static SideStream* side_stream() {
+  constexpr int kMaxDevices = 64;
+  static thread_local SideStream per_device[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  SideStream& s = per_device[dev];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  }
+  return &s;
+}
+
 uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts) {
   return Workspace{nullptr, n, attempts ? attempts : 1}.bytes();
 }
@@ -1105,11 +1126,23 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   a.lds_bytes = (uint32_t)(a.bits_bytes + 4 * n4 <= kLdsBig ? a.bits_bytes + 4 * n4 : kLdsBig);
   hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);
   a.lds_bytes = 0;
-  hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), a.n > kRegPts * 256 ? 8 * kLightMax : 0, stream, a);
   if (a.n > kLightMax) {
+    // The two attempt launches are independent (each frame belongs to exactly one): the heavy one goes to a
+    // side stream, forked after the prepare kernel and joined before the labelling, so a scene cut's long
+    // workgroups run beside the light frames instead of after them.
+    SideStream* side = side_stream();
+    if (!side) return fail(SVC_ERR_HIP, "segment: cannot create the side stream");
+    SegArgs heavy = a;
     // more than kRegPts points per lane are possible: LDS for the large-frame path
-    if (a.n > kRegPts * kTA) a.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
-    hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), a.lds_bytes, stream, a);
+    if (a.n > kRegPts * kTA) heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
+    hipEventRecord(side->fork, stream);
+    hipStreamWaitEvent(side->stream, side->fork, 0);
+    hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, side->stream, heavy);
+    hipEventRecord(side->join, side->stream);
+    hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
+    hipStreamWaitEvent(stream, side->join, 0);
+  } else {
+    hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
   }
   if (5 * n4 <= kLdsBig)
     hipLaunchKernelGGL((segment_label_kernel<true, true>), dim3(n_frames), dim3(kTA), 5 * n4, stream, a);
