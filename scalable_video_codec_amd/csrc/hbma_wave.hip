@@ -5,13 +5,19 @@
 // libs/motion.cpp:268-340) and, level by level, behind EstimateMotionHierarchical
 // (:412-465) for shapes the fused kernel (hbma_fused.hip) does not cover.
 //
-// Per MV block (one 64-lane wave = one workgroup):
+// A workgroup is one 64-lane wave.  Its lanes are cut into groups of 64, 32 or 16 -- the smallest
+// power of two that holds a level's (2R+1)^2 candidates -- and every group searches its own MV
+// block (25 candidates would otherwise leave 39 of 64 lanes idle, 9 candidates 55); a wave then
+// walks several such rounds, because at the coarse levels (4x4, 2x2 blocks) a launch of one tiny
+// workgroup per block is bound by the workgroup launch rate, not by its arithmetic.
+// Per MV block (one group of lanes):
 //   1. the anchor block and the clamped search window of the tracked plane are
 //      staged in LDS with coalesced dword loads (window origin aligned down to 4);
 //   2. candidates are dealt across lanes in raster order; each lane walks its
 //      candidates' rows with v_sad_u8 over 4-byte words, realigning the tracked
 //      word with v_alignbyte_b32;
-//   3. a wave-wide min over packed (sad, index) keys gives the argmin with the
+//   3. a group-wide min over packed (sad, index) keys (xor-shuffles below the group size never
+//      leave the group) gives the argmin with the
 //      reference's tie rule: top level `<=` => LAST raster minimum (:324),
 //      refinement strict `<` => FIRST raster minimum that beats the MAD carried
 //      from the coarser level (:401);
@@ -38,13 +44,19 @@ struct WaveLevelArgs {
   uint32_t w_pitch;     // LDS row pitch of the window
   uint32_t sads_off;    // LDS byte offset of the per-candidate SAD array
   uint32_t top;         // 1 = EBMA semantics, 0 = refinement semantics
+  uint32_t gs;          // lanes per group: 64, 32 or 16
+  uint32_t rounds;      // rounds of 64 / gs blocks a wave walks
+  uint32_t lds_group;   // LDS bytes per group
+  uint32_t n_items;     // pairs * blocks
   float* mv;            // [pairs][blocks][2]
   float* mad;           // [pairs][blocks]
 };
 
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+// min over the gs-lane group the lane belongs to (gs a power of two: lane ^ off stays inside it)
+__device__ __forceinline__ uint64_t group_min_u64(uint64_t v, uint32_t gs) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
+    if ((uint32_t)off >= gs) continue;
     uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
     uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
     uint64_t o = ((uint64_t)hi << 32) | lo;
@@ -55,27 +67,33 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 
 template <bool DW>
 __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+  const uint32_t gs = a.gs, groups = 64u / gs;
+  const uint32_t sub = threadIdx.x / gs, lane = threadIdx.x - sub * gs;  // group and lane inside it
+  uint8_t* lds = lds_all + (size_t)sub * a.lds_group;
   uint8_t* lds_anchor = lds;
   uint8_t* lds_win = lds + (size_t)a.bh * a.a_pitch;
   uint32_t* lds_sads = reinterpret_cast<uint32_t*>(lds + a.sads_off);
+  const unsigned long long gmask = (gs == 64 ? ~0ull : ((1ull << gs) - 1ull)) << (sub * gs);
 
-  const uint32_t lane = threadIdx.x;
-  const uint32_t item = blockIdx.x;  // pair * blocks + block
-  const uint32_t pair = item / a.blocks;
-  const uint32_t blk = item - pair * a.blocks;
+  for (uint32_t round = 0; round < a.rounds; ++round) {
+  const uint32_t item = (blockIdx.x * a.rounds + round) * groups + sub;  // pair * blocks + block
+  const bool live = item < a.n_items;  // a dead group keeps pace with the barriers and shuffles, on item 0's data
+  const uint32_t it = live ? item : 0u;
+  const uint32_t pair = it / a.blocks;
+  const uint32_t blk = it - pair * a.blocks;
   const uint32_t by = blk / a.mfw, bx = blk - by * a.mfw;
   const uint32_t ax = bx * a.bw, ay = by * a.bh;
 
   const uint8_t* trk = a.tracked + pair * a.pair_stride + a.level_off;
   const uint8_t* anc = a.anchor + pair * a.pair_stride + a.level_off;
-  float* mv = a.mv + ((size_t)item) * 2;
-  float* mad = a.mad + item;
+  float* mv = a.mv + ((size_t)it) * 2;
+  float* mad = a.mad + it;
 
   // centre of the search (libs/motion.cpp:372-373; the MV was doubled at :458-460)
   int mvx = 0, mvy = 0;
   float carried = 0.f;
-  if (!a.top) {
+  if (!a.top && live) {  // a dead group searches around (0, 0): always a valid window
     mvx = 2 * (int)roundf(mv[0]);
     mvy = 2 * (int)roundf(mv[1]);
     carried = *mad;
@@ -95,12 +113,12 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
     const uint32_t x0a = x0 & ~3u;
     xshift = x0 - x0a;
     const uint32_t a_dw = a.a_pitch >> 2, w_dw = a.w_pitch >> 2;
-    for (uint32_t i = lane; i < a.bh * a_dw; i += 64) {
+    for (uint32_t i = lane; i < a.bh * a_dw; i += gs) {
       uint32_t r = i / a_dw, c = i - r * a_dw;
       reinterpret_cast<uint32_t*>(lds_anchor)[i] =
           *reinterpret_cast<const uint32_t*>(anc + (size_t)(ay + r) * a.fw + ax + 4 * c);
     }
-    for (uint32_t i = lane; i < win_rows * w_dw; i += 64) {
+    for (uint32_t i = lane; i < win_rows * w_dw; i += gs) {
       uint32_t r = i / w_dw, c = i - r * w_dw;
       // columns past the last needed byte are don't-care; keep them in the row
       uint32_t col = min(x0a + 4 * c, a.fw - 4u);
@@ -108,21 +126,21 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
           *reinterpret_cast<const uint32_t*>(trk + (size_t)(y0 + r) * a.fw + col);
     }
   } else {
-    for (uint32_t i = lane; i < a.bh * a.bw; i += 64) {
+    for (uint32_t i = lane; i < a.bh * a.bw; i += gs) {
       uint32_t r = i / a.bw, c = i - r * a.bw;
       lds_anchor[r * a.a_pitch + c] = anc[(size_t)(ay + r) * a.fw + ax + c];
     }
     const uint32_t wcols = nx + a.bw - 1;
-    for (uint32_t i = lane; i < win_rows * wcols; i += 64) {
+    for (uint32_t i = lane; i < win_rows * wcols; i += gs) {
       uint32_t r = i / wcols, c = i - r * wcols;
       lds_win[r * a.w_pitch + c] = trk[(size_t)(y0 + r) * a.fw + x0 + c];
     }
   }
   __syncthreads();
 
-  // each lane: candidates lane, lane+64, ... in raster order
+  // each lane: candidates lane, lane+gs, ... in raster order
   uint32_t best_sad = 0xFFFFFFFFu, best_idx = 0;
-  for (uint32_t c = lane; c < ncand; c += 64) {
+  for (uint32_t c = lane; c < ncand; c += gs) {
     const uint32_t iy = c / nx, ix = c - iy * nx;
     uint32_t sad = 0;
     if (DW) {
@@ -156,20 +174,20 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
   }
   __syncthreads();
 
-  // wave argmin: smaller sad first, then LAST index (top) / FIRST index (refine)
+  // group argmin: smaller sad first, then LAST index (top) / FIRST index (refine)
   uint64_t key = ((uint64_t)best_sad << 32) | (a.top ? ~best_idx : best_idx);
-  key = wave_min_u64(key);
+  key = group_min_u64(key, gs);
   const uint32_t w_sad = (uint32_t)(key >> 32);
   const uint32_t w_idx = a.top ? ~(uint32_t)key : (uint32_t)key;
 
   // top level: did every candidate update, i.e. are the SADs non-increasing?
   bool mono = true;
   if (a.top)
-    for (uint32_t c = lane; c < ncand; c += 64)
+    for (uint32_t c = lane; c < ncand; c += gs)
       if (c > 0 && lds_sads[c] > lds_sads[c - 1]) mono = false;
-  const bool all_updated = __all(mono);
+  const bool all_updated = (__ballot(mono) & gmask) == gmask;
 
-  if (lane == 0) {
+  if (lane == 0 && live) {
     const float m = (float)w_sad / (float)(a.bw * a.bh);  // libs/motion.cpp:38-40
     const uint32_t iy = w_idx / nx, ix = w_idx - iy * nx;
     float ox = (float)((int)(x0 + ix) - (int)ax);
@@ -187,6 +205,8 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
       mv[0] = (float)mvx;
       mv[1] = (float)mvy;
     }
+  }
+  __syncthreads();  // the LDS areas are restaged by the next round
   }
 }
 
@@ -218,14 +238,21 @@ static int launch_wave_level(const uint8_t* d_tracked, const uint8_t* d_anchor,
                 "hbma: block %ux%u with search range %u needs %llu B of LDS per block (limit 65536)",
                 bw, bh, range, (unsigned long long)lds_bytes);
   a.sads_off = (uint32_t)off;
-  const uint64_t grid = (uint64_t)a.blocks * n_pairs;
-  if (grid == 0) return SVC_OK;
-  if (grid > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu work items exceed one launch", (unsigned long long)grid);
+  const uint64_t items = (uint64_t)a.blocks * n_pairs;
+  if (items == 0) return SVC_OK;
+  if (items > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu work items exceed one launch", (unsigned long long)items);
+  a.n_items = (uint32_t)items;
+  a.gs = ncand_max <= 16 ? 16u : ncand_max <= 32 ? 32u : 64u;
+  const uint32_t groups = 64u / a.gs;
+  a.lds_group = (uint32_t)((lds_bytes + 15u) & ~15ull);
+  // small blocks: several rounds per wave, so that a launch is not bound by the workgroup launch rate
+  a.rounds = bw * bh <= 16 ? 8u : bw * bh <= 64 ? 4u : 2u;
+  const uint64_t grid = (items + (uint64_t)groups * a.rounds - 1) / ((uint64_t)groups * a.rounds);
   const bool dw = (bw % 4 == 0) && (fw % 4 == 0) && fw >= 4;
   if (dw)
-    hipLaunchKernelGGL(hbma_wave_level_kernel<true>, dim3((uint32_t)grid), dim3(64), lds_bytes, stream, a);
+    hipLaunchKernelGGL(hbma_wave_level_kernel<true>, dim3((uint32_t)grid), dim3(64), (size_t)a.lds_group * groups, stream, a);
   else
-    hipLaunchKernelGGL(hbma_wave_level_kernel<false>, dim3((uint32_t)grid), dim3(64), lds_bytes, stream, a);
+    hipLaunchKernelGGL(hbma_wave_level_kernel<false>, dim3((uint32_t)grid), dim3(64), (size_t)a.lds_group * groups, stream, a);
   return check_launch("hbma_wave_level_kernel");
 }
 
