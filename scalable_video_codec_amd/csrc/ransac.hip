@@ -248,57 +248,70 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
 
 // ---- the same, with the motion field in registers ---------------------------------------------
 // The kernel above walks the field in L2 half a dozen times and pays a block-wide reduction (two
-// barriers) per model.  For fields of up to 32 x T blocks every lane keeps ITS blocks (i = u * T + tid)
+// barriers) per model.  For fields of up to PER x G blocks every lane keeps ITS blocks (i = u * G + gt)
 // in registers for the whole kernel: the models of a pass are scored against registers, their
 // counts reduced inside the wave and summed across waves by one lane after ONE barrier, and the
 // mask / mean / RMSE passes never touch memory for the field again.  Out-of-range slots hold
 // +inf, which no model accepts.  Same arithmetic, same order: bit-identical results.
+//
+// A workgroup of T lanes takes F frames, G = T / F lanes each.  What that buys is the serial tail:
+// the in-order f32 sums are one dependent add per term (~8.7 cycles each, 8 160 terms at 1080p)
+// whatever the lane count, and two workgroups sharing a CU were measured to stretch each other's
+// chain by 1.7x -- a 300-frame clip on 256 CUs doubles up on 43 of them.  With F = 2 the clip is 150
+// workgroups, one per CU, and the chains of a workgroup's frames run as LANES of one wave, in the
+// same instructions.  Every barrier is reached by all groups: nothing below returns early or loops
+// on a per-frame condition.
 constexpr uint32_t kPassModels = 16;
 
-template <uint32_t T, uint32_t PER>
-__global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
-  __shared__ __attribute__((aligned(16))) float2 s_stage[kChunk];
-  __shared__ float s_model[kPassModels][2];
-  __shared__ uint32_t s_cnt[2][T / 64][kPassModels];
-  __shared__ int s_isum[2];
-  __shared__ uint32_t s_flag, s_mag, s_bestn, s_bestit;
-  __shared__ float s_gm[2];
-  const uint32_t tid = threadIdx.x, frame = blockIdx.x, lane = tid & 63u, wave = tid >> 6;
+template <uint32_t T, uint32_t PER, uint32_t F>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_reg_kernel(RansacArgs a, uint32_t n_frames) {
+  constexpr uint32_t G = T / F, GW = G / 64;  // lanes and waves per frame
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];  // F staging areas of kChunk float2
+  __shared__ float s_model[F][kPassModels][2];
+  __shared__ uint32_t s_cnt[2][F][GW][kPassModels];
+  __shared__ int s_isum[F][2];
+  __shared__ uint32_t s_flag[F], s_mag[F], s_bestn[F], s_bestit[F], s_serial;
+  __shared__ float s_gm[F][2], s_out[F][2];
+  const uint32_t tid = threadIdx.x, g = tid / G, gt = tid - g * G, lane = tid & 63u, gwave = gt >> 6;
+  const uint32_t frame_raw = blockIdx.x * F + g;
+  const bool live = frame_raw < n_frames;
+  const uint32_t frame = live ? frame_raw : 0u;  // a dead group recomputes frame 0 and writes nothing
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * a.blocks;
   const uint32_t* samples = a.samples + (size_t)frame * a.iters * a.subset;
   uint8_t* mask = a.mask + (size_t)frame * a.blocks;
+  float2* s_stage = reinterpret_cast<float2*>(dyn_lds) + (size_t)g * kChunk;
   const float t2 = a.thresh * a.thresh;
 
   float2 m[PER];
 #pragma unroll
   for (uint32_t u = 0; u < PER; ++u) {
-    const uint32_t i = u * T + tid;
+    const uint32_t i = u * G + gt;
     m[u] = i < a.blocks ? mv[i] : make_float2(__builtin_inff(), __builtin_inff());
   }
 
   // ---- iterations (motion.cpp:210-238), kPassModels at a time ---------------------------------
-  uint32_t best_n = 0, best_it = 0;  // tracked by thread 0, published below
+  uint32_t best_n = 0, best_it = 0;  // tracked by the group's first lane, published below
   float bgx = 0.f, bgy = 0.f;
   uint32_t par = 0;
   for (uint32_t it0 = 0; it0 < a.iters; it0 += kPassModels, par ^= 1u) {
     const uint32_t nm = min(kPassModels, a.iters - it0);
-    if (tid < nm) {
+    if (gt < nm) {
       float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 s = mv[min(samples[(size_t)(it0 + tid) * a.subset + i], a.blocks)];  // [0, N]: N is the reference's off-by-one (svc_hip.h)
+        const float2 s = mv[min(samples[(size_t)(it0 + gt) * a.subset + i], a.blocks)];  // [0, N]: N is the reference's off-by-one (svc_hip.h)
         sx = sx + s.x;
         sy = sy + s.y;
       }
       const float inv = 1.0f / (float)a.subset;
-      s_model[tid][0] = sx * inv;
-      s_model[tid][1] = sy * inv;
+      s_model[g][gt][0] = sx * inv;
+      s_model[g][gt][1] = sy * inv;
     }
     __syncthreads();
     float gx[kPassModels], gy[kPassModels];
 #pragma unroll
     for (uint32_t k = 0; k < kPassModels; ++k) {
-      gx[k] = s_model[k < nm ? k : 0][0];
-      gy[k] = s_model[k < nm ? k : 0][1];
+      gx[k] = s_model[g][k < nm ? k : 0][0];
+      gy[k] = s_model[g][k < nm ? k : 0][1];
     }
 #pragma unroll
     for (uint32_t k = 0; k < kPassModels; ++k) {
@@ -308,13 +321,13 @@ __global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
       for (uint32_t u = 0; u < PER; ++u) c += is_inlier(gx[k], gy[k], m[u].x, m[u].y, t2) ? 1u : 0u;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-      if (lane == 0) s_cnt[par][wave][k] = c;
+      if (lane == 0) s_cnt[par][g][gwave][k] = c;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (gt == 0) {
       for (uint32_t k = 0; k < nm; ++k) {
         uint32_t total = 0;
-        for (uint32_t w = 0; w < T / 64; ++w) total += s_cnt[par][w][k];
+        for (uint32_t w = 0; w < GW; ++w) total += s_cnt[par][g][w][k];
         if (total >= best_n) {  // motion.cpp:233, in iteration order: ties -> later
           best_n = total;
           best_it = it0 + k;
@@ -326,46 +339,28 @@ __global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
     // s_model is rewritten by the next pass only after every lane has read it (the reads sit before
     // the barrier above); s_cnt alternates between two copies
   }
-  if (tid == 0) { s_bestn = best_n; s_bestit = best_it; s_gm[0] = bgx; s_gm[1] = bgy; s_flag = 1u; s_isum[0] = 0; s_isum[1] = 0; s_mag = 0; }
-  __syncthreads();
-  best_n = s_bestn; best_it = s_bestit; bgx = s_gm[0]; bgy = s_gm[1];
-  const bool any_iter = a.iters > 0;
-
-  if (best_n < a.subset) {
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-      const uint32_t i = u * T + tid;
-      if (i < a.blocks) mask[i] = (any_iter && is_inlier(bgx, bgy, m[u].x, m[u].y, t2)) ? 1 : 0;
-    }
-    // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
-    if (tid == 0) {
-      const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
-      float acc = 0.f;
-      for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 s = mv[min(samples[(size_t)best_it * a.subset + i], a.blocks)];
-        const float dx = s.x - ix, dy = s.y - iy;
-        acc += dx * dx + dy * dy;
-      }
-      a.gm[2 * frame] = bgx;
-      a.gm[2 * frame + 1] = bgy;
-      a.rmse[frame] = sqrtf(acc / (float)a.subset);
-      a.count[frame] = best_n;
-    }
-    return;
+  if (gt == 0) {
+    s_bestn[g] = best_n; s_bestit[g] = best_it; s_gm[g][0] = bgx; s_gm[g][1] = bgy;
+    s_flag[g] = 1u; s_isum[g][0] = 0; s_isum[g][1] = 0; s_mag[g] = 0;
   }
+  if (tid == 0) s_serial = 0;
+  __syncthreads();
+  best_n = s_bestn[g]; best_it = s_bestit[g]; bgx = s_gm[g][0]; bgy = s_gm[g][1];
+  const bool any_iter = a.iters > 0;
+  const bool few = best_n < a.subset;  // motion.cpp:240-242: keep the best subset's model, RMSE against the incoming one
 
   // ---- inlier mask (== best_inliers, motion.cpp:244-253) and the final model = mean of the
   // inliers (motion.cpp:255-256); integer fast path as in ransac_kernel
-  uint64_t inl = 0;  // bit u: block u * T + tid is an inlier
+  uint64_t inl = 0;  // bit u: block u * G + gt is an inlier
   {
     bool ok = true;
     int ix = 0, iy = 0;
     uint32_t mag = 0;
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
-      const uint32_t i = u * T + tid;
-      const bool in = is_inlier(bgx, bgy, m[u].x, m[u].y, t2);
-      if (i < a.blocks) mask[i] = in ? 1 : 0;
+      const uint32_t i = u * G + gt;
+      const bool in = (!few || any_iter) && is_inlier(bgx, bgy, m[u].x, m[u].y, t2);
+      if (live && i < a.blocks) mask[i] = in ? 1 : 0;
       if (!in) continue;
       inl |= 1ull << u;
       ok = ok && m[u].x == truncf(m[u].x) && m[u].y == truncf(m[u].y) && fabsf(m[u].x) <= 32768.f && fabsf(m[u].y) <= 32768.f;
@@ -374,7 +369,7 @@ __global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
         mag += (uint32_t)fabsf(m[u].x) + (uint32_t)fabsf(m[u].y);
       }
     }
-    if (!ok || mag >= (1u << 24)) s_flag = 0u;
+    if (!ok || mag >= (1u << 24)) s_flag[g] = 0u;
     mag &= 0xFFFFFFu;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -383,60 +378,82 @@ __global__ __launch_bounds__(T) void ransac_reg_kernel(RansacArgs a) {
       mag += __shfl_xor(mag, off, 64);
     }
     if (lane == 0) {
-      if (mag >= (1u << 24)) { s_flag = 0u; mag = 0; }  // a wave's 64 addends fit; T / 64 clamped ones cannot wrap s_mag
-      atomicAdd(&s_isum[0], ix);
-      atomicAdd(&s_isum[1], iy);
-      atomicAdd(&s_mag, mag);
+      if (mag >= (1u << 24)) { s_flag[g] = 0u; mag = 0; }  // a wave's 64 addends fit; GW clamped ones cannot wrap s_mag
+      atomicAdd(&s_isum[g][0], ix);
+      atomicAdd(&s_isum[g][1], iy);
+      atomicAdd(&s_mag[g], mag);
     }
   }
   __syncthreads();
-  const bool exact_int = s_flag != 0u && s_mag < (1u << 24);
+  const bool exact_int = s_flag[g] != 0u && s_mag[g] < (1u << 24);
+  if (gt == 0 && !few && !exact_int) s_serial = 1;  // some frame of this workgroup needs the in-order walk
+  __syncthreads();
   float sx = 0.f, sy = 0.f;
   if (exact_int) {
-    sx = (float)s_isum[0];
-    sy = (float)s_isum[1];
-  } else {
+    sx = (float)s_isum[g][0];
+    sy = (float)s_isum[g][1];
+  }
+  if (s_serial) {  // workgroup-uniform
     for (uint32_t base = 0; base < a.blocks; base += kChunk) {
       const uint32_t n = min(kChunk, a.blocks - base);
 #pragma unroll
       for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t i = u * T + tid;
+        const uint32_t i = u * G + gt;
         if (i >= base && i < base + n) s_stage[i - base] = ((inl >> u) & 1ull) ? m[u] : make_float2(0.f, 0.f);
       }
       __syncthreads();
-      if (tid == 0) serial_sum2(s_stage, n, sx, sy);
+      if (gt == 0 && !exact_int) serial_sum2(s_stage, n, sx, sy);
       __syncthreads();
     }
-    if (tid == 0) { s_gm[0] = sx; s_gm[1] = sy; }
+    if (gt == 0 && !exact_int) { s_gm[g][0] = sx; s_gm[g][1] = sy; }
     __syncthreads();
-    sx = s_gm[0];
-    sy = s_gm[1];
+    if (!exact_int) { sx = s_gm[g][0]; sy = s_gm[g][1]; }
   }
   const float inv = 1.0f / (float)best_n;
-  const float out_gx = sx * inv, out_gy = sy * inv;
+  const float out_gx = few ? bgx : sx * inv, out_gy = few ? bgy : sy * inv;
+  if (gt == 0) { s_out[g][0] = out_gx; s_out[g][1] = out_gy; }  // read after the barriers of the RMSE loop
 
-  // ---- RMSE (motion.cpp:258-259, :165-180): terms in parallel, the sum in order -----
+  // ---- RMSE (motion.cpp:258-259, :165-180): terms in parallel, the sums in order -- lane f of the
+  // first wave walks frame f's terms, all F chains in the same instructions
   float acc = 0.f;
-  float* terms = reinterpret_cast<float*>(s_stage);
   for (uint32_t base = 0; base < a.blocks; base += 2 * kChunk) {
     const uint32_t n = min(2 * kChunk, a.blocks - base);
+    float* terms = reinterpret_cast<float*>(s_stage);
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
-      const uint32_t i = u * T + tid;
+      const uint32_t i = u * G + gt;
       if (i >= base && i < base + n) {
         const float dx = m[u].x - out_gx, dy = m[u].y - out_gy;
         terms[i - base] = ((inl >> u) & 1ull) ? dx * dx + dy * dy : 0.f;
       }
     }
     __syncthreads();
-    if (tid == 0) serial_sum1(terms, n, acc);
+    if (tid < F) serial_sum1(reinterpret_cast<const float*>(reinterpret_cast<const float2*>(dyn_lds) + (size_t)tid * kChunk), n, acc);
     __syncthreads();
   }
-  if (tid == 0) {
-    a.gm[2 * frame] = out_gx;
-    a.gm[2 * frame + 1] = out_gy;
-    a.rmse[frame] = sqrtf(acc / (float)best_n);
-    a.count[frame] = best_n;
+  if (tid < F && blockIdx.x * F + tid < n_frames) {
+    const uint32_t f = blockIdx.x * F + tid;  // lane f of the first wave finishes frame f of the workgroup
+    const uint32_t bn = s_bestn[tid];
+    const bool fw = bn < a.subset;
+    float r;
+    if (fw) {  // motion.cpp:240-242: RMSE of the best subset against the INCOMING global motion
+      const float2* fmv = reinterpret_cast<const float2*>(a.mv) + (size_t)f * a.blocks;
+      const uint32_t* fs = a.samples + (size_t)f * a.iters * a.subset;
+      const float ix = a.gm[2 * f], iy = a.gm[2 * f + 1];
+      float e = 0.f;
+      for (uint32_t i = 0; i < a.subset; ++i) {
+        const float2 s = fmv[min(fs[(size_t)s_bestit[tid] * a.subset + i], a.blocks)];
+        const float dx = s.x - ix, dy = s.y - iy;
+        e += dx * dx + dy * dy;
+      }
+      r = sqrtf(e / (float)a.subset);
+    } else {
+      r = sqrtf(acc / (float)bn);
+    }
+    a.gm[2 * f] = s_out[tid][0];  // published by the frame's own group
+    a.gm[2 * f + 1] = s_out[tid][1];
+    a.rmse[f] = r;
+    a.count[f] = bn;
   }
 }
 
@@ -473,12 +490,15 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ran
   a.rmse = d_rmse;
   a.mask = d_mask;
   a.count = d_count;
+  constexpr size_t kStage = kChunk * sizeof(float2);
   if (blocks <= 8 * 256)
-    hipLaunchKernelGGL((ransac_reg_kernel<256, 8>), dim3(n_frames), dim3(256), 0, stream, a);
-  else if (blocks <= 8 * 1024)
-    hipLaunchKernelGGL((ransac_reg_kernel<1024, 8>), dim3(n_frames), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL((ransac_reg_kernel<256, 8, 1>), dim3(n_frames), dim3(256), kStage, stream, a, n_frames);
+  else if (blocks <= 8 * 1024 && n_frames <= 256)  // one workgroup per CU as it is
+    hipLaunchKernelGGL((ransac_reg_kernel<1024, 8, 1>), dim3(n_frames), dim3(1024), kStage, stream, a, n_frames);
+  else if (blocks <= 16 * 512)  // more frames than CUs: two frames per workgroup rather than two workgroups per CU
+    hipLaunchKernelGGL((ransac_reg_kernel<1024, 16, 2>), dim3((n_frames + 1) / 2), dim3(1024), 2 * kStage, stream, a, n_frames);
   else if (blocks <= 32 * 1024)
-    hipLaunchKernelGGL((ransac_reg_kernel<1024, 32>), dim3(n_frames), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL((ransac_reg_kernel<1024, 32, 1>), dim3(n_frames), dim3(1024), kStage, stream, a, n_frames);
   else
     hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), 0, stream, a);
   return check_launch("ransac_kernel");
