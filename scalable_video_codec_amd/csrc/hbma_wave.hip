@@ -5,17 +5,18 @@
 // libs/motion.cpp:268-340) and, level by level, behind EstimateMotionHierarchical
 // (:412-465) for shapes the fused kernel (hbma_fused.hip) does not cover.
 //
-// A workgroup is one 64-lane wave.  Its lanes are cut into groups of 64, 32 or 16 -- the smallest
-// power of two that holds a level's (2R+1)^2 candidates -- and every group searches its own MV
+// A workgroup is one 64-lane wave.  Its lanes are cut into groups of 4 .. 64 -- the smallest power
+// of two that holds a level's lane tasks (four candidates each on the dword path) -- and every group searches its own MV
 // block (25 candidates would otherwise leave 39 of 64 lanes idle, 9 candidates 55); a wave then
 // walks several such rounds, because at the coarse levels (4x4, 2x2 blocks) a launch of one tiny
 // workgroup per block is bound by the workgroup launch rate, not by its arithmetic.
 // Per MV block (one group of lanes):
 //   1. the anchor block and the clamped search window of the tracked plane are
 //      staged in LDS with coalesced dword loads (window origin aligned down to 4);
-//   2. candidates are dealt across lanes in raster order; each lane walks its
-//      candidates' rows with v_sad_u8 over 4-byte words, realigning the tracked
-//      word with v_alignbyte_b32;
+//   2. the candidate grid is dealt across lanes four horizontally adjacent candidates at a
+//      time, in raster order; a lane walks their rows with v_qsad_pk_u16_u8 (one anchor word
+//      against 8 window bytes = the SADs of all four), the window having been funnel-shifted
+//      to a dword boundary when it was staged;
 //   3. a group-wide min over packed (sad, index) keys (xor-shuffles below the group size never
 //      leave the group) gives the argmin with the
 //      reference's tie rule: top level `<=` => LAST raster minimum (:324),
@@ -44,7 +45,7 @@ struct WaveLevelArgs {
   uint32_t w_pitch;     // LDS row pitch of the window
   uint32_t sads_off;    // LDS byte offset of the per-candidate SAD array
   uint32_t top;         // 1 = EBMA semantics, 0 = refinement semantics
-  uint32_t gs;          // lanes per group: 64, 32 or 16
+  uint32_t gs;          // lanes per group: a power of two, 4 .. 64
   uint32_t rounds;      // rounds of 64 / gs blocks a wave walks
   uint32_t lds_group;   // LDS bytes per group
   uint32_t n_items;     // pairs * blocks
@@ -120,10 +121,12 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
     }
     for (uint32_t i = lane; i < win_rows * w_dw; i += gs) {
       uint32_t r = i / w_dw, c = i - r * w_dw;
-      // columns past the last needed byte are don't-care; keep them in the row
-      uint32_t col = min(x0a + 4 * c, a.fw - 4u);
-      reinterpret_cast<uint32_t*>(lds_win)[i] =
-          *reinterpret_cast<const uint32_t*>(trk + (size_t)(y0 + r) * a.fw + col);
+      // funnel-shifted once here so that column x0 sits at byte 0 of the staged row (the QSADs below
+      // want their windows dword-aligned); columns past the last needed byte are don't-care
+      const uint8_t* row = trk + (size_t)(y0 + r) * a.fw;
+      const uint32_t lo = *reinterpret_cast<const uint32_t*>(row + min(x0a + 4 * c, a.fw - 4u));
+      const uint32_t hi = *reinterpret_cast<const uint32_t*>(row + min(x0a + 4 * c + 4, a.fw - 4u));
+      reinterpret_cast<uint32_t*>(lds_win)[i] = __builtin_amdgcn_alignbyte(hi, lo, xshift);
     }
   } else {
     for (uint32_t i = lane; i < a.bh * a.bw; i += gs) {
@@ -138,38 +141,64 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
   }
   __syncthreads();
 
-  // each lane: candidates lane, lane+gs, ... in raster order
   uint32_t best_sad = 0xFFFFFFFFu, best_idx = 0;
-  for (uint32_t c = lane; c < ncand; c += gs) {
-    const uint32_t iy = c / nx, ix = c - iy * nx;
-    uint32_t sad = 0;
-    if (DW) {
-      const uint32_t a_dw = a.a_pitch >> 2;
-      const uint32_t* a32 = reinterpret_cast<const uint32_t*>(lds_anchor);
-      const uint32_t* w32 = reinterpret_cast<const uint32_t*>(lds_win);
+  if (DW) {
+    // a lane takes FOUR horizontally adjacent candidates of one row of the grid: v_qsad_pk_u16_u8 gives, for one
+    // anchor word and 8 window bytes, the SADs at byte offsets 0..3 (16 issue cycles for 16 byte-differences:
+    // half of align + v_sad_u8 per candidate, and a quarter of the LDS reads)
+    const uint32_t ngx = (nx + 3) >> 2, ntasks = ny * ngx;
+    const uint32_t a_dw = a.a_pitch >> 2, w_dw = a.w_pitch >> 2, nwords = a.bw >> 2;
+    const uint32_t* a32 = reinterpret_cast<const uint32_t*>(lds_anchor);
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(lds_win);
+    const uint32_t flush_rows = max(1u, 256u / a.bw);  // packed u16 accumulators hold 256 byte-differences
+    for (uint32_t t = lane; t < ntasks; t += gs) {
+      const uint32_t iy = t / ngx, gxi = t - iy * ngx;
+      uint32_t s4[4] = {0, 0, 0, 0};
+      uint64_t acc = 0;
+      uint32_t since = 0;
       for (uint32_t r = 0; r < a.bh; ++r) {
-        const uint32_t o = (iy + r) * a.w_pitch + xshift + ix;
-        const uint32_t* wrow = w32 + (o >> 2);
-        const uint32_t sh = o & 3u;
+        const uint32_t* wrow = w32 + (iy + r) * w_dw + gxi;
         uint32_t lo = wrow[0];
-        for (uint32_t k = 0; k < a.bw / 4; ++k) {
-          uint32_t hi = wrow[k + 1];
-          uint32_t t = __builtin_amdgcn_alignbyte(hi, lo, sh);
-          sad = __builtin_amdgcn_sad_u8(a32[r * a_dw + k], t, sad);
+        for (uint32_t k = 0; k < nwords; ++k) {
+          const uint32_t hi = wrow[k + 1];
+          acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)hi << 32) | lo, a32[r * a_dw + k], acc);
           lo = hi;
         }
+        if (++since == flush_rows) {
+          s4[0] += (uint32_t)acc & 0xFFFFu; s4[1] += (uint32_t)(acc >> 16) & 0xFFFFu;
+          s4[2] += (uint32_t)(acc >> 32) & 0xFFFFu; s4[3] += (uint32_t)(acc >> 48);
+          acc = 0; since = 0;
+        }
       }
-    } else {
+      s4[0] += (uint32_t)acc & 0xFFFFu; s4[1] += (uint32_t)(acc >> 16) & 0xFFFFu;
+      s4[2] += (uint32_t)(acc >> 32) & 0xFFFFu; s4[3] += (uint32_t)(acc >> 48);
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t ix = 4 * gxi + j;
+        if (ix >= nx) break;
+        const uint32_t c = iy * nx + ix, sad = s4[j];  // raster index: ascending with t, then j
+        lds_sads[c] = sad;
+        if (a.top ? (sad <= best_sad) : (sad < best_sad)) {
+          best_sad = sad;
+          best_idx = c;
+        }
+      }
+    }
+  } else {
+    // each lane: candidates lane, lane+gs, ... in raster order
+    for (uint32_t c = lane; c < ncand; c += gs) {
+      const uint32_t iy = c / nx, ix = c - iy * nx;
+      uint32_t sad = 0;
       for (uint32_t r = 0; r < a.bh; ++r)
         for (uint32_t k = 0; k < a.bw; ++k) {
           int d = (int)lds_anchor[r * a.a_pitch + k] - (int)lds_win[(iy + r) * a.w_pitch + ix + k];
           sad += (uint32_t)(d < 0 ? -d : d);
         }
-    }
-    lds_sads[c] = sad;
-    if (a.top ? (sad <= best_sad) : (sad < best_sad)) {
-      best_sad = sad;
-      best_idx = c;
+      lds_sads[c] = sad;
+      if (a.top ? (sad <= best_sad) : (sad < best_sad)) {
+        best_sad = sad;
+        best_idx = c;
+      }
     }
   }
   __syncthreads();
@@ -242,13 +271,15 @@ static int launch_wave_level(const uint8_t* d_tracked, const uint8_t* d_anchor,
   if (items == 0) return SVC_OK;
   if (items > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu work items exceed one launch", (unsigned long long)items);
   a.n_items = (uint32_t)items;
-  a.gs = ncand_max <= 16 ? 16u : ncand_max <= 32 ? 32u : 64u;
+  const bool dw = (bw % 4 == 0) && (fw % 4 == 0) && fw >= 4;
+  // lane tasks per block: candidates, or groups of four candidates on the dword path
+  const uint64_t tasks_max = dw ? (2ull * range + 1) * ((2ull * range + 1 + 3) / 4) : ncand_max;
+  a.gs = tasks_max <= 4 ? 4u : tasks_max <= 8 ? 8u : tasks_max <= 16 ? 16u : tasks_max <= 32 ? 32u : 64u;
   const uint32_t groups = 64u / a.gs;
   a.lds_group = (uint32_t)((lds_bytes + 15u) & ~15ull);
   // small blocks: several rounds per wave, so that a launch is not bound by the workgroup launch rate
   a.rounds = bw * bh <= 16 ? 8u : bw * bh <= 64 ? 4u : 2u;
   const uint64_t grid = (items + (uint64_t)groups * a.rounds - 1) / ((uint64_t)groups * a.rounds);
-  const bool dw = (bw % 4 == 0) && (fw % 4 == 0) && fw >= 4;
   if (dw)
     hipLaunchKernelGGL(hbma_wave_level_kernel<true>, dim3((uint32_t)grid), dim3(64), (size_t)a.lds_group * groups, stream, a);
   else
