@@ -72,6 +72,36 @@ def test_ransac_frames_batched(native, oracle):
         assert np.array_equal(oracle.fg_mask(inl_o, n) == 0, mask[f].cpu().numpy() == 1)
 
 
+@pytest.mark.parametrize("frames,n", [(1, 2048), (3, 2049), (257, 8160), (300, 3600), (259, 8192), (5, 8200), (3, 32768), (2, 33000)])
+@pytest.mark.parametrize("subset", [1, 3])
+def test_ransac_frames_every_launch_shape(native, oracle, frames, n, subset):
+    """Every kernel variant (256 / 1024 lanes, 8 / 16 / 32 blocks per lane, one or two frames per workgroup with an odd
+    frame left over, the L2-walking fallback), frames that take the integer fast path next to frames that need the
+    in-order walk, and frames where no iteration gathers a subset (motion.cpp:240-242)."""
+    rng = np.random.default_rng(frames * 31 + n + subset)
+    p = dict(DEFAULT_RANSAC, subset_sz=subset)
+    k = oracle.ransac_iter_count(**p)
+    check = sorted(set([0, 1, frames // 2, frames - 2, frames - 1]) & set(range(frames)))
+    mv = np.empty((frames, n, 2), np.float32)
+    for f in range(frames):
+        mv[f] = _field(rng, n, 0.05 * (f % 7))
+        if f % 3 == 1:
+            mv[f] += (rng.random((n, 2)) * 0.37).astype(np.float32)       # fractional: the serial sums
+        if f % 5 == 4:
+            mv[f] = (rng.random((n, 2)) * 1e4).astype(np.float32)          # scattered: too few inliers for subset 3
+    samples = np.stack([np.stack([rng.choice(n, subset, replace=False) for _ in range(k)]) for _ in range(frames)]).astype(np.int32)
+    gm_in = rng.integers(-3, 4, (frames, 2)).astype(np.float32)
+    gm, rmse, mask, count = native.ransac_frames(torch.from_numpy(mv).cuda(), torch.from_numpy(samples).cuda(),
+                                                 gm_in=torch.from_numpy(gm_in).cuda(), **p)
+    torch.cuda.synchronize()
+    gm, rmse, mask, count = gm.cpu().numpy(), rmse.cpu().numpy(), mask.cpu().numpy(), count.cpu().numpy()
+    for f in check:
+        gm_o, rmse_o, inl_o = oracle.ransac(mv[f], samples[f].astype(np.uint32), gm_in=tuple(gm_in[f]), **p)
+        assert gm[f].tobytes() == gm_o.tobytes(), f
+        assert rmse[f].tobytes() == rmse_o.tobytes(), f
+        assert np.array_equal(np.flatnonzero(mask[f]), inl_o) and int(count[f]) == len(inl_o), f
+
+
 # the last three are regressions: frames shorter than one 32-row LDS tile (rows beyond the frame
 # must not be reflected twice), found by tests/test_gpu_misc_property.py
 @pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4), (64, 16, 2), (32, 8, 3), (128, 2, 2)])
