@@ -1135,12 +1135,12 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
     SegArgs heavy = a;
     // more than kRegPts points per lane are possible: LDS for the large-frame path
     if (a.n > kRegPts * kTA) heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
-    hipEventRecord(side->fork, stream);
-    hipStreamWaitEvent(side->stream, side->fork, 0);
+    SVC_HIP_TRY(hipEventRecord(side->fork, stream));
+    SVC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
     hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, side->stream, heavy);
-    hipEventRecord(side->join, side->stream);
+    SVC_HIP_TRY(hipEventRecord(side->join, side->stream));
     hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
-    hipStreamWaitEvent(stream, side->join, 0);
+    SVC_HIP_TRY(hipStreamWaitEvent(stream, side->join, 0));
   } else {
     hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
   }
