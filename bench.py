@@ -179,7 +179,8 @@ def main() -> None:
     ap.add_argument("--config", default="C3-1080p-3L-dct8-quant", choices=sorted(configs.ALL))
     ap.add_argument("--frames", type=int, default=0, help="override the clip length (0 = the config's)")
     ap.add_argument("--chunks", type=int, default=1,
-                    help="cut the clip into this many chunks; the transform of chunk k overlaps the front of chunk k+1 on a second stream")
+                    help="experiment kept for the record: cut the clip into this many chunks, the transform of chunk k overlapping the front of "
+                         "chunk k+1 on a second stream -- slower than whole-clip launches (the latency-bound kernels are paid per chunk)")
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
