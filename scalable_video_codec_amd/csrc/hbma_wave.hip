@@ -66,7 +66,9 @@ __device__ __forceinline__ uint64_t group_min_u64(uint64_t v, uint32_t gs) {
   return v;
 }
 
-template <bool DW>
+// NWT: dwords per block row when the block width is 4, 8, 16 or 32 (inner loops unrolled, LDS reads in flight
+// together), 0 = any width.
+template <bool DW, int NWT>
 __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
   const uint32_t gs = a.gs, groups = 64u / gs;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
     // anchor word and 8 window bytes, the SADs at byte offsets 0..3 (16 issue cycles for 16 byte-differences:
     // half of align + v_sad_u8 per candidate, and a quarter of the LDS reads)
     const uint32_t ngx = (nx + 3) >> 2, ntasks = ny * ngx;
-    const uint32_t a_dw = a.a_pitch >> 2, w_dw = a.w_pitch >> 2, nwords = a.bw >> 2;
+    const uint32_t a_dw = a.a_pitch >> 2, w_dw = a.w_pitch >> 2, nwords = NWT ? (uint32_t)NWT : a.bw >> 2;
     const uint32_t* a32 = reinterpret_cast<const uint32_t*>(lds_anchor);
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(lds_win);
     const uint32_t flush_rows = max(1u, 256u / a.bw);  // packed u16 accumulators hold 256 byte-differences
@@ -158,11 +160,21 @@ __global__ __launch_bounds__(64) void hbma_wave_level_kernel(WaveLevelArgs a) {
       uint32_t since = 0;
       for (uint32_t r = 0; r < a.bh; ++r) {
         const uint32_t* wrow = w32 + (iy + r) * w_dw + gxi;
-        uint32_t lo = wrow[0];
-        for (uint32_t k = 0; k < nwords; ++k) {
-          const uint32_t hi = wrow[k + 1];
-          acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)hi << 32) | lo, a32[r * a_dw + k], acc);
-          lo = hi;
+        if constexpr (NWT > 0) {
+          uint32_t wv[NWT + 1], av[NWT > 0 ? NWT : 1];
+#pragma unroll
+          for (int k = 0; k <= NWT; ++k) wv[k] = wrow[k];
+#pragma unroll
+          for (int k = 0; k < NWT; ++k) av[k] = a32[r * a_dw + k];
+#pragma unroll
+          for (int k = 0; k < NWT; ++k) acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)wv[k + 1] << 32) | wv[k], av[k], acc);
+        } else {
+          uint32_t lo = wrow[0];
+          for (uint32_t k = 0; k < nwords; ++k) {
+            const uint32_t hi = wrow[k + 1];
+            acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)hi << 32) | lo, a32[r * a_dw + k], acc);
+            lo = hi;
+          }
         }
         if (++since == flush_rows) {
           s4[0] += (uint32_t)acc & 0xFFFFu; s4[1] += (uint32_t)(acc >> 16) & 0xFFFFu;
@@ -280,10 +292,14 @@ static int launch_wave_level(const uint8_t* d_tracked, const uint8_t* d_anchor,
   // small blocks: several rounds per wave, so that a launch is not bound by the workgroup launch rate
   a.rounds = bw * bh <= 16 ? 8u : bw * bh <= 64 ? 4u : 2u;
   const uint64_t grid = (items + (uint64_t)groups * a.rounds - 1) / ((uint64_t)groups * a.rounds);
-  if (dw)
-    hipLaunchKernelGGL(hbma_wave_level_kernel<true>, dim3((uint32_t)grid), dim3(64), (size_t)a.lds_group * groups, stream, a);
-  else
-    hipLaunchKernelGGL(hbma_wave_level_kernel<false>, dim3((uint32_t)grid), dim3(64), (size_t)a.lds_group * groups, stream, a);
+  const dim3 g((uint32_t)grid), b(64);
+  const size_t lds_total = (size_t)a.lds_group * groups;
+  if (!dw) hipLaunchKernelGGL((hbma_wave_level_kernel<false, 0>), g, b, lds_total, stream, a);
+  else if (bw == 4) hipLaunchKernelGGL((hbma_wave_level_kernel<true, 1>), g, b, lds_total, stream, a);
+  else if (bw == 8) hipLaunchKernelGGL((hbma_wave_level_kernel<true, 2>), g, b, lds_total, stream, a);
+  else if (bw == 16) hipLaunchKernelGGL((hbma_wave_level_kernel<true, 4>), g, b, lds_total, stream, a);
+  else if (bw == 32) hipLaunchKernelGGL((hbma_wave_level_kernel<true, 8>), g, b, lds_total, stream, a);
+  else hipLaunchKernelGGL((hbma_wave_level_kernel<true, 0>), g, b, lds_total, stream, a);
   return check_launch("hbma_wave_level_kernel");
 }
 
