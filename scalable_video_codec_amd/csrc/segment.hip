@@ -340,7 +340,8 @@ __device__ __forceinline__ void lloyd_quad(const uint32_t (&v)[4], const bool (&
       double da = ax * ax;
       da = da + ay * ay;
       da = da + az * az;
-      if (da < best[u]) { best[u] = da; bj[u] = j; }
+      bj[u] = da < best[u] ? j : bj[u];        // strict <: the lowest index keeps a tie
+      best[u] = __builtin_fmin(best[u], da);  // one v_min_f64 instead of two selects (no NaNs here)
     }
   }
 #pragma unroll
