@@ -3,17 +3,22 @@
 headline workload: 1080p (padded 1920x1088), 300-frame synthetic clip, 16x16 MV
 blocks, 3-level HBMA + RANSAC + 8x8 DCT + quant (fg 1 / bg 640).
 
-One "step" = one pass of the hot path over the whole clip resident in HBM:
-  luma + pyramid (all frames) -> [N>1: halo exchange of the previous rank's last
-  pyramid, RCCL send/recv] -> fused HBMA (all frame pairs) -> RANSAC (per frame) ->
-  segmentation (mask, close/open, k-means, connected components -> region ids) ->
-  fused DCT + quant (per encoded frame).
-`value` = encoded frames of all ranks / max-over-ranks time, BGR frames already
-resident in HBM when the timed region starts (PCIe excluded).
+One "step" = one pass of the hot path over this rank's shard of the clip, resident in HBM:
+  luma + pyramid (all frames) -> [N>1: halo shift of the previous rank's last pyramid, RCCL
+  send/recv on its own stream] -> fused HBMA (all frame pairs) -> RANSAC (per frame) ->
+  segmentation (mask, close/open, k-means, connected components -> region ids) -> fused DCT +
+  quant (per encoded frame).
+The driver of a step is C++ (svc::ClipEncoder, include/svc/clip_encoder.hpp) behind the C handle
+API of include/svc_clip.h; this file loads frames, calls step() and reports.
 
-Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 the driver
-launches it under torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints
-ONE JSON line.
+N GPUs (BASELINE configs 4/5): the SAME clip is cut into N consecutive chunks, one per rank
+("scaling": "strong": 300 frames -> 37/38 per GPU at N = 8); the weak-scaling figure (300 frames per
+GPU) is measured after it and reported under "weak".  `value` = encoded frames of all ranks /
+max-over-ranks time, BGR frames already resident in HBM when the timed region starts (PCIe
+excluded).
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 the driver launches it under
+torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -30,6 +35,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+from scalable_video_codec_amd import clip as clipmod  # noqa: E402
 from scalable_video_codec_amd import configs, native, pipeline, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -134,6 +140,8 @@ def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 12.0):
                    f", RANSAC/segmentation/DCT(f64 separable)/quant = C restatement (cv::dct is not buildable offline)"),
         "hbma_ms_per_frame": t_hbma / done * 1e3 if done else None,
         "ransac_dct_quant_ms_per_frame": t_rest / done * 1e3 if done else None,
+        "dct_leg": "own f64 separable DCT-II (C restatement), not cv::dct: OpenCV is not installed, the reference's transform cannot be timed",
+        "dct_is_reference": False,
         "reference_sse2_4level_hbma_ms_per_frame": sse2_ms,
         "all_cores": all_cores,
     }
@@ -171,22 +179,137 @@ def hbm_streaming_rates(device) -> dict:
     return out
 
 
+
+
+class _DevMem:
+    """A raw device range as a __cuda_array_interface__ object (zero-copy torch view of a C++-owned buffer)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _torch_halo_transport(rank: int, world: int, staged: bool):
+    """The neighbour shift through torch.distributed P2P (RCCL under backend "nccl"; `staged` = gloo rehearsal,
+    through host memory).  Alternative to the C ABI's own RCCL entry point (SVC_HALO=torch)."""
+    def fn(send_ptr, recv_ptr, nbytes, stream_ptr):
+        stream = torch.cuda.ExternalStream(stream_ptr)
+        with torch.cuda.stream(stream):
+            send = torch.as_tensor(_DevMem(send_ptr, nbytes), device="cuda")
+            recv = torch.as_tensor(_DevMem(recv_ptr, nbytes), device="cuda")
+            if staged:
+                stream.synchronize()
+                send_h, recv_h = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
+            ops = []
+            if rank + 1 < world:
+                ops.append(dist.P2POp(dist.isend, send_h if staged else send, rank + 1))
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, recv_h if staged else recv, rank - 1))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()  # nccl: orders the stream behind the transfer, does not block the host
+            if staged and rank > 0:
+                recv.copy_(recv_h)
+                stream.synchronize()
+    return fn
+
+
+def _checksum(x: torch.Tensor) -> int:
+    w = (torch.arange(x.numel(), device=x.device, dtype=torch.int64) % 251) + 1
+    return int((x.to(torch.int64) * w).sum().item())
+
+
+def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, comm):
+    """Builds this rank's shard for `mode` ("strong": cfg.frames cut over the ranks; "weak": cfg.frames per rank),
+    runs W warm-up and exactly K timed steps between barriers, returns the measurements of this rank."""
+    n_cfg = args.frames or cfg.frames
+    clip_frames = n_cfg if mode == "strong" else n_cfg * world
+    schedule = clipmod.SERIAL if args.schedule == "serial" else clipmod.PIPELINED
+    enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule, graph=args.graph,
+                       segmentation=not args.no_segmentation, wire=args.wire)
+    info = enc.info
+    src = synth.SynthClip(cfg.width, cfg.height, clip_frames, cfg.seed, device=dev)
+    pw, ph = cfg.padded
+    for j in range(info.frames):
+        enc.load_frames(synth.pad_frame(src.frame_bgr(info.first_frame + j), pw, ph).unsqueeze(0).contiguous(), j)
+    sample_frames = [synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(min(info.frames, 129))] \
+        if (rank == 0 and mode == "strong" and world == 1 and not args.no_cpu_baseline) else None
+    del src
+    halo = None
+    if world > 1:
+        if comm is not None:
+            enc.set_comm(comm)
+            halo = "svc_hip_halo_shift (RCCL send/recv, C ABI)"
+        else:
+            enc.set_halo_transport(_torch_halo_transport(rank, world, staged=backend != "nccl"))
+            halo = f"torch.distributed P2P ({'RCCL' if backend == 'nccl' else backend + ', staged through host memory'})"
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1 if world > 1 else 0)):
+        enc.step()
+    enc.sync()
+    if world > 1:
+        # the halo that arrived must be the predecessor's last pyramid: checked once, outside the timed region
+        pyr = enc.read("pyramids", device=dev)
+        stride = info.pyramid_stride
+        mine = torch.tensor([_checksum(pyr[info.frames * stride:(info.frames + 1) * stride])], dtype=torch.int64,
+                            device=dev if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if rank > 0 and _checksum(pyr[:stride]) != int(every[rank - 1].item()):
+            raise SystemExit(f"rank {rank}: the halo received is not rank {rank - 1}'s last pyramid")
+        del pyr
+    barrier()
+    enc.reset_timers()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.step(timed=not args.graph)
+    enc.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    encoded = torch.tensor([float(info.pairs)], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(encoded, op=dist.ReduceOp.SUM)
+    st = enc.stage_times_ms()
+    res = {
+        "elapsed": float(t.item()), "encoded_per_step": float(encoded.item()), "info": info, "halo": halo,
+        "stage_ms_per_step": {k: v[0] / args.steps for k, v in st.items()},
+        "launches_per_step": {k: v[1] / args.steps for k, v in st.items()},
+        "sample_frames": sample_frames, "clip_frames": clip_frames,
+    }
+    enc.close()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3-1080p-3L-dct8-quant", choices=sorted(configs.ALL))
     ap.add_argument("--frames", type=int, default=0, help="override the clip length (0 = the config's)")
-    ap.add_argument("--chunks", type=int, default=1,
-                    help="experiment kept for the record: cut the clip into this many chunks, the transform of chunk k overlapping the front of "
-                         "chunk k+1 on a second stream -- slower than whole-clip launches (the latency-bound kernels are paid per chunk)")
+    ap.add_argument("--schedule", choices=("pipelined", "serial"), default="pipelined",
+                    help="pipelined: software pipeline over consecutive steps (HBM-bound kernels back to back on one stream, RANSAC + "
+                         "segmentation of the previous step beside them, halo in flight meanwhile); serial: one stream, stages back to back")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the steady-state iteration from a captured hipGraph (no per-kernel events, so no roofline object)")
+    ap.add_argument("--scaling", choices=("both", "strong", "weak"), default="both",
+                    help="N > 1: which shardings to measure (default: strong = the BASELINE config 4/5 workload, then weak)")
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
-    ap.add_argument("--overlap", action="store_true",
-                    help="software-pipeline consecutive passes on two streams (back end of pass s beside the front end of pass s+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -202,141 +325,123 @@ def main() -> None:
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     native.load()
+    clipmod.load()
     torch.set_num_threads(min(8, torch.get_num_threads()))  # CPU share of a 1-GPU box is small
+    if world > 1 and backend == "nccl" and os.environ.get("SVC_HALO", "rccl") == "rccl":
+        # the C ABI's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
+        box = [clipmod.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=dev)
+        comm = clipmod.comm_create(box[0], rank, world)
 
     cfg = configs.ALL[args.config]
-    n_frames = args.frames or cfg.frames
-    dev = torch.device("cuda", local_rank)
-
-    # this rank's slice of a (world * n_frames)-frame clip: one generator, offset frames
-    clip = synth.SynthClip(cfg.width, cfg.height, world * n_frames, cfg.seed, device=dev)
-    pw, ph = cfg.padded
-    frames = [synth.pad_frame(clip.frame_bgr(rank * n_frames + t), pw, ph) for t in range(n_frames)]
-    enc = pipeline.ClipEncoder(cfg, n_frames, dev, rank=rank, world=world, segmentation=not args.no_segmentation,
-                               wire=args.wire)
-    enc.load_frames(frames)
-    del clip
-    torch.cuda.synchronize()
-
-    def one_step(timed=False):
-        if args.overlap:
-            enc.step_overlapped(timed=timed)
-        else:
-            enc.step(timed=timed, chunks=args.chunks)
-
-    for _ in range(args.warmup):
-        one_step()
-    enc.finish_overlapped()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    enc.reset_kernel_timers()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(timed=True)
-    enc.finish_overlapped()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    encoded = torch.tensor([enc.encoded_per_step], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(encoded, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_encoded = float(encoded.item())
+    modes = ["strong"] if world == 1 else (["strong", "weak"] if args.scaling == "both" else [args.scaling])
+    results = {m: run_mode(args, cfg, m, rank, world, dev, backend, comm) for m in modes}
 
     if rank == 0:
-        kt = enc.kernel_times_ms()  # per-launch averages from HIP events on the launch stream
-        hbma_bytes = cfg.hbma_bytes_per_frame() * enc.pairs_per_step
-        dct_bytes = cfg.dct_bytes_per_frame() * enc.encoded_per_step
-        hbma_gbps = hbma_bytes / (kt["hbma"] * 1e-3) / 1e9
-        has_dct = "dct_quant" in kt
-        dct_gbps = dct_bytes / (kt["dct_quant"] * 1e-3) / 1e9 if has_dct else None
-        nl = enc.launches_per_step()  # launches per step of each stage (= --chunks)
-        pmc = pipeline.load_pmc_traffic()
-
-        def per_launch_traffic(key, stage):
-            # PMC traffic was recorded for whole-clip launches; a chunked launch moves 1/chunks of it
-            v = pmc.get(key)
-            return v / nl[stage] if v is not None else None
+        main_mode = modes[0]
+        r = results[main_mode]
+        info = r["info"]
+        pw, ph = cfg.padded
+        kt, nl = r["stage_ms_per_step"], r["launches_per_step"]
+        elapsed = r["elapsed"]
         out = {
             "metric": "encoded frames/sec (1080p, 16x16 HBMA+DCT)" if cfg.name.startswith("C3") else
                       f"encoded frames/sec ({cfg.name})",
-            "value": total_encoded * args.steps / elapsed,
+            "value": r["encoded_per_step"] * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": main_mode if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u8 (SAD, integer argmin) / f64 accumulate -> f32 (DCT, quant)",
             "data": "synthetic",
             "config": {
-                "workload": cfg.name,
+                "workload": cfg.name + (" (BASELINE config 4: the 300-frame clip cut over the ranks)" if world > 1 and main_mode == "strong" and cfg.name.startswith("C3-") else ""),
                 "frame": f"{cfg.width}x{cfg.height} -> padded {pw}x{ph}",
-                "frames_per_gpu": n_frames,
-                "encoded_frames_per_step": total_encoded,
+                "clip_frames": r["clip_frames"],
+                "frames_per_gpu": info.frames if world == 1 else [clipmod.plan_shard(r["clip_frames"], world, q)[1] for q in range(world)],
+                "encoded_frames_per_step": r["encoded_per_step"],
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
-                "chunks_per_step": args.chunks,
-                "schedule": "two-stream software pipeline across passes" if args.overlap else "one stream, passes back to back",
-                "parallelism": f"frame-sharded x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} halo (1 pyramid/rank/step)" if world > 1 else ""),
+                "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-3) back to back on one stream; "
+                             "RANSAC+segmentation(s-2) beside them on a second; halo(s) on a third" if args.schedule == "pipelined"
+                             else "one stream, stages back to back") + ("; steady-state iteration replayed from a hipGraph" if args.graph else ""),
+                "driver": "svc::ClipEncoder (C++, include/svc/clip_encoder.hpp)",
+                "parallelism": f"frame-sharded x{world}" + (f", halo = 1 pyramid/rank/step via {r['halo']}" if world > 1 else ""),
             },
-            "roofline": {
-                "kernel": "hbma_fused16_kernel (MAD search, all pyramid levels)",
-                "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": hbma_gbps / HBM_PEAK_GBPS,
-                "traffic": per_launch_traffic("hbma_bytes_per_launch", "hbma") if cfg.name.startswith("C3-") else None,
-                "algorithmic_bytes_per_launch": hbma_bytes / nl["hbma"],
-                "avg_launch_ms": kt["hbma"] / nl["hbma"],
-                "launches_per_step": nl["hbma"],
-                "note": "HBM is the stated bound; measured VALU busy ~86 % (byte-SAD ops issue at 4 cycles/wave): "
-                        "VALU time ~= HBM floor, see DESIGN.md 4.1",
-            },
-            "roofline_dct": {
-                "kernel": f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)",
-                "bound": "hbm", "achieved": dct_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": dct_gbps / HBM_PEAK_GBPS,
-                "traffic": per_launch_traffic("dct_bytes_per_launch", "dct_quant") if cfg.name.startswith("C3-") else None,
-                "algorithmic_bytes_per_launch": dct_bytes / nl["dct_quant"],
-                "avg_launch_ms": kt["dct_quant"] / nl["dct_quant"],
-                "launches_per_step": nl["dct_quant"],
-            } if has_dct else None,
             "kernel_ms_per_step": kt,
         }
-        if not has_dct:
-            out.pop("roofline_dct")
-        if "hbma_wave" in (enc.hbma_kernel_name or ""):
-            out["roofline"]["kernel"] = "hbma_wave_level_kernel (LDS-staged wave-per-block search)"
-        if world == 1:
-            # context for the roofline fractions: what plain streaming kernels get from this box's HBM
-            rates = hbm_streaming_rates(dev)
-            out["hbm_streaming_measured"] = {"unit": "GB/s", **rates,
-                                             "note": "svc_hip_probe_stream on this GPU; the MAD kernel is read-only, luma+pyramid 3:1, DCT+quant 1:4"}
-            out["roofline"]["frac_of_streaming_read_rate"] = hbma_gbps / rates["read_only"]
-            if has_dct:
-                out["roofline_dct"]["frac_of_streaming_fill_rate"] = dct_gbps / rates["write_only_torch_fill"]
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(cfg, frames)
-            if out["cpu_baseline"]["value"]:
-                out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        if world > 1:
+            out["halo_exchange_ms"] = kt.get("halo_exchange")
+            out["rank0_kernel_ms_per_step"] = kt
+        if "weak" in results and main_mode != "weak":
+            w = results["weak"]
+            out["weak"] = {"value": w["encoded_per_step"] * args.steps / w["elapsed"], "unit": "frames/s",
+                           "ms_per_step": w["elapsed"] / args.steps * 1e3, "clip_frames": w["clip_frames"],
+                           "frames_per_gpu": w["info"].frames, "encoded_frames_per_step": w["encoded_per_step"],
+                           "rank0_kernel_ms_per_step": w["stage_ms_per_step"]}
+        if "hbma" in kt:
+            pmc = pipeline.load_pmc_traffic().get(cfg.name, {})
+
+            def traffic(key, pairs):  # offline PMC, recorded for a whole-clip launch: scaled to this launch's pairs
+                v, base = pmc.get(key), pmc.get("pairs")
+                return v * pairs / base if v is not None and base else None
+            hbma_bytes = cfg.hbma_bytes_per_frame() * info.pairs
+            hbma_ms = kt["hbma"] / nl["hbma"]
+            hbma_gbps = hbma_bytes / (hbma_ms * 1e-3) / 1e9
+            fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2)
+            out["roofline"] = {
+                "kernel": "hbma_fused16_kernel (MAD search, all pyramid levels)" if fused else
+                          "hbma_wave_level_kernel (LDS-staged wave-per-block search)",
+                "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": hbma_gbps / HBM_PEAK_GBPS,
+                "traffic": traffic("hbma_bytes_per_launch", info.pairs),
+                "traffic_source": (f"offline PMC ({pmc.get('source')}), scaled from {pmc.get('pairs')} to {info.pairs} frame pairs; not measured in this run"
+                                   if pmc else None),
+                "algorithmic_bytes_per_launch": hbma_bytes,
+                "avg_launch_ms": hbma_ms,
+                "launches_per_step": nl["hbma"],
+                "note": "HBM is the stated bound; measured VALU busy ~86 % (byte-SAD ops issue at 4 cycles/wave): VALU time ~= HBM floor, DESIGN.md 4.1"
+                        + ("; timed beside the previous step's RANSAC + segmentation kernels (pipelined schedule)" if args.schedule == "pipelined" else ""),
+            }
+            if "dct_quant" in kt:
+                dct_bytes = cfg.dct_bytes_per_frame() * info.pairs
+                dct_ms = kt["dct_quant"] / nl["dct_quant"]
+                dct_gbps = dct_bytes / (dct_ms * 1e-3) / 1e9
+                out["roofline_dct"] = {
+                    "kernel": f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)",
+                    "bound": "hbm", "achieved": dct_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": dct_gbps / HBM_PEAK_GBPS,
+                    "traffic": traffic("dct_bytes_per_launch", info.pairs),
+                    "traffic_source": out["roofline"]["traffic_source"],
+                    "algorithmic_bytes_per_launch": dct_bytes, "avg_launch_ms": dct_ms, "launches_per_step": nl["dct_quant"],
+                }
+        if world == 1 and not args.no_hbm_probe:
+            # context only: what plain streaming kernels get from this box's HBM (not a ceiling: the DCT kernel beats the 1:4 probe)
+            out["hbm_streaming_measured"] = {"unit": "GB/s", **hbm_streaming_rates(dev),
+                                             "note": "svc_hip_probe_stream on this GPU, context only; roofline fractions are against the 8 TB/s peak"}
+        if r["sample_frames"] is not None:
+            out["cpu_baseline"] = cpu_baseline(cfg, r["sample_frames"])
+            cb = out["cpu_baseline"]
+            if cb.get("hbma_ms_per_frame") and "hbma" in kt:
+                # the one like-for-like ratio: the unmodified reference's motion search vs the MAD kernel, per frame pair
+                out["speedup_hbma_vs_cpu_1core"] = cb["hbma_ms_per_frame"] / (kt["hbma"] / info.pairs)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        clipmod.comm_destroy(comm)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,120 @@
+// clip_encoder.hpp -- the hot path for one rank's shard of a clip that is RESIDENT IN HBM: the
+// C++ driver behind bench.py and the multi-GPU form of the path (BASELINE
+// configs 3-5).
+//
+// What one step runs is the middle of Encoder::operator() (reference libs/encoder.cpp:453-664)
+// over every frame of the shard at once: luma + pyramid, EstimateMotionHierarchical,
+// EstimateGlobalMotionRansac, the segmentation glue -> region ids, Dct + the decoder's quant
+// lines -- every stage a call into the C ABI of include/svc_hip.h, nothing computed here.
+//
+// Sharding.  The reference's only cross-frame state is the previous SOURCE frame's Y pyramid
+// (libs/encoder.cpp:661-663), so a clip is cut into `world` consecutive chunks (PlanShard) and
+// rank r needs one thing from rank r - 1: the pyramid of the frame just before its chunk.  That
+// halo is shifted rank r -> r + 1 once per step with RCCL send/recv (svc_hip_halo_shift) on a
+// communication stream of its own.  RANSAC draws and k-means seeds are a function of (seed, clip
+// frame index) only, so a sharded clip encodes to exactly the bytes of the unsharded one.
+//
+// Schedule.  kSerial runs a step's stages back to back on one stream.  kPipelined is a software
+// pipeline over consecutive steps, as a streaming encoder runs consecutive chunks: per call of
+// Step() the main stream carries luma+pyramid of the newest step, the motion search of the one
+// before and the transform of the step three back -- the HBM-bound kernels, back to back -- while
+// a second stream carries RANSAC + segmentation (latency-bound: one workgroup per frame) of the
+// step two back beside them, and the halo of the newest step crosses xGMI meanwhile.  Small
+// per-frame outputs are double-buffered; Flush() drains the pipeline.
+#ifndef SVC_CLIP_ENCODER_HPP
+#define SVC_CLIP_ENCODER_HPP
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+
+#include "svc_hip.h"
+
+namespace svc {
+
+struct Shard {
+  uint32_t first_frame = 0;  // clip index of the shard's first source frame
+  uint32_t frames = 0;       // source frames held by the rank
+  bool needs_halo = false;   // first_frame > 0: the pyramid of frame first_frame - 1 comes from rank - 1
+  uint32_t pairs = 0;        // encoded frames = frame pairs of the rank (clip frame 0 is tracked-only,
+                             // libs/encoder.cpp:361-367)
+  uint32_t first_encoded = 0;  // clip index of the first encoded frame
+};
+
+// Consecutive chunks, the first (clip_frames % world) ranks one frame longer.
+Shard PlanShard(uint32_t clip_frames, uint32_t world, uint32_t rank);
+
+enum class Schedule : uint32_t { kSerial = 0, kPipelined = 1 };
+
+struct ClipEncoderConfig {
+  uint32_t width = 0, height = 0;  // source frame size; padded as libs/encoder.cpp:164-168 does
+  uint32_t levels = 3;             // pyr-lvl-count
+  uint32_t mv_block = 16;          // apps/encoder.cpp:28-58 defaults from here on
+  uint32_t search_range = 8;
+  uint32_t dct_block_w = 8, dct_block_h = 8;  // transform block; 0 = no transform
+  uint32_t fg_step = 1, bg_step = 640;        // apps/decoder.cpp:22-23
+  bool wire = false;          // serialised records (libs/encoder.cpp:222-269) instead of planes
+  bool segmentation = true;   // false: region ids from the in-repo part only (foreground = one region)
+  uint64_t seed = 0;
+  svc_ransac_params ransac{1, 7.5f, 0.99f, 0.5f};
+  svc_segment_params segment{3, 3, 10, 3, 10, 1.0f, 4};
+  uint32_t clip_frames = 0;   // frames of the WHOLE clip
+  uint32_t rank = 0, world = 1;
+  Schedule schedule = Schedule::kPipelined;
+  bool graph = false;         // replay the steady-state iteration from a captured hipGraph
+};
+
+enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kCount };
+enum class Buffer : uint32_t { kMv = 0, kMinMad, kGlobalMotion, kRmse, kInlierMask, kInlierCount, kBlockTypes,
+                               kCoeffs, kRecords, kPyramids, kBgr, kCount };
+
+class ClipEncoder {
+ public:
+  // The halo transport: called with the communication stream once per step; must enqueue, on
+  // that stream, the send of `bytes` from d_send to rank + 1 (if any) and the receive into d_recv
+  // from rank - 1 (if any).  Default: svc_hip_halo_shift on the communicator given to SetComm().
+  using HaloFn = std::function<void(const uint8_t* d_send, uint8_t* d_recv, uint64_t bytes, void* stream)>;
+
+  // Allocates every buffer on the current device; throws std::runtime_error on failure.
+  explicit ClipEncoder(const ClipEncoderConfig& config);
+  ~ClipEncoder();
+  ClipEncoder(const ClipEncoder&) = delete;
+  ClipEncoder& operator=(const ClipEncoder&) = delete;
+
+  const Shard& shard() const;
+  uint32_t padded_width() const;
+  uint32_t padded_height() const;
+  uint32_t blocks() const;
+  uint64_t pyramid_stride() const;
+
+  // Copies `n` PADDED B,G,R u8 frames (padded_height x padded_width x 3) into shard slots
+  // [first_local, first_local + n); synchronous.
+  void LoadFrames(const uint8_t* src, uint32_t first_local, uint32_t n, bool src_on_device);
+
+  void SetComm(void* nccl_comm);  // an ncclComm_t of `world` ranks (svc_hip_comm_create)
+  void SetHaloTransport(HaloFn fn);
+
+  // Enqueues one step (a pass over the whole shard); returns without waiting for the GPU.
+  // timed: HIP events around every stage this call enqueues, on the stream it is launched on (in
+  // the pipelined schedule those are stages of up to four different steps; Flush() keeps timing
+  // what it drains, so K timed steps from an empty pipeline time every stage exactly K times).
+  void Step(bool timed = false);
+  void Flush();  // pipelined schedule: enqueues what is left of the steps in flight
+  void Sync();   // Flush() + waits for every stream
+
+  // Sum over timed steps of a stage's event time / number of launches timed; Sync()s first.
+  void StageTime(Stage s, double* total_ms, uint32_t* launches);
+  void ResetTimers();
+  uint32_t steps_submitted() const;
+
+  // Device pointer + size of the NEWEST finished step's output; Sync()s first.
+  void* Output(Buffer b, uint64_t* bytes);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> p_;
+};
+
+}  // namespace svc
+
+#endif  // SVC_CLIP_ENCODER_HPP

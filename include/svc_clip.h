@@ -1,0 +1,98 @@
+/*
+ * svc_clip.h -- C handle API over svc::ClipEncoder (include/svc/clip_encoder.hpp): the driver of
+ * one rank's shard of an HBM-resident clip.  This is what bench.py and the Python harness bind
+ * with ctypes; a C++ host uses the class directly.  Built into libsvc_motion.so.
+ *
+ * The stages a step runs are the reference's per-frame loop, libs/encoder.cpp:453-664, batched
+ * over the shard: luma + pyramid (:468-470), EstimateMotionHierarchical (:472-482),
+ * EstimateGlobalMotionRansac (:491-498), segmentation glue -> region ids (:507-623), Dct (:638-640)
+ * + the decoder's quant lines (libs/decoder.cpp:130-144) -- each a call into include/svc_hip.h.
+ *
+ * Every function returns 0 on success; svc_clip_last_error() has the calling thread's last message.
+ */
+#ifndef SVC_CLIP_H
+#define SVC_CLIP_H
+
+#include <stdint.h>
+
+#include "svc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svc_clip svc_clip;
+
+#define SVC_CLIP_SERIAL 0u    /* a step's stages back to back on one stream */
+#define SVC_CLIP_PIPELINED 1u /* software pipeline over consecutive steps, see clip_encoder.hpp */
+
+typedef struct svc_clip_config {
+  uint32_t width, height; /* source size (padded per libs/encoder.cpp:164-168) */
+  uint32_t levels, mv_block, search_range;
+  uint32_t dct_block_w, dct_block_h; /* 0 = no transform */
+  uint32_t fg_step, bg_step;
+  uint32_t wire;         /* 1: serialised records (libs/encoder.cpp:222-269) instead of planes */
+  uint32_t segmentation; /* 0: in-repo part only (foreground = one region) */
+  uint64_t seed;
+  svc_ransac_params ransac;
+  svc_segment_params segment;
+  uint32_t clip_frames; /* frames of the whole clip */
+  uint32_t rank, world; /* this handle holds shard `rank` of `world` */
+  uint32_t schedule;    /* SVC_CLIP_SERIAL / SVC_CLIP_PIPELINED */
+  uint32_t graph;       /* 1: replay the steady-state iteration from a captured hipGraph */
+} svc_clip_config;
+
+typedef struct svc_clip_info {
+  uint32_t padded_w, padded_h, mv_field_w, mv_field_h, blocks, ransac_iters;
+  uint64_t pyramid_stride, frame_bytes, record_bytes;
+  uint32_t first_frame, frames, pairs, first_encoded, needs_halo;
+} svc_clip_info;
+
+/* stage ids for svc_clip_stage_time */
+enum { SVC_STAGE_LUMA_PYRAMID = 0, SVC_STAGE_HALO, SVC_STAGE_HBMA, SVC_STAGE_RANSAC, SVC_STAGE_SEGMENT,
+       SVC_STAGE_TRANSFORM, SVC_STAGE_COUNT };
+/* buffer ids for svc_clip_output / svc_clip_read */
+enum { SVC_BUF_MV = 0, SVC_BUF_MIN_MAD, SVC_BUF_GLOBAL_MOTION, SVC_BUF_RMSE, SVC_BUF_INLIER_MASK,
+       SVC_BUF_INLIER_COUNT, SVC_BUF_BLOCK_TYPES, SVC_BUF_COEFFS, SVC_BUF_RECORDS, SVC_BUF_PYRAMIDS,
+       SVC_BUF_BGR, SVC_BUF_COUNT };
+
+/* Halo transport override: must enqueue on `stream` the send of `bytes` from d_send to rank + 1
+ * (if any) and the receive into d_recv from rank - 1 (if any). */
+typedef int (*svc_clip_halo_fn)(const uint8_t* d_send, uint8_t* d_recv, uint64_t bytes, void* stream,
+                                void* user);
+
+const char* svc_clip_last_error(void);
+
+/* Consecutive chunks; the first (clip_frames % world) ranks hold one frame more. */
+int svc_clip_plan_shard(uint32_t clip_frames, uint32_t world, uint32_t rank, uint32_t* first_frame,
+                        uint32_t* frames, uint32_t* pairs, uint32_t* first_encoded);
+
+int svc_clip_create(const svc_clip_config* config, svc_clip** out);
+void svc_clip_destroy(svc_clip* clip);
+int svc_clip_get_info(svc_clip* clip, svc_clip_info* out);
+
+/* n PADDED B,G,R u8 frames into shard slots [first_local, first_local + n); synchronous. */
+int svc_clip_load_frames(svc_clip* clip, const uint8_t* src, uint32_t first_local, uint32_t n,
+                         int src_on_device);
+
+int svc_clip_set_comm(svc_clip* clip, void* nccl_comm); /* from svc_hip_comm_create */
+int svc_clip_set_halo_callback(svc_clip* clip, svc_clip_halo_fn fn, void* user);
+
+int svc_clip_step(svc_clip* clip, int timed); /* enqueue one pass over the shard */
+int svc_clip_flush(svc_clip* clip);           /* enqueue what the pipeline still holds */
+int svc_clip_sync(svc_clip* clip);            /* flush + wait for the GPU */
+
+/* HIP-event time of a stage summed over the timed steps, and the launches it covers. */
+int svc_clip_stage_time(svc_clip* clip, uint32_t stage, double* total_ms, uint32_t* launches);
+int svc_clip_reset_timers(svc_clip* clip);
+
+/* The newest finished step's output (syncs first). */
+int svc_clip_output(svc_clip* clip, uint32_t buffer, void** d_ptr, uint64_t* bytes);
+int svc_clip_read(svc_clip* clip, uint32_t buffer, uint64_t offset, void* dst, uint64_t bytes,
+                  int dst_on_device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SVC_CLIP_H */

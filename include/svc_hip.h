@@ -278,6 +278,31 @@ int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_byte
                                 void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Multi-GPU: frames shard as consecutive chunks, one per rank, and the only
+ * cross-rank dependency is the reference's only cross-frame state -- the previous SOURCE
+ * frame's Y pyramid (libs/encoder.cpp:661-663).  Rank r therefore sends the packed pyramid of
+ * its last frame to rank r + 1 and receives its predecessor's: one RCCL send/recv pair per
+ * rank and step over one xGMI link per direction, no other collective anywhere on the path.
+ * RCCL is bound at run time (librccl.so.1, the copy already in the process if there is one);
+ * without it these return SVC_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------- */
+#define SVC_COMM_ID_BYTES 128u /* sizeof(ncclUniqueId) */
+#define SVC_SHIFT_CYCLIC 1u    /* the last rank also sends to rank 0 (frame-per-GPU round robin) */
+
+/* ncclGetUniqueId: call on one rank, hand the bytes to all of them out of band. */
+int svc_hip_comm_unique_id(uint8_t id[SVC_COMM_ID_BYTES]);
+/* ncclCommInitRank on the calling thread's current device; *comm is an ncclComm_t. */
+int svc_hip_comm_create(const uint8_t id[SVC_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+                        void** comm);
+int svc_hip_comm_destroy(void* comm);
+
+/* The halo shift: enqueues on `stream`, as ONE RCCL group, the send of `bytes` from d_send to
+ * rank + 1 (if there is one) and the receive of `bytes` into d_recv from rank - 1 (if there is
+ * one).  comm: an ncclComm_t of `world` ranks in which the caller is `rank`.  Only enqueues. */
+int svc_hip_halo_shift(void* comm, const uint8_t* d_send, uint8_t* d_recv, uint64_t bytes,
+                       uint32_t rank, uint32_t world, uint32_t flags, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Host-pointer forms: what the C++ wrappers of include/svc/motion.hpp call.  They
  * stage through pinned buffers owned by the library, run the device entry point
  * on an internal stream and synchronise before returning (the reference's calls

@@ -23,7 +23,7 @@ OBJ = os.path.join(PKG, "_obj")
 LIB_HIP = os.path.join(PKG, "libsvc_hip.so")
 LIB_MOTION = os.path.join(PKG, "libsvc_motion.so")
 
-HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip"]
+HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip"]
 HOST_SOURCES = [os.path.join("host", "motion_hip.cpp")]
 
 # -ffp-contract=off: the reference's float expressions (RANSAC inlier test, quant) are
@@ -74,21 +74,25 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 
 STREAM_SRC = os.path.join(CSRC, "host", "stream_encoder.cpp")
+CLIP_SRC = os.path.join(CSRC, "host", "clip_encoder.cpp")
 
 
 def build_motion(force: bool = False) -> str:
     """The C++ layer above the C ABI: the reference's motion.hpp entry points (plain C++, g++) and the
     batched host-memory encoder (uses the HIP runtime for buffers, streams and events: hipcc, host only)."""
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
-    deps = srcs + [STREAM_SRC, os.path.join(INCLUDE, "svc_hip.h")] + \
-        [os.path.join(INCLUDE, "svc", h) for h in ("motion.hpp", "math.hpp", "types.hpp", "stream_encoder.hpp")]
+    deps = srcs + [STREAM_SRC, CLIP_SRC, os.path.join(INCLUDE, "svc_hip.h"), os.path.join(INCLUDE, "svc_clip.h")] + \
+        [os.path.join(INCLUDE, "svc", h) for h in ("motion.hpp", "math.hpp", "types.hpp", "stream_encoder.hpp",
+                                                    "clip_encoder.hpp")]
     if force or not _newer(LIB_MOTION, deps + [LIB_HIP]):
         cxx = shutil.which("g++") or "g++"
         stream_obj = os.path.join(OBJ, "stream_encoder.o")
+        clip_obj = os.path.join(OBJ, "clip_encoder.o")
         _run([_hipcc(), "-std=c++17", "-O2", "-fPIC", "-Wall", f"-I{INCLUDE}", "-c", STREAM_SRC, "-o", stream_obj])
+        _run([_hipcc(), "-std=c++17", "-O2", "-fPIC", "-Wall", f"-I{INCLUDE}", "-c", CLIP_SRC, "-o", clip_obj])
         rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
         _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", f"-I{INCLUDE}", f"-I{os.path.join(INCLUDE, 'svc')}",
-              "-o", LIB_MOTION, *srcs, stream_obj, f"-L{PKG}", "-lsvc_hip", f"-L{rocm_lib}", "-lamdhip64",
+              "-o", LIB_MOTION, *srcs, stream_obj, clip_obj, f"-L{PKG}", "-lsvc_hip", f"-L{rocm_lib}", "-lamdhip64",
               "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{rocm_lib}"])
     return LIB_MOTION
 

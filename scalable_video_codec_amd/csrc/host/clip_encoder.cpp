@@ -1,0 +1,548 @@
+// clip_encoder.cpp -- include/svc/clip_encoder.hpp + include/svc_clip.h: buffers, streams, the
+// step schedule and the halo of one rank's shard.  No arithmetic of the hot path lives here;
+// every stage is a call into the C ABI (include/svc_hip.h).
+#include "svc/clip_encoder.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "svc_clip.h"
+
+namespace svc {
+namespace {
+
+void Hip(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string("svc::ClipEncoder: ") + what + ": " + hipGetErrorString(e));
+}
+void Abi(int rc, const char* what) {
+  if (rc) throw std::runtime_error(std::string("svc::ClipEncoder: ") + what + ": " + svc_hip_last_error());
+}
+
+// libs/math.hpp:276-283 (ClosestLargerDivisible)
+uint32_t ClosestLargerDivisible(uint32_t dim, uint32_t a, uint32_t b) {
+  while (dim % a != 0 || dim % b != 0) ++dim;
+  return dim;
+}
+
+uint32_t Hash32(uint64_t x) {  // the harness's stateless mixer (synth.py:hash32, stream_encoder.cpp)
+  uint32_t v = (uint32_t)x;
+  v ^= v >> 16; v *= 0x7FEB352Du;
+  v ^= v >> 15; v *= 0x846CA68Bu;
+  v ^= v >> 16;
+  return v;
+}
+
+template <typename T> struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void Alloc(size_t count) {
+    n = count;
+    Hip(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc");
+  }
+  uint64_t bytes() const { return (uint64_t)n * sizeof(T); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+constexpr uint32_t kStages = (uint32_t)Stage::kCount;
+
+}  // namespace
+
+Shard PlanShard(uint32_t clip_frames, uint32_t world, uint32_t rank) {
+  Shard s;
+  if (world == 0 || rank >= world) return s;
+  const uint32_t base = clip_frames / world, extra = clip_frames % world;
+  s.frames = base + (rank < extra ? 1u : 0u);
+  s.first_frame = rank * base + std::min(rank, extra);
+  s.needs_halo = s.first_frame > 0 && s.frames > 0;
+  s.pairs = s.frames == 0 ? 0 : s.frames - (s.needs_halo ? 0u : 1u);
+  s.first_encoded = s.needs_halo ? s.first_frame : s.first_frame + 1;
+  return s;
+}
+
+struct ClipEncoder::Impl {
+  ClipEncoderConfig c;
+  Shard sh;
+  uint32_t pw = 0, ph = 0, mfw = 0, mfh = 0, blocks = 0, iters = 0;
+  uint64_t pyr_stride = 0, frame_bytes = 0, plane_elems = 0, record_bytes = 0, seg_ws_bytes = 0;
+  hipStream_t sM = nullptr, sL = nullptr, sC = nullptr;
+  DevBuf<uint8_t> bgr, pyr[2], mask[2], seg_ws, records;
+  DevBuf<float> mv[2], mad[2], gm[2], rmse[2], coeffs;
+  DevBuf<uint32_t> count[2], types[2], samples;
+  hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[2] = {nullptr, nullptr};
+  bool halo_recorded[2] = {false, false}, join_pending[2] = {false, false};
+  void* comm = nullptr;
+  HaloFn halo;
+  // pipeline progress: steps whose stage has been enqueued
+  uint64_t n_luma = 0, n_hbma = 0, n_lat = 0, n_dct = 0;
+  bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
+  // timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
+  std::vector<hipEvent_t> event_pool;
+  // graph of the steady-state block, one per buffer parity
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  hipGraph_t graph[2] = {nullptr, nullptr};
+
+  ~Impl() {
+    for (hipStream_t s : {sM, sL, sC})
+      if (s) (void)hipStreamSynchronize(s);
+    for (int b = 0; b < 2; ++b) {
+      if (gexec[b]) (void)hipGraphExecDestroy(gexec[b]);
+      if (graph[b]) (void)hipGraphDestroy(graph[b]);
+    }
+    for (auto& v : timed)
+      for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {e_pyr[0], e_pyr[1], e_halo[0], e_halo[1], e_fork, e_join[0], e_join[1]})
+      if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {sM, sL, sC})
+      if (s) (void)hipStreamDestroy(s);
+  }
+
+  hipEvent_t TimingEvent() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    Hip(hipEventCreate(&e), "hipEventCreate");
+    return e;
+  }
+
+  // Runs fn with HIP events around it on `stream` when timing is on.
+  template <typename F> void Run(Stage st, hipStream_t stream, bool timing, F&& fn) {
+    if (!timing) { fn(); return; }
+    hipEvent_t a = TimingEvent(), b = TimingEvent();
+    Hip(hipEventRecord(a, stream), "hipEventRecord");
+    fn();
+    Hip(hipEventRecord(b, stream), "hipEventRecord");
+    timed[(uint32_t)st].emplace_back(a, b);
+  }
+
+  // buffer set of step s: the pipelined schedule alternates two, the serial one has one
+  int Par(uint64_t s) const { return c.schedule == Schedule::kPipelined ? (int)(s & 1) : 0; }
+
+  // ---- the stages; `s` is the step index, its buffers are those of set Par(s) ---------------
+  void Luma(uint64_t s, hipStream_t st, bool timing) {
+    const int b = Par(s);
+    Run(Stage::kLumaPyramid, st, timing, [&] {
+      Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, sh.frames, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
+          "svc_hip_luma_pyramid_frames");
+    });
+  }
+
+  // my last pyramid -> rank + 1's slot 0; slot 0 <- rank - 1's last pyramid
+  void Halo(uint64_t s, bool timing) {
+    const int b = Par(s);
+    Hip(hipEventRecord(e_pyr[b], sM), "hipEventRecord");
+    Hip(hipStreamWaitEvent(sC, e_pyr[b], 0), "hipStreamWaitEvent");
+    Run(Stage::kHalo, sC, timing, [&] {
+      const uint8_t* send = pyr[b].p + (uint64_t)sh.frames * pyr_stride;
+      if (halo) halo(send, pyr[b].p, pyr_stride, sC);
+      else if (comm) Abi(svc_hip_halo_shift(comm, send, pyr[b].p, pyr_stride, c.rank, c.world, 0, sC), "svc_hip_halo_shift");
+      else throw std::runtime_error("svc::ClipEncoder: world > 1 needs SetComm() or SetHaloTransport() before Step()");
+    });
+    Hip(hipEventRecord(e_halo[b], sC), "hipEventRecord");
+    halo_recorded[b] = true;
+  }
+
+  void Hbma(uint64_t s, hipStream_t st, bool timing) {
+    if (!sh.pairs) return;
+    const int b = Par(s);
+    const uint64_t t0 = sh.needs_halo ? 0 : 1;  // slot of the first tracked pyramid
+    Run(Stage::kHbma, st, timing, [&] {
+      Abi(svc_hip_hbma_pairs(pyr[b].p + t0 * pyr_stride, pyr[b].p + (t0 + 1) * pyr_stride, pyr_stride, sh.pairs, c.levels, pw, ph,
+                             c.search_range, c.mv_block, c.mv_block, mv[b].p, mad[b].p, SVC_HBMA_AUTO, st), "svc_hip_hbma_pairs");
+    });
+  }
+
+  // RANSAC + region ids: one workgroup per frame, latency-bound
+  void Lat(uint64_t s, hipStream_t st, bool timing) {
+    if (!sh.pairs) return;
+    const int b = Par(s);
+    const uint64_t g0 = sh.first_encoded - 1;  // clip-wide index of the shard's first pair
+    Run(Stage::kRansac, st, timing, [&] {
+      Hip(hipMemsetAsync(gm[b].p, 0, gm[b].bytes(), st), "hipMemsetAsync");  // in/out, libs/motion.cpp:241-242
+      Abi(svc_hip_ransac_frames(mv[b].p, blocks, sh.pairs, c.ransac, samples.p, iters, gm[b].p, rmse[b].p, mask[b].p,
+                                count[b].p, st), "svc_hip_ransac_frames");
+    });
+    Run(Stage::kSegment, st, timing, [&] {
+      if (c.segmentation)
+        Abi(svc_hip_segment_frames(mask[b].p, mv[b].p, mfw, mfh, sh.pairs, c.mv_block, c.mv_block, c.segment,
+                                   c.seed * 1000003ull + g0, seg_ws.p, seg_ws_bytes, types[b].p, st), "svc_hip_segment_frames");
+      else
+        Abi(svc_hip_block_types_frames(mask[b].p, blocks, sh.pairs, types[b].p, st), "svc_hip_block_types_frames");
+    });
+  }
+
+  void Transform(uint64_t s, hipStream_t st, bool timing) {
+    if (!sh.pairs || !c.dct_block_w) return;
+    const int b = Par(s);
+    const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
+    Run(Stage::kTransform, st, timing, [&] {
+      if (c.wire)
+        Abi(svc_hip_dct_records_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block,
+                                       c.fg_step, c.bg_step, ph, records.p, record_bytes, st), "svc_hip_dct_records_frames");
+      else
+        Abi(svc_hip_dct_quant_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, types[b].p, c.mv_block,
+                                     c.mv_block, c.fg_step, c.bg_step, coeffs.p, st), "svc_hip_dct_quant_frames");
+    });
+  }
+
+  // RANSAC + segmentation of step l on the second stream, behind everything the main stream holds so far;
+  // the main stream picks the result up (JoinLat) only where it is needed, an iteration later.
+  void ForkLat(uint64_t l, bool timing) {
+    Hip(hipEventRecord(e_fork, sM), "hipEventRecord");
+    Hip(hipStreamWaitEvent(sL, e_fork, 0), "hipStreamWaitEvent");
+    Lat(l, sL, timing);
+    Hip(hipEventRecord(e_join[l & 1], sL), "hipEventRecord");
+    join_pending[l & 1] = true;
+  }
+  void JoinLat(uint64_t l) {
+    if (!join_pending[l & 1]) return;
+    Hip(hipStreamWaitEvent(sM, e_join[l & 1], 0), "hipStreamWaitEvent");
+    join_pending[l & 1] = false;
+  }
+
+  // The steady-state iteration as ONE fork/join block (what the hipGraph option captures): motion search of
+  // step h on the main stream with the transform of step h - 2 behind it, RANSAC + segmentation of step
+  // h - 1 beside them on the second stream.
+  void Block(uint64_t h, uint64_t l, uint64_t d) {
+    ForkLat(l, false);
+    Hbma(h, sM, false);
+    Transform(d, sM, false);
+    JoinLat(l);
+  }
+
+  // One iteration of the software pipeline.  Buffer hazards (sets alternate with the step's parity):
+  //   lat(l) reads mv[l], writes mask/types[l]   | beside it: hbma(l + 1) writes mv[l + 1], transform(l - 1)
+  //   reads types[l - 1] -- disjoint; the NEXT iteration's hbma(l + 2) and transform(l) touch set l again, so the
+  //   main stream joins lat(l) there, after the next luma: lat(l) has luma + hbma + transform + luma to hide behind.
+  void Iterate(bool new_step, bool timing) {
+    const uint64_t lumas = n_luma, hbmas = n_hbma, lats = n_lat;
+    const bool do_hbma = n_hbma < lumas, do_lat = n_lat < hbmas, do_dct = n_dct < lats;
+    const uint64_t h = n_hbma, l = n_lat, d = n_dct;
+    const bool replay = c.graph && do_hbma && do_lat && do_dct && !timing;
+    if (do_lat && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
+    if (new_step) {
+      const uint64_t s = n_luma;
+      const int b = Par(s);
+      if (c.world > 1 && halo_recorded[b])  // the send out of pyr[b] two steps ago must have left
+        Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
+      Luma(s, sM, timing);
+      if (c.world > 1) Halo(s, timing);
+      ++n_luma;
+    }
+    if (l > 0) JoinLat(l - 1);  // set (l - 1) & 1 is about to be written by hbma(l + 1) and read by transform(l - 1)
+    if (do_hbma && c.world > 1)  // the halo of step h has had a whole iteration to arrive
+      Hip(hipStreamWaitEvent(sM, e_halo[Par(h)], 0), "hipStreamWaitEvent");
+    if (replay) {
+      const int b = Par(h);
+      if (!gexec[b]) {
+        Hip(hipStreamBeginCapture(sM, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        try {
+          Block(h, l, d);
+        } catch (...) {
+          hipGraph_t dead = nullptr;
+          (void)hipStreamEndCapture(sM, &dead);
+          if (dead) (void)hipGraphDestroy(dead);
+          throw;
+        }
+        Hip(hipStreamEndCapture(sM, &graph[b]), "hipStreamEndCapture");
+        Hip(hipGraphInstantiate(&gexec[b], graph[b], nullptr, nullptr, 0), "hipGraphInstantiate");
+      }
+      Hip(hipGraphLaunch(gexec[b], sM), "hipGraphLaunch");
+    } else {
+      if (do_hbma) Hbma(h, sM, timing);
+      if (do_dct) Transform(d, sM, timing);
+    }
+    n_hbma += do_hbma; n_lat += do_lat; n_dct += do_dct;
+  }
+
+  void SerialStep(bool timing) {
+    const uint64_t s = n_luma;
+    const int b = Par(s);
+    if (c.world > 1 && halo_recorded[b]) Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
+    Luma(s, sM, timing);
+    if (c.world > 1) {
+      Halo(s, timing);
+      Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
+    }
+    Hbma(s, sM, timing);
+    Lat(s, sM, timing);
+    Transform(s, sM, timing);
+    ++n_luma; ++n_hbma; ++n_lat; ++n_dct;
+  }
+};
+
+ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
+  Impl& m = *p_;
+  m.c = config;
+  const ClipEncoderConfig& c = m.c;
+  if (!c.width || !c.height || !c.levels || c.levels > 16 || !c.mv_block || c.world == 0 || c.rank >= c.world)
+    throw std::runtime_error("svc::ClipEncoder: invalid configuration");
+  if (c.clip_frames < 2 || c.clip_frames < c.world)
+    throw std::runtime_error("svc::ClipEncoder: a clip needs at least two frames and one frame per rank");
+  if ((c.dct_block_w == 0) != (c.dct_block_h == 0))
+    throw std::runtime_error("svc::ClipEncoder: transform block needs both sides");
+  if (c.wire && c.dct_block_w != c.dct_block_h)
+    throw std::runtime_error("svc::ClipEncoder: the fused record emitter takes square transform blocks");
+  m.sh = PlanShard(c.clip_frames, c.world, c.rank);
+  const uint32_t f = 1u << (c.levels - 1);
+  m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
+  m.ph = ClosestLargerDivisible(c.height, c.mv_block, f);
+  m.mfw = m.pw / c.mv_block; m.mfh = m.ph / c.mv_block; m.blocks = m.mfw * m.mfh;
+  m.pyr_stride = (svc_hip_pyramid_bytes(m.pw, m.ph, c.levels) + 255) / 256 * 256;
+  m.frame_bytes = (uint64_t)m.pw * m.ph * 3;
+  m.plane_elems = (uint64_t)m.pw * m.ph;
+  const bool transform = c.dct_block_w != 0;
+  m.record_bytes = (c.wire && transform) ? svc_hip_serialized_frame_bytes(m.pw, m.ph, c.dct_block_w, c.dct_block_h) : 0;
+  m.iters = svc_hip_ransac_iter_count(c.ransac);
+  const uint32_t P = m.sh.pairs, N = m.sh.frames;
+  m.seg_ws_bytes = c.segmentation ? svc_hip_segment_workspace_bytes(m.mfw, m.mfh, std::max(P, 1u), c.segment.attempt_count) : 0;
+  // All three at the default priority.  Measured on MI355X (38-frame shard, pipelined): raising the second and
+  // the communication stream stretched the main stream's HBM-bound kernels 1.8x (0.41 -> 0.64 ms per step), and
+  // a low-priority main stream was slower still (0.79).
+  for (hipStream_t* s : {&m.sM, &m.sL, &m.sC}) Hip(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreate");
+  for (hipEvent_t* e : {&m.e_pyr[0], &m.e_pyr[1], &m.e_halo[0], &m.e_halo[1], &m.e_fork, &m.e_join[0], &m.e_join[1]})
+    Hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+  m.bgr.Alloc((size_t)N * m.frame_bytes);
+  const int sets = c.schedule == Schedule::kPipelined ? 2 : 1;
+  for (int b = 0; b < 2; ++b) {
+    if (b >= sets) continue;
+    m.pyr[b].Alloc((size_t)(N + 1) * m.pyr_stride);  // slot 0 = halo, slots 1..N = own frames
+    Hip(hipMemset(m.pyr[b].p, 0, (size_t)(N + 1) * m.pyr_stride), "hipMemset");
+    m.mv[b].Alloc((size_t)P * m.blocks * 2); m.mad[b].Alloc((size_t)P * m.blocks);
+    m.gm[b].Alloc((size_t)P * 2); m.rmse[b].Alloc(P);
+    m.mask[b].Alloc((size_t)P * m.blocks); m.count[b].Alloc(P); m.types[b].Alloc((size_t)P * m.blocks);
+  }
+  m.seg_ws.Alloc(m.seg_ws_bytes);
+  if (transform) {
+    if (c.wire) m.records.Alloc((size_t)P * m.record_bytes);
+    else m.coeffs.Alloc((size_t)P * 3 * m.plane_elems);
+  }
+  // RANSAC draws: distinct within an iteration, a function of (seed, clip frame, iteration) only --
+  // the generator of stream_encoder.cpp / pipeline.ransac_samples, indexed by the CLIP-wide pair
+  {
+    const uint64_t g0 = m.sh.first_encoded - 1;
+    const size_t n = (size_t)P * m.iters * c.ransac.subset_sz;
+    std::vector<uint32_t> h(std::max<size_t>(n, 1));
+    const uint32_t div = std::max<uint32_t>(1, (m.blocks - 1) / std::max<uint32_t>(1, c.ransac.subset_sz));
+    for (size_t i = 0; i < (size_t)P * m.iters; ++i) {
+      const uint64_t idx = g0 * m.iters + i;
+      const uint32_t first = Hash32(idx * 0x9E3779B1ull + c.seed) % m.blocks;
+      const uint32_t step = 1 + Hash32(idx * 0x85EBCA6Bull + c.seed + 1) % div;
+      for (uint32_t k = 0; k < c.ransac.subset_sz; ++k)
+        h[i * c.ransac.subset_sz + k] = (uint32_t)(((uint64_t)first + (uint64_t)step * k) % m.blocks);
+    }
+    m.samples.Alloc(n);
+    if (n) Hip(hipMemcpy(m.samples.p, h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy");
+  }
+  Hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+}
+
+ClipEncoder::~ClipEncoder() = default;
+const Shard& ClipEncoder::shard() const { return p_->sh; }
+uint32_t ClipEncoder::padded_width() const { return p_->pw; }
+uint32_t ClipEncoder::padded_height() const { return p_->ph; }
+uint32_t ClipEncoder::blocks() const { return p_->blocks; }
+uint64_t ClipEncoder::pyramid_stride() const { return p_->pyr_stride; }
+uint32_t ClipEncoder::steps_submitted() const { return (uint32_t)p_->n_luma; }
+
+void ClipEncoder::LoadFrames(const uint8_t* src, uint32_t first_local, uint32_t n, bool src_on_device) {
+  Impl& m = *p_;
+  if (!src || (uint64_t)first_local + n > m.sh.frames) throw std::runtime_error("svc::ClipEncoder: LoadFrames out of range");
+  Sync();
+  Hip(hipMemcpy(m.bgr.p + (size_t)first_local * m.frame_bytes, src, (size_t)n * m.frame_bytes,
+                src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "hipMemcpy");
+}
+
+void ClipEncoder::SetComm(void* nccl_comm) { p_->comm = nccl_comm; }
+void ClipEncoder::SetHaloTransport(HaloFn fn) { p_->halo = std::move(fn); }
+
+void ClipEncoder::Step(bool timed) {
+  p_->last_timed = timed;
+  if (p_->c.schedule == Schedule::kPipelined) p_->Iterate(true, timed);
+  else p_->SerialStep(timed);
+}
+
+void ClipEncoder::Flush() {
+  Impl& m = *p_;
+  while (m.n_dct < m.n_luma) m.Iterate(false, m.last_timed);
+}
+
+void ClipEncoder::Sync() {
+  Flush();
+  for (hipStream_t s : {p_->sC, p_->sL, p_->sM}) Hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+
+void ClipEncoder::StageTime(Stage s, double* total_ms, uint32_t* launches) {
+  Sync();
+  double t = 0;
+  for (auto& pr : p_->timed[(uint32_t)s]) {
+    float ms = 0;
+    Hip(hipEventElapsedTime(&ms, pr.first, pr.second), "hipEventElapsedTime");
+    t += ms;
+  }
+  if (total_ms) *total_ms = t;
+  if (launches) *launches = (uint32_t)p_->timed[(uint32_t)s].size();
+}
+
+void ClipEncoder::ResetTimers() {
+  Sync();
+  for (auto& v : p_->timed) {
+    for (auto& pr : v) { p_->event_pool.push_back(pr.first); p_->event_pool.push_back(pr.second); }
+    v.clear();
+  }
+}
+
+void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
+  Impl& m = *p_;
+  Sync();
+  const int par = m.n_dct ? m.Par(m.n_dct - 1) : 0;
+  void* ptr = nullptr;
+  uint64_t n = 0;
+  switch (b) {
+    case Buffer::kMv: ptr = m.mv[par].p; n = m.mv[par].bytes(); break;
+    case Buffer::kMinMad: ptr = m.mad[par].p; n = m.mad[par].bytes(); break;
+    case Buffer::kGlobalMotion: ptr = m.gm[par].p; n = m.gm[par].bytes(); break;
+    case Buffer::kRmse: ptr = m.rmse[par].p; n = m.rmse[par].bytes(); break;
+    case Buffer::kInlierMask: ptr = m.mask[par].p; n = m.mask[par].bytes(); break;
+    case Buffer::kInlierCount: ptr = m.count[par].p; n = m.count[par].bytes(); break;
+    case Buffer::kBlockTypes: ptr = m.types[par].p; n = m.types[par].bytes(); break;
+    case Buffer::kCoeffs: ptr = m.coeffs.p; n = m.coeffs.bytes(); break;
+    case Buffer::kRecords: ptr = m.records.p; n = m.records.bytes(); break;
+    case Buffer::kPyramids: ptr = m.pyr[par].p; n = m.pyr[par].bytes(); break;
+    case Buffer::kBgr: ptr = m.bgr.p; n = m.bgr.bytes(); break;
+    default: throw std::runtime_error("svc::ClipEncoder: unknown buffer");
+  }
+  if (bytes) *bytes = n;
+  return ptr;
+}
+
+}  // namespace svc
+
+// ---- C handle API (include/svc_clip.h) ---------------------------------------------------------
+struct svc_clip {
+  std::unique_ptr<svc::ClipEncoder> enc;
+  svc::ClipEncoderConfig cfg;
+};
+
+namespace {
+thread_local std::string g_clip_err;
+
+template <typename F> int Guard(F&& fn) {
+  try {
+    fn();
+    return 0;
+  } catch (const std::exception& e) {
+    g_clip_err = e.what();
+    return 1;
+  } catch (...) {
+    g_clip_err = "unknown exception";
+    return 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* svc_clip_last_error(void) { return g_clip_err.c_str(); }
+
+int svc_clip_plan_shard(uint32_t clip_frames, uint32_t world, uint32_t rank, uint32_t* first_frame, uint32_t* frames,
+                        uint32_t* pairs, uint32_t* first_encoded) {
+  return Guard([&] {
+    if (world == 0 || rank >= world) throw std::runtime_error("svc_clip_plan_shard: rank out of range");
+    const svc::Shard s = svc::PlanShard(clip_frames, world, rank);
+    if (first_frame) *first_frame = s.first_frame;
+    if (frames) *frames = s.frames;
+    if (pairs) *pairs = s.pairs;
+    if (first_encoded) *first_encoded = s.first_encoded;
+  });
+}
+
+int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
+  return Guard([&] {
+    if (!k || !out) throw std::runtime_error("svc_clip_create: null pointer");
+    svc::ClipEncoderConfig c;
+    c.width = k->width; c.height = k->height; c.levels = k->levels; c.mv_block = k->mv_block;
+    c.search_range = k->search_range; c.dct_block_w = k->dct_block_w; c.dct_block_h = k->dct_block_h;
+    c.fg_step = k->fg_step; c.bg_step = k->bg_step; c.wire = k->wire != 0; c.segmentation = k->segmentation != 0;
+    c.seed = k->seed; c.ransac = k->ransac; c.segment = k->segment; c.clip_frames = k->clip_frames;
+    c.rank = k->rank; c.world = k->world;
+    c.schedule = k->schedule == SVC_CLIP_SERIAL ? svc::Schedule::kSerial : svc::Schedule::kPipelined;
+    c.graph = k->graph != 0;
+    std::unique_ptr<svc_clip> h(new svc_clip);
+    h->cfg = c;
+    h->enc.reset(new svc::ClipEncoder(c));
+    *out = h.release();
+  });
+}
+
+void svc_clip_destroy(svc_clip* clip) { delete clip; }
+
+int svc_clip_get_info(svc_clip* clip, svc_clip_info* o) {
+  return Guard([&] {
+    if (!clip || !o) throw std::runtime_error("svc_clip_get_info: null pointer");
+    const svc::ClipEncoder& e = *clip->enc;
+    const svc::Shard& s = e.shard();
+    o->padded_w = e.padded_width(); o->padded_h = e.padded_height();
+    o->mv_field_w = o->padded_w / clip->cfg.mv_block; o->mv_field_h = o->padded_h / clip->cfg.mv_block;
+    o->blocks = e.blocks(); o->ransac_iters = svc_hip_ransac_iter_count(clip->cfg.ransac);
+    o->pyramid_stride = e.pyramid_stride();
+    o->frame_bytes = (uint64_t)o->padded_w * o->padded_h * 3;
+    o->record_bytes = (clip->cfg.wire && clip->cfg.dct_block_w)
+                          ? svc_hip_serialized_frame_bytes(o->padded_w, o->padded_h, clip->cfg.dct_block_w, clip->cfg.dct_block_h) : 0;
+    o->first_frame = s.first_frame; o->frames = s.frames; o->pairs = s.pairs; o->first_encoded = s.first_encoded;
+    o->needs_halo = s.needs_halo ? 1u : 0u;
+  });
+}
+
+int svc_clip_load_frames(svc_clip* clip, const uint8_t* src, uint32_t first_local, uint32_t n, int src_on_device) {
+  return Guard([&] { clip->enc->LoadFrames(src, first_local, n, src_on_device != 0); });
+}
+
+int svc_clip_set_comm(svc_clip* clip, void* nccl_comm) { return Guard([&] { clip->enc->SetComm(nccl_comm); }); }
+
+int svc_clip_set_halo_callback(svc_clip* clip, svc_clip_halo_fn fn, void* user) {
+  return Guard([&] {
+    if (!fn) { clip->enc->SetHaloTransport(nullptr); return; }
+    clip->enc->SetHaloTransport([fn, user](const uint8_t* s, uint8_t* r, uint64_t bytes, void* stream) {
+      if (fn(s, r, bytes, stream, user)) throw std::runtime_error("svc::ClipEncoder: the halo callback failed");
+    });
+  });
+}
+
+int svc_clip_step(svc_clip* clip, int timed) { return Guard([&] { clip->enc->Step(timed != 0); }); }
+int svc_clip_flush(svc_clip* clip) { return Guard([&] { clip->enc->Flush(); }); }
+int svc_clip_sync(svc_clip* clip) { return Guard([&] { clip->enc->Sync(); }); }
+
+int svc_clip_stage_time(svc_clip* clip, uint32_t stage, double* total_ms, uint32_t* launches) {
+  return Guard([&] {
+    if (stage >= SVC_STAGE_COUNT) throw std::runtime_error("svc_clip_stage_time: unknown stage");
+    clip->enc->StageTime((svc::Stage)stage, total_ms, launches);
+  });
+}
+
+int svc_clip_reset_timers(svc_clip* clip) { return Guard([&] { clip->enc->ResetTimers(); }); }
+
+int svc_clip_output(svc_clip* clip, uint32_t buffer, void** d_ptr, uint64_t* bytes) {
+  return Guard([&] {
+    if (buffer >= SVC_BUF_COUNT || !d_ptr) throw std::runtime_error("svc_clip_output: bad argument");
+    *d_ptr = clip->enc->Output((svc::Buffer)buffer, bytes);
+  });
+}
+
+int svc_clip_read(svc_clip* clip, uint32_t buffer, uint64_t offset, void* dst, uint64_t bytes, int dst_on_device) {
+  return Guard([&] {
+    if (buffer >= SVC_BUF_COUNT || !dst) throw std::runtime_error("svc_clip_read: bad argument");
+    uint64_t have = 0;
+    const uint8_t* p = static_cast<const uint8_t*>(clip->enc->Output((svc::Buffer)buffer, &have));
+    if (offset + bytes > have) throw std::runtime_error("svc_clip_read: range exceeds the buffer");
+    svc::Hip(hipMemcpy(dst, p + offset, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost), "hipMemcpy");
+  });
+}
+
+}  // extern "C"

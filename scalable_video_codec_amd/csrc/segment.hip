@@ -1130,18 +1130,27 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   if (a.n > kLightMax) {
     // The two attempt launches are independent (each frame belongs to exactly one): the heavy one goes to a
     // side stream, forked after the prepare kernel and joined before the labelling, so a scene cut's long
-    // workgroups run beside the light frames instead of after them.
-    SideStream* side = side_stream();
-    if (!side) return fail(SVC_ERR_HIP, "segment: cannot create the side stream");
+    // workgroups run beside the light frames instead of after them.  Not while `stream` is being captured
+    // into a hipGraph: a fork out of a stream that is itself a fork of the capture's origin sends ROCm 7.2's
+    // hipStreamEndCapture into unbounded recursion, so a capture gets the two launches in stream order.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    SVC_HIP_TRY(hipStreamIsCapturing(stream, &capturing));
     SegArgs heavy = a;
     // more than kRegPts points per lane are possible: LDS for the large-frame path
     if (a.n > kRegPts * kTA) heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
-    SVC_HIP_TRY(hipEventRecord(side->fork, stream));
-    SVC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-    hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, side->stream, heavy);
-    SVC_HIP_TRY(hipEventRecord(side->join, side->stream));
-    hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
-    SVC_HIP_TRY(hipStreamWaitEvent(stream, side->join, 0));
+    if (capturing == hipStreamCaptureStatusNone) {
+      SideStream* side = side_stream();
+      if (!side) return fail(SVC_ERR_HIP, "segment: cannot create the side stream");
+      SVC_HIP_TRY(hipEventRecord(side->fork, stream));
+      SVC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+      hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, side->stream, heavy);
+      SVC_HIP_TRY(hipEventRecord(side->join, side->stream));
+      hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
+      SVC_HIP_TRY(hipStreamWaitEvent(stream, side->join, 0));
+    } else {
+      hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, stream, heavy);
+      hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
+    }
   } else {
     hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
   }

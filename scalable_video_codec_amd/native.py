@@ -80,6 +80,10 @@ SIGNATURES = {
     "svc_hip_dct_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp]),
     "svc_hip_dct_quant_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp]),
     "svc_hip_quant_host": (C.c_int, [_vp, _u64, _u32]),
+    "svc_hip_comm_unique_id": (C.c_int, [_vp]),
+    "svc_hip_comm_create": (C.c_int, [_vp, _u32, _u32, C.POINTER(_vp)]),
+    "svc_hip_comm_destroy": (C.c_int, [_vp]),
+    "svc_hip_halo_shift": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

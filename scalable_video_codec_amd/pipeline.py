@@ -1,6 +1,10 @@
-"""Clip-level driver of the hot path: the part of the reference's per-frame loop
+"""Stage-by-stage harness over the C ABI: the part of the reference's per-frame loop
 (Encoder::operator(), libs/encoder.cpp:453-664) that touches motion search, global
-motion, block types and the transform, batched over a clip that lives in HBM.
+motion, block types and the transform, batched over a clip that lives in HBM, one
+C-ABI call per stage on torch's current stream.  The product driver -- schedules,
+streams, RCCL halo -- is C++ (svc::ClipEncoder, include/svc/clip_encoder.hpp, bound in
+clip.py); this module is what the tests compare it with, plus the torch.distributed
+halo transport that the CPU (gloo) tests and the bench's SVC_HALO=torch switch use.
 
 Frame order follows the reference: the tracked frame of encoded frame t is the
 previous SOURCE frame (libs/encoder.cpp:661-663 swaps source pyramids; there is no
@@ -38,15 +42,14 @@ def load_pmc_traffic() -> Dict[str, float]:
 
 
 def plan_shards(total_frames: int, world: int) -> List[Tuple[int, int, bool]]:
-    """Cuts a clip of `total_frames` into `world` consecutive chunks.  Returns, per rank,
-    (first_frame, n_frames, needs_halo): every rank but the first needs the pyramid of
-    frame first_frame - 1 from its predecessor.  Encoded frames: total_frames - 1."""
-    base, extra = divmod(total_frames, world)
-    out, start = [], 0
+    """Cuts a clip of `total_frames` into `world` consecutive chunks -- svc::PlanShard, the C++ driver's own plan
+    (include/svc/clip_encoder.hpp).  Returns, per rank, (first_frame, n_frames, needs_halo): every rank but the
+    first needs the pyramid of frame first_frame - 1 from its predecessor.  Encoded frames: total_frames - 1."""
+    from . import clip
+    out = []
     for r in range(world):
-        n = base + (1 if r < extra else 0)
-        out.append((start, n, r > 0 and n > 0))
-        start += n
+        first, n, _pairs, _first_encoded = clip.plan_shard(total_frames, world, r)
+        out.append((first, n, first > 0 and n > 0))
     return out
 
 
@@ -138,7 +141,6 @@ class ClipEncoder:
                                       cfg.seed + 7919 * rank, device)
         self._ev: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._steps_timed = 0
-        self._side: Optional[torch.cuda.Stream] = None
         fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2)
         self.hbma_kernel_name = "hbma_fused16_kernel" if fused else "hbma_wave_level_kernel"
 
@@ -184,150 +186,36 @@ class ClipEncoder:
         """Ring-less neighbour shift: my last pyramid -> rank+1's halo slot (RCCL over xGMI)."""
         halo_exchange(self.pyr, self.stride, self.n, self.rank, self.world)
 
-    # -- software-pipelined schedule ---------------------------------------------------------
-    def _ensure_overlap_buffers(self) -> None:
-        if getattr(self, "_ov", None) is not None:
-            return
-        names = ("mv", "mad", "gm", "rmse", "mask", "count", "types")
-        # parity 0 = the ordinary buffers, parity 1 = a second set (small: ~50 KB per frame)
-        self._ov = [{n: getattr(self, n) for n in names},
-                    {n: torch.empty_like(getattr(self, n)) for n in names}]
-        self._ov[1]["gm"].zero_()
-        self._front = torch.cuda.Stream(device=self.dev)
-        self._back = torch.cuda.Stream(device=self.dev)
-        self._front_done = [None, None]
-        self._back_done = [None, None]
-        self._ov_step = 0
-
-    def step_overlapped(self, timed: bool = False) -> None:
-        """One pass, software-pipelined across passes as a streaming encoder would run: the front end
-        of this pass (luma + pyramid, halo, motion search) goes to one HIP stream, its back end
-        (RANSAC, segmentation, transform) to another, so the back end of pass s overlaps the front
-        end of pass s + 1.  The per-frame outputs that cross the two halves are double-buffered.
-        Call finish_overlapped() before reading results or stopping the clock."""
-        self._ensure_overlap_buffers()
+    def step(self, timed: bool = False) -> None:
+        """One pass over the clip on torch's current stream, one C-ABI call per stage."""
         c = self.cfg
-        b = self._ov_step & 1
-        buf = self._ov[b]
-        t0 = 0 if self.has_halo else 1
-        with torch.cuda.stream(self._front):
-            if self._back_done[b] is not None:      # pass s - 2 must have released buffer set b
-                self._front.wait_event(self._back_done[b])
-            with self._timed("luma_pyramid", timed):
-                native.luma_pyramid_frames(self.bgr, self.levels, out=self.pyr[self.stride:], stride=self.stride)
-            with self._timed("halo_exchange", timed and self.world > 1):
-                self.exchange_halo()
-            with self._timed("hbma", timed):
-                native.hbma_pairs(self.pyr[t0 * self.stride:], self.pyr[(t0 + 1) * self.stride:], self.stride,
-                                  self.pairs_per_step, self.levels, self.pw, self.ph, c.search_range,
-                                  c.mv_block, c.mv_block, out=(buf["mv"], buf["mad"]))
-            ev = torch.cuda.Event()
-            ev.record(self._front)
-            self._front_done[b] = ev
-        with torch.cuda.stream(self._back):
-            self._back.wait_event(self._front_done[b])
-            with self._timed("ransac", timed):
-                native.ransac_frames(buf["mv"], self.samples, out=(buf["gm"], buf["rmse"], buf["mask"], buf["count"]),
-                                     **self.ransac)
-            if self.segmentation:
-                with self._timed("segment", timed):
-                    native.segment_frames(buf["mask"], buf["mv"], self.mfw, self.mfh, c.mv_block, seed=self.seg_seed,
-                                          out=buf["types"], workspace=self.seg_ws, **self.segment)
-            else:
-                with self._timed("block_types", timed):
-                    native.block_types_frames(buf["mask"], out=buf["types"])
-            if c.dct_block:
-                with self._timed("dct_quant", timed):
-                    if self.wire:
-                        native.dct_records_frames(self.bgr[self.first_encoded:], c.dct_block, buf["types"], c.mv_block,
-                                                  c.fg_step, c.bg_step, out=self.records)
-                    else:
-                        native.dct_quant_frames(self.bgr[self.first_encoded:], c.dct_block, buf["types"], c.mv_block,
-                                                c.fg_step, c.bg_step, out=self.coeffs)
-            ev = torch.cuda.Event()
-            ev.record(self._back)
-            self._back_done[b] = ev
-        self._ov_step += 1
-        self._steps_timed += 1 if timed else 0
-
-    def finish_overlapped(self) -> None:
-        """Joins both streams into the current one and points the result attributes at the newest buffers."""
-        if getattr(self, "_ov", None) is None:
-            return
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(self._front)
-        cur.wait_stream(self._back)
-        if self._ov_step:
-            for n, t in self._ov[(self._ov_step - 1) & 1].items():
-                setattr(self, n, t)
-
-    def step(self, timed: bool = False, chunks: int = 1) -> None:
-        """One pass over the clip.  chunks > 1 cuts the clip into consecutive chunks and runs
-        the transform of chunk k on a second HIP stream while the front (luma, pyramid, motion
-        search, RANSAC, block types) of chunk k + 1 runs on the first: the DCT+quant kernel is
-        HBM-bound, the motion search VALU-bound and RANSAC latency-bound, so they overlap.
-        The dependency DCT+quant(k) <- block types(k) is a HIP event."""
-        c = self.cfg
-        chunks = max(1, min(chunks, self.pairs_per_step))
-        if chunks > 1 and self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        main = torch.cuda.current_stream()
         t0 = 0 if self.has_halo else 1        # slot of the first tracked pyramid
-        bounds = [self.pairs_per_step * i // chunks for i in range(chunks + 1)]
-        done_frames = 0                        # frames whose pyramid exists (own frames, 0-based)
-        for k in range(chunks):
-            p0, p1 = bounds[k], bounds[k + 1]  # pairs [p0, p1) of this step
-            # pair p uses slots t0 + p (tracked) and t0 + p + 1 (anchor); slot s > 0 is own frame s - 1
-            need = t0 + p1                     # own frames [0, need) must have pyramids
-            if need > done_frames:
-                with self._timed("luma_pyramid", timed):
-                    native.luma_pyramid_frames(self.bgr[done_frames:need], self.levels,
-                                               out=self.pyr[(done_frames + 1) * self.stride:], stride=self.stride)
-                done_frames = need
-            if k == 0:
-                if chunks > 1 and self.world > 1 and done_frames < self.n:
-                    # the halo payload is this rank's LAST pyramid: build it before the exchange
-                    with self._timed("luma_pyramid", timed):
-                        native.luma_pyramid_frames(self.bgr[self.n - 1:self.n], self.levels,
-                                                   out=self.pyr[self.n * self.stride:], stride=self.stride)
-                with self._timed("halo_exchange", timed and self.world > 1):
-                    self.exchange_halo()
-            np_ = p1 - p0
-            with self._timed("hbma", timed):
-                native.hbma_pairs(self.pyr[(t0 + p0) * self.stride:], self.pyr[(t0 + p0 + 1) * self.stride:],
-                                  self.stride, np_, self.levels, self.pw, self.ph, c.search_range,
-                                  c.mv_block, c.mv_block, out=(self.mv[p0:p1], self.mad[p0:p1]))
-            with self._timed("ransac", timed):
-                native.ransac_frames(self.mv[p0:p1], self.samples[p0:p1],
-                                     out=(self.gm[p0:p1], self.rmse[p0:p1], self.mask[p0:p1], self.count[p0:p1]),
-                                     **self.ransac)
-            if self.segmentation:
-                with self._timed("segment", timed):
-                    native.segment_frames(self.mask[p0:p1], self.mv[p0:p1], self.mfw, self.mfh, c.mv_block,
-                                          seed=self.seg_seed + p0, out=self.types[p0:p1], workspace=self.seg_ws,
-                                          **self.segment)
-            else:
-                with self._timed("block_types", timed):
-                    native.block_types_frames(self.mask[p0:p1], out=self.types[p0:p1])
-            if not c.dct_block:
-                continue
-            f0 = self.first_encoded + p0       # encoded frame of pair p is own frame first_encoded + p
-            if self.wire:
-                with self._timed("dct_quant", timed):
-                    native.dct_records_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
-                                              c.fg_step, c.bg_step, out=self.records[p0:p1])
-            elif chunks == 1:
-                with self._timed("dct_quant", timed):
-                    native.dct_quant_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
-                                            c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
-            elif not self.wire:
-                ready = torch.cuda.Event()
-                ready.record(main)
-                with torch.cuda.stream(self._side):
-                    self._side.wait_event(ready)
-                    with self._timed("dct_quant", timed):
-                        native.dct_quant_frames(self.bgr[f0:f0 + np_], c.dct_block, self.types[p0:p1], c.mv_block,
-                                                c.fg_step, c.bg_step, out=self.coeffs[p0:p1])
-        if chunks > 1 and c.dct_block and not self.wire:
-            main.wait_stream(self._side)
+        p = self.pairs_per_step
+        with self._timed("luma_pyramid", timed):
+            native.luma_pyramid_frames(self.bgr, self.levels, out=self.pyr[self.stride:], stride=self.stride)
+        with self._timed("halo_exchange", timed and self.world > 1):
+            self.exchange_halo()
+        with self._timed("hbma", timed):
+            native.hbma_pairs(self.pyr[t0 * self.stride:], self.pyr[(t0 + 1) * self.stride:], self.stride, p,
+                              self.levels, self.pw, self.ph, c.search_range, c.mv_block, c.mv_block,
+                              out=(self.mv, self.mad))
+        with self._timed("ransac", timed):
+            self.gm.zero_()
+            native.ransac_frames(self.mv, self.samples, out=(self.gm, self.rmse, self.mask, self.count), **self.ransac)
+        if self.segmentation:
+            with self._timed("segment", timed):
+                native.segment_frames(self.mask, self.mv, self.mfw, self.mfh, c.mv_block, seed=self.seg_seed,
+                                      out=self.types, workspace=self.seg_ws, **self.segment)
+        else:
+            with self._timed("block_types", timed):
+                native.block_types_frames(self.mask, out=self.types)
+        if c.dct_block:
+            f0 = self.first_encoded       # encoded frame of pair p is own frame first_encoded + p
+            with self._timed("dct_quant", timed):
+                if self.wire:
+                    native.dct_records_frames(self.bgr[f0:f0 + p], c.dct_block, self.types, c.mv_block,
+                                              c.fg_step, c.bg_step, out=self.records)
+                else:
+                    native.dct_quant_frames(self.bgr[f0:f0 + p], c.dct_block, self.types, c.mv_block,
+                                            c.fg_step, c.bg_step, out=self.coeffs)
         self._steps_timed += 1 if timed else 0

@@ -31,6 +31,39 @@ def test_header_symbols_are_exported():
     assert lib.svc_hip_abi_version() == 1
 
 
+def test_clip_header_symbols_are_exported():
+    """include/svc_clip.h (C handle API of svc::ClipEncoder) vs libsvc_motion.so vs the ctypes binding."""
+    from scalable_video_codec_amd import clip
+    lib = clip.load()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "svc_clip.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(svc_clip_\w+)\s*\(", text)) - {"svc_clip_halo_fn"})
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/svc_clip.h but not exported"
+    assert set(names) == set(clip.SIGNATURES), set(names) ^ set(clip.SIGNATURES)
+    assert ctypes.sizeof(clip.ClipConfig) == 120 and ctypes.sizeof(clip.ClipInfo) == 72  # struct layout of the header
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", native.MOTION_LIB_PATH], text=True)
+    for sym in ("svc::ClipEncoder::ClipEncoder(svc::ClipEncoderConfig const&)", "svc::ClipEncoder::Step(bool)",
+                "svc::PlanShard(unsigned int, unsigned int, unsigned int)", "svc::ClipEncoder::SetComm(void*)"):
+        assert sym in out, sym
+
+
+def test_clip_api_without_a_gpu():
+    """Host logic of the C++ driver: the shard plan, and a loud failure (no fallback) when no device is there."""
+    import torch
+    from scalable_video_codec_amd import clip, configs
+    assert clip.plan_shard(300, 8, 0) == (0, 38, 37, 1) and clip.plan_shard(300, 8, 3) == (114, 38, 38, 114)
+    assert clip.plan_shard(300, 8, 4) == (152, 37, 37, 152) and clip.plan_shard(300, 8, 7) == (263, 37, 37, 263)
+    assert clip.plan_shard(2, 2, 0) == (0, 1, 0, 1) and clip.plan_shard(2, 2, 1) == (1, 1, 1, 1)
+    with pytest.raises(clip.ClipError):
+        clip.plan_shard(10, 2, 2)
+    if not torch.cuda.is_available():
+        with pytest.raises(clip.ClipError, match="no ROCm-capable device|hipStreamCreate|invalid device"):
+            clip.Clip(configs.C3, 300)
+        with pytest.raises(native.SvcError):
+            clip.comm_create(bytes(128), 0, 1)  # RCCL cannot bring up a communicator without a device
+
+
 def test_motion_library_exports_reference_symbols():
     """Itanium-mangled names of the reference's public functions (nm -C of the compiled
     reference object) -- what apps/encoder.cpp links against."""

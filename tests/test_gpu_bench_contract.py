@@ -34,9 +34,37 @@ def test_bench_line_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    assert "not cv::dct" in c["dct_leg"] and c["dct_is_reference"] is False
     assert d["hbm_streaming_measured"]["read_only"] > 1000
+    assert not any(k.startswith("frac_of_streaming") for k in r)
+    assert "traffic_source" in r and d["config"]["driver"].startswith("svc::ClipEncoder")
+    assert set(d["kernel_ms_per_step"]) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
 
 
 def test_bench_other_config_and_flags():
     d = _run("--config", "C2-720p-3L-dct8", "--frames", "6", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--wire")
     assert "cpu_baseline" not in d and d["config"]["workload"] == "C2-720p-3L-dct8" and d["value"] > 0
+
+
+def test_bench_serial_schedule_and_graph():
+    d = _run("--frames", "10", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--schedule", "serial", "--no-hbm-probe")
+    assert "roofline" in d and "one stream" in d["config"]["schedule"]
+    g = _run("--frames", "10", "--steps", "6", "--warmup", "4", "--no-cpu-baseline", "--graph", "--no-hbm-probe")
+    assert "roofline" not in g and "hipGraph" in g["config"]["schedule"] and g["value"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """N = 2 end to end on ONE device (gloo rehearsal switch; RCCL refuses two ranks on a GPU): strong sharding of
+    the clip, halo through the encoder's transport hook, the halo self-check, the weak figure as second field."""
+    env = dict(os.environ, SVC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29513", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "9", "--steps", "3",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["clip_frames"] == 9
+    assert d["config"]["frames_per_gpu"] == [5, 4] and d["config"]["encoded_frames_per_step"] == 8
+    assert d["weak"]["clip_frames"] == 18 and d["weak"]["encoded_frames_per_step"] == 17 and d["weak"]["value"] > 0
+    assert d["halo_exchange_ms"] is not None

@@ -1,0 +1,185 @@
+"""svc::ClipEncoder (include/svc/clip_encoder.hpp) through its C handle API: the C++ driver of one rank's
+shard.  Checked here: every schedule (serial, pipelined, pipelined + hipGraph) gives the bytes of the
+stage-by-stage C-ABI calls; a clip cut into shards -- the halo moved by the encoder's own transport hook --
+encodes to exactly the unsharded clip; the RCCL entry points bind and move bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from scalable_video_codec_amd import clip as clipmod
+from scalable_video_codec_amd import configs, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+CFG = configs.CodecConfig("t-360p-3L-dct8", 41, 640, 360, 11, levels=3, dct_block=8)
+
+
+def _frames(cfg, n, dev):
+    src = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
+    pw, ph = cfg.padded
+    return torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph)
+                        for t in range(n)]).contiguous()
+
+
+def _reference_outputs(native, cfg, frames):
+    """The same clip through the stage-by-stage C-ABI calls of the Python harness (pipeline.ClipEncoder)."""
+    n = frames.shape[0]
+    ref = pipeline.ClipEncoder(cfg, n, frames.device)
+    ref.load_frames(list(frames))
+    ref.step()
+    torch.cuda.synchronize()
+    return ref
+
+
+def _assert_same(out, ref, coeffs=None):
+    assert torch.equal(out["mv"], ref.mv.cpu())
+    assert torch.equal(out["min_mad"], ref.mad.cpu())
+    assert out["global_motion"].numpy().tobytes() == ref.gm.cpu().numpy().tobytes()
+    assert out["rmse"].numpy().tobytes() == ref.rmse.cpu().numpy().tobytes()
+    assert torch.equal(out["inlier_mask"], ref.mask.cpu())
+    assert torch.equal(out["inlier_count"], ref.count.cpu())
+    assert torch.equal(out["block_types"], ref.types.cpu())
+    if coeffs is not None:
+        assert torch.equal(coeffs.view(ref.coeffs.shape), ref.coeffs.cpu())
+
+
+@pytest.mark.parametrize("schedule,graph,steps", [(clipmod.SERIAL, False, 1), (clipmod.SERIAL, False, 3),
+                                                   (clipmod.PIPELINED, False, 1), (clipmod.PIPELINED, False, 5),
+                                                   (clipmod.PIPELINED, True, 7)])
+def test_schedules_equal_stagewise_calls(native, schedule, graph, steps):
+    dev = torch.device("cuda")
+    n = CFG.frames
+    frames = _frames(CFG, n, dev)
+    ref = _reference_outputs(native, CFG, frames)
+    enc = clipmod.Clip(CFG, n, schedule=schedule, graph=graph)
+    assert (enc.info.frames, enc.info.pairs, enc.info.first_encoded, enc.info.needs_halo) == (n, n - 1, 1, 0)
+    enc.load_frames(frames)
+    for s in range(steps):
+        enc.step(timed=not graph)
+    enc.sync()
+    _assert_same(enc.outputs(), ref, enc.read("coeffs"))
+    if not graph:
+        t = enc.stage_times_ms()
+        assert set(t) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
+        assert all(ms > 0 and launches == steps for ms, launches in t.values())
+    enc.close()
+
+
+def test_wire_and_no_segmentation(native):
+    dev = torch.device("cuda")
+    n = 6
+    frames = _frames(CFG, n, dev)
+    ref = pipeline.ClipEncoder(CFG, n, dev, wire=True, segmentation=False)
+    ref.load_frames(list(frames))
+    ref.step()
+    torch.cuda.synchronize()
+    enc = clipmod.Clip(CFG, n, wire=True, segmentation=False)
+    enc.load_frames(frames)
+    enc.step()
+    enc.step()
+    enc.sync()
+    assert torch.equal(enc.read("block_types").view(n - 1, -1), ref.types.cpu())
+    assert torch.equal(enc.read("records").view(ref.records.shape), ref.records.cpu())
+
+
+_hip = None
+
+
+def _hip_memcpy_async(dst, src, nbytes, stream):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so.7")  # the HIP runtime already in the process
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rc = _hip.hipMemcpyAsync(dst, src, nbytes, 3, stream)  # hipMemcpyDeviceToDevice
+    assert rc == 0, rc
+
+
+@pytest.mark.parametrize("world,total,schedule", [(2, 11, clipmod.SERIAL), (3, 11, clipmod.PIPELINED), (4, 5, clipmod.PIPELINED),
+                                                  (4, 4, clipmod.SERIAL), (8, 11, clipmod.PIPELINED)])
+def test_sharded_clip_equals_unsharded(native, world, total, schedule):
+    """All ranks of a sharded clip in ONE process: rank r's halo transport copies rank r - 1's last pyramid (the
+    bytes RCCL would deliver).  Concatenated shard outputs == the unsharded clip's, bit for bit -- uneven shards,
+    a rank with a single frame, rank 0 with a single frame (no pair at all) included."""
+    dev = torch.device("cuda")
+    frames = _frames(CFG, total, dev)
+    whole = clipmod.Clip(CFG, total, schedule=clipmod.SERIAL)
+    whole.load_frames(frames)
+    whole.step()
+    whole.sync()
+    want = whole.outputs()
+    per = 3 * whole.info.padded_w * whole.info.padded_h
+    want_coeffs = whole.read("coeffs").view(total - 1, per)
+    steps = 1 if schedule == clipmod.SERIAL else 4
+    got = {k: [] for k in want}
+    got_coeffs = []
+    prev = None
+    seen_pairs = 0
+    for r in range(world):
+        enc = clipmod.Clip(CFG, total, rank=r, world=world, schedule=schedule)
+        i = enc.info
+        assert (i.first_frame, i.frames, i.pairs, i.first_encoded) == clipmod.plan_shard(total, world, r)
+        assert i.first_encoded - 1 == seen_pairs
+        enc.load_frames(frames[i.first_frame:i.first_frame + i.frames].contiguous())
+        calls = []
+
+        def transport(send, recv, nbytes, stream, r=r, prev=prev, calls=calls, stride=i.pyramid_stride):
+            assert nbytes == stride and send
+            calls.append(r)
+            if r > 0:  # what rank r - 1 sends: its last pyramid, finished and synced below
+                src, have = C.c_void_p(), C.c_uint64()
+                clipmod._check(clipmod.load().svc_clip_output(prev._h, clipmod.BUFFERS["pyramids"][0], C.byref(src), C.byref(have)))
+                _hip_memcpy_async(recv, src.value + prev.info.frames * stride, nbytes, stream)
+        enc.set_halo_transport(transport)
+        for _ in range(steps):
+            enc.step()
+        enc.sync()
+        assert len(calls) == steps
+        o = enc.outputs()
+        for k in want:
+            got[k].append(o[k])
+        got_coeffs.append(enc.read("coeffs").view(i.pairs, per))
+        seen_pairs += i.pairs
+        prev = enc
+    assert seen_pairs == total - 1
+    for k in want:
+        assert torch.equal(torch.cat(got[k]), want[k]), k
+    assert torch.equal(torch.cat(got_coeffs), want_coeffs)
+
+
+def test_world_needs_a_transport(native):
+    enc = clipmod.Clip(CFG, 6, rank=1, world=2)
+    enc.load_frames(_frames(CFG, 6, torch.device("cuda"))[3:6].contiguous())
+    with pytest.raises(clipmod.ClipError, match="SetComm"):
+        enc.step()
+
+
+def test_rccl_entry_points_move_bytes(native):
+    """One rank, cyclic shift = a send to and a receive from itself through RCCL: the library binds at run time,
+    a communicator comes up on this GPU, the group enqueues on the caller's stream."""
+    dev = torch.device("cuda")
+    uid = clipmod.comm_unique_id()
+    assert len(uid) == clipmod.COMM_ID_BYTES and any(uid)
+    comm = clipmod.comm_create(uid, 0, 1)
+    try:
+        n = 2_741_760  # one C3 pyramid
+        send = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
+        recv = torch.zeros(n, dtype=torch.uint8, device=dev)
+        clipmod.halo_shift(comm, send, recv, n, 0, 1)  # non-cyclic, single rank: no neighbour, nothing moves
+        torch.cuda.synchronize()
+        assert int(recv.max()) == 0
+        clipmod.halo_shift(comm, send, recv, n, 0, 1, cyclic=True)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        clipmod.comm_destroy(comm)
+
+
+def test_invalid_configurations(native):
+    with pytest.raises(clipmod.ClipError):
+        clipmod.Clip(CFG, 1)  # a clip needs two frames
+    with pytest.raises(clipmod.ClipError):
+        clipmod.Clip(CFG, 3, rank=0, world=4)  # fewer frames than ranks
+    with pytest.raises(clipmod.ClipError):
+        clipmod.Clip(CFG, 8, rank=2, world=2)

@@ -99,9 +99,9 @@ def test_dct_energy_dc_and_quant_properties(native, encoded):
     assert bool((bgc % cfg.bg_step == 0).all())
 
 
-def test_chunked_schedule_and_wire_mode_agree_with_the_plain_step(native):
-    """The two-stream chunked schedule and the fused record output are scheduling / layout choices:
-    every output must be identical to the single-launch planar step."""
+def test_wire_mode_agrees_with_the_plain_step(native):
+    """The fused record output is a layout choice: the records must be the planar step's coefficients serialised
+    (schedules -- serial, pipelined, hipGraph -- are checked in tests/test_gpu_clip.py)."""
     cfg = configs.C2
     dev = torch.device("cuda")
     n = 9
@@ -111,22 +111,10 @@ def test_chunked_schedule_and_wire_mode_agree_with_the_plain_step(native):
     base = pipeline.ClipEncoder(cfg, n, dev)
     base.load_frames(frames)
     base.step()
-    chunked = pipeline.ClipEncoder(cfg, n, dev)
-    chunked.load_frames(frames)
-    chunked.step(chunks=3)
     wired = pipeline.ClipEncoder(cfg, n, dev, wire=True)
     wired.load_frames(frames)
     wired.step()
     torch.cuda.synchronize()
-    piped = pipeline.ClipEncoder(cfg, n, dev)
-    piped.load_frames(frames)
-    for _ in range(3):  # three passes in flight across the two streams
-        piped.step_overlapped()
-    piped.finish_overlapped()
-    torch.cuda.synchronize()
-    for name in ("mv", "mad", "gm", "rmse", "mask", "count", "types", "coeffs"):
-        assert torch.equal(getattr(base, name), getattr(chunked, name)), name
-        assert torch.equal(getattr(base, name), getattr(piped, name)), f"overlapped {name}"
     assert torch.equal(base.types, wired.types)
     want = native.serialize_frames(base.coeffs, base.types, pw, ph, 8, 8, base.mfw, base.mfh)
     assert torch.equal(wired.records, want)
