@@ -53,7 +53,8 @@ struct ClipEncoderConfig {
   uint32_t search_range = 8;
   uint32_t dct_block_w = 8, dct_block_h = 8;  // transform block; 0 = no transform
   uint32_t fg_step = 1, bg_step = 640;        // apps/decoder.cpp:22-23
-  bool wire = false;          // serialised records (libs/encoder.cpp:222-269) instead of planes
+  bool wire = false;          // serialised records (libs/encoder.cpp:222-269) of the RAW coefficients, as the
+                              // reference's encoder emits them, instead of quantised planes
   bool segmentation = true;   // false: region ids from the in-repo part only (foreground = one region)
   uint64_t seed = 0;
   svc_ransac_params ransac{1, 7.5f, 0.99f, 0.5f};

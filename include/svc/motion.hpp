@@ -61,6 +61,27 @@ void EstimateGlobalMotionRansac(const Vec2f* motion_field, uint motion_field_sz,
                                 Vec2f* global_motion,
                                 std::vector<uint>* inlier_indices);
 
+// libs/motion.hpp:38 / motion.cpp:45-53: the f32 running mean, bit for bit.
+Vec2f EstimateGlobalMotionAvg(const Vec2f* motion_field, uint sz);
+
+// libs/motion.hpp:45-49 / motion.cpp:55-99.  DEVIATION: the reference's loops compare
+// `int dy <= uint search_range` (motion.cpp:72, :81), so for search_range > 0 they never run and
+// it returns {0, 0} and FLT_MAX whatever the frames hold.  This is the search the code evidently
+// means: every (dx, dy) in [-R, R]^2, MAD of the overlap, strict `<` in raster order.  With
+// search_range == 0 both give the whole-frame MAD at zero displacement.
+void EstimateGlobalMotionExhaustiveSearch(const uchar* tracked_frame,
+                                          const uchar* anchor_frame, uint frame_w,
+                                          uint frame_h, uint search_range,
+                                          Vec2f* global_motion, float* min_mad);
+
+// libs/motion.hpp:55-59 / motion.cpp:101-142, on top of the search above (same deviation): top
+// level with range / 2^(L-1), then gm = 2 gm + (a +-1 search around zero) per finer level.
+void EstimateGlobalMotionHierarchical(const uchar* const* tracked_pyramid,
+                                      const uchar* const* anchor_pyramid,
+                                      uint num_levels, uint base_frame_w,
+                                      uint base_frame_h, uint base_search_range,
+                                      Vec2f* global_motion);
+
 // ---- additions (no counterpart in the reference's headers) -------------------
 
 // Makes this thread's RANSAC draws reproducible.

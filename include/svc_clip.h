@@ -31,7 +31,7 @@ typedef struct svc_clip_config {
   uint32_t levels, mv_block, search_range;
   uint32_t dct_block_w, dct_block_h; /* 0 = no transform */
   uint32_t fg_step, bg_step;
-  uint32_t wire;         /* 1: serialised records (libs/encoder.cpp:222-269) instead of planes */
+  uint32_t wire;         /* 1: serialised records (libs/encoder.cpp:222-269) of the raw coefficients instead of quantised planes */
   uint32_t segmentation; /* 0: in-repo part only (foreground = one region) */
   uint64_t seed;
   svc_ransac_params ransac;

@@ -113,7 +113,9 @@ int svc_hip_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor,
  * EstimateGlobalMotionRansac, libs/motion.hpp:100-103 / motion.cpp:182-266, with
  * the random draws made explicit: d_samples is [n_frames][iter_count][subset_sz]
  * accepted sample indices (each < blocks; the reference's inclusive upper bound,
- * motion.cpp:208, is an out-of-bounds read and is not reproduced).
+ * motion.cpp:208, is an out-of-bounds read and is not reproduced: svc_hip_ransac_host
+ * rejects such an index, and the device form, which cannot inspect d_samples, reads
+ * entry blocks - 1 for it, so no draw ever leaves the frame's own field).
  * Outputs per frame: d_gm_xy [2] (in/out, see motion.cpp:241-242), d_rmse,
  * d_inlier_mask [blocks] u8 (1 = inlier, i.e. background; the ascending index
  * list of motion.cpp:261-265 is the positions of the 1s), d_inlier_count.
@@ -156,7 +158,11 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy,
  * d_bgr + f * frame_stride_bytes.  d_planes: [n_frames][3][H][W] f32, plane order
  * B,G,R (cv::split, encoder.cpp:328); coefficient (v,u) of the tile at (x,y) is at
  * row y+v, column x+u (in-place cv::dct on the ROI, encoder.cpp:330-337).
- * block_w/block_h in {8, 16}, dividing W and H.
+ * block_w x block_h: any transform block the reference's Validate admits (libs/encoder.cpp:62-142)
+ * and cv::dct implements -- even sides, or a single row / column of even length -- dividing W and
+ * H, up to 64 x 64; 8x8 and 16x16 on frames a multiple of 16 wide take the tuned kernels (and ask
+ * for 16-byte aligned frames), every other shape a general one.  An odd side is
+ * SVC_ERR_INVALID_ARG (cv::dct asserts there), a side above 64 SVC_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------- */
 
 /* replaces static Dct, libs/encoder.cpp:323-339 */
@@ -278,6 +284,32 @@ int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_byte
                                 void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Whole-frame global motion: the three estimators of libs/motion.hpp:38-59.  No caller in the
+ * reference (the encoder uses RANSAC); kept so that the replacement library is complete.
+ *  - exhaustive: MAD (libs/motion.cpp:17-43, 32-bit sums) of the overlap of the two frames
+ *    shifted by (dx, dy) for dy, dx in [-R, R], raster order, strict `<` (first minimum);
+ *    outputs {dx, dy} and the minimum MAD.  DEVIATION: the reference's loops compare an int with
+ *    an unsigned (motion.cpp:72, :81) and never run for R > 0 -- it always returns {0, 0},
+ *    FLT_MAX; this is the function as evidently meant.  R must be smaller than both frame sides.
+ *  - hierarchical (motion.cpp:101-142): exhaustive search on the top level with R / 2^(L-1), then
+ *    per finer level gm = 2 gm + (a +-1 exhaustive search around zero), as written there.
+ *  - average (motion.cpp:45-53): the f32 running mean avg += (mv[i] - avg) * (1 / (i + 1)).
+ * d_workspace: svc_hip_global_ebma_workspace_bytes() bytes, 8-byte aligned.
+ * ------------------------------------------------------------------------- */
+uint64_t svc_hip_global_ebma_workspace_bytes(uint32_t search_range, uint32_t n_pairs);
+
+/* replaces EstimateGlobalMotionExhaustiveSearch, libs/motion.hpp:45-49, batched over pairs */
+int svc_hip_global_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor,
+                              uint64_t pair_stride_bytes, uint32_t n_pairs, uint32_t frame_w,
+                              uint32_t frame_h, uint32_t search_range, uint8_t* d_workspace,
+                              uint64_t workspace_bytes, float* d_gm_xy, float* d_min_mad,
+                              void* stream);
+
+/* replaces EstimateGlobalMotionAvg, libs/motion.hpp:38, batched: d_avg_xy [n_frames][2] */
+int svc_hip_global_avg_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
+                              float* d_avg_xy, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Multi-GPU: frames shard as consecutive chunks, one per rank, and the only
  * cross-rank dependency is the reference's only cross-frame state -- the previous SOURCE
  * frame's Y pyramid (libs/encoder.cpp:661-663).  Rank r therefore sends the packed pyramid of
@@ -334,6 +366,18 @@ int svc_hip_dct_quant_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_
                            float* planes);
 
 int svc_hip_quant_host(float* coeffs, uint64_t n, uint32_t step);
+
+int svc_hip_global_ebma_host(const uint8_t* tracked, const uint8_t* anchor, uint32_t frame_w,
+                             uint32_t frame_h, uint32_t search_range, float* gm_xy,
+                             float* min_mad);
+
+/* replaces EstimateGlobalMotionHierarchical, libs/motion.hpp:55-59 */
+int svc_hip_global_hbma_host(const uint8_t* const* tracked_pyr,
+                             const uint8_t* const* anchor_pyr, uint32_t level_count,
+                             uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                             float* gm_xy);
+
+int svc_hip_global_avg_host(const float* mv_xy, uint32_t blocks, float* avg_xy);
 
 #ifdef __cplusplus
 }

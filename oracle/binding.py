@@ -68,6 +68,12 @@ class Oracle:
                                         _f32p, _f32p, _u32p, _u32p]
         L.svc_oracle_fg_mask.restype = None
         L.svc_oracle_fg_mask.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_global_avg.restype = None
+        L.svc_oracle_global_avg.argtypes = [_f32p, C.c_uint32, _f32p]
+        L.svc_oracle_global_ebma.restype = None
+        L.svc_oracle_global_ebma.argtypes = [_u8p, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _f32p, _f32p]
+        L.svc_oracle_global_hbma.restype = None
+        L.svc_oracle_global_hbma.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 4 + [C.c_int, _f32p]
         L.svc_oracle_segment.restype = C.c_int
         L.svc_oracle_segment.argtypes = [_u8p, _f32p] + [C.c_uint32] * 9 + [C.c_float, C.c_uint32, C.c_uint64, _u32p]
         L.svc_oracle_serialize_frame.restype = C.c_uint64
@@ -126,6 +132,27 @@ class Oracle:
         if rc:
             raise ValueError("svc_oracle_hbma16_sse2: precondition violated")
         return mv, mad
+
+    # -- whole-frame global motion (libs/motion.cpp:45-142) --
+    def global_avg(self, mv):
+        mv = np.ascontiguousarray(mv, np.float32)
+        out = np.zeros(2, np.float32)
+        self.lib.svc_oracle_global_avg(_ptr(mv, _f32p), len(mv), _ptr(out, _f32p))
+        return out
+
+    def global_ebma(self, tracked, anchor, r, reference_loop=False):
+        h, w = tracked.shape
+        gm, mad = np.zeros(2, np.float32), np.zeros(1, np.float32)
+        self.lib.svc_oracle_global_ebma(_ptr(np.ascontiguousarray(tracked), _u8p), _ptr(np.ascontiguousarray(anchor), _u8p),
+                                        w, h, r, int(reference_loop), _ptr(gm, _f32p), _ptr(mad, _f32p))
+        return gm, mad[0]
+
+    def global_hbma(self, tracked_pyr, anchor_pyr, r, reference_loop=False):
+        h, w = tracked_pyr[0].shape
+        gm = np.zeros(2, np.float32)
+        self.lib.svc_oracle_global_hbma(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr), len(tracked_pyr), w, h, r,
+                                        int(reference_loop), _ptr(gm, _f32p))
+        return gm
 
     # -- RANSAC --
     def ransac_iter_count(self, **p) -> int:
@@ -271,6 +298,31 @@ class Reference:
         self.lib.svc_ref_hbma16_sse2(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr), w, h, r,
                                      _ptr(mv, _f32p), _ptr(mad, _f32p))
         return mv, mad
+
+    def global_avg(self, mv):
+        mv = np.ascontiguousarray(mv, np.float32)
+        out = np.zeros(2, np.float32)
+        self.lib.svc_ref_global_avg.restype = None
+        self.lib.svc_ref_global_avg.argtypes = [_f32p, C.c_uint32, _f32p]
+        self.lib.svc_ref_global_avg(_ptr(mv, _f32p), len(mv), _ptr(out, _f32p))
+        return out
+
+    def global_ebma(self, tracked, anchor, r):
+        h, w = tracked.shape
+        gm, mad = np.zeros(2, np.float32), np.zeros(1, np.float32)
+        self.lib.svc_ref_global_ebma.restype = None
+        self.lib.svc_ref_global_ebma.argtypes = [_u8p, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, _f32p, _f32p]
+        self.lib.svc_ref_global_ebma(_ptr(np.ascontiguousarray(tracked), _u8p), _ptr(np.ascontiguousarray(anchor), _u8p), w, h, r,
+                                     _ptr(gm, _f32p), _ptr(mad, _f32p))
+        return gm, mad[0]
+
+    def global_hbma(self, tracked_pyr, anchor_pyr, r):
+        h, w = tracked_pyr[0].shape
+        gm = np.zeros(2, np.float32)
+        self.lib.svc_ref_global_hbma.restype = None
+        self.lib.svc_ref_global_hbma.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 4 + [_f32p]
+        self.lib.svc_ref_global_hbma(_pyr_ptrs(tracked_pyr), _pyr_ptrs(anchor_pyr), len(tracked_pyr), w, h, r, _ptr(gm, _f32p))
+        return gm
 
     def ransac(self, mv_n_plus_1, n, gm_in=(0.0, 0.0), **p):
         """`mv_n_plus_1` holds n + 1 vectors (the reference may read entry n)."""

@@ -70,6 +70,23 @@ void svc_ref_hbma16_sse2(const uint8_t* const* tracked_pyr,
 #endif
 }
 
+// The three whole-frame estimators (libs/motion.hpp:38-59); no caller in the reference.
+void svc_ref_global_avg(const float* mv_xy, uint32_t n, float* avg_xy) {
+  Vec2f a = EstimateGlobalMotionAvg(reinterpret_cast<const Vec2f*>(mv_xy), n);
+  avg_xy[0] = a.x;
+  avg_xy[1] = a.y;
+}
+
+void svc_ref_global_ebma(const uint8_t* tracked, const uint8_t* anchor, uint32_t w, uint32_t h,
+                         uint32_t r, float* gm_xy, float* min_mad) {
+  EstimateGlobalMotionExhaustiveSearch(tracked, anchor, w, h, r, reinterpret_cast<Vec2f*>(gm_xy), min_mad);
+}
+
+void svc_ref_global_hbma(const uint8_t* const* tracked_pyr, const uint8_t* const* anchor_pyr,
+                         uint32_t levels, uint32_t w, uint32_t h, uint32_t r, float* gm_xy) {
+  EstimateGlobalMotionHierarchical(tracked_pyr, anchor_pyr, levels, w, h, r, reinterpret_cast<Vec2f*>(gm_xy));
+}
+
 // Runs the reference RANSAC.  `mv_xy` must hold n + 1 vectors: the reference
 // draws indices from [0, n] inclusive (motion.cpp:208) and so may read entry n.
 // `gm_xy` is in/out (the reference reads it uninitialised at :241-242).

@@ -42,6 +42,72 @@ float svc_oracle_mad(const uint8_t* a_frame, const uint8_t* b_frame,
   return (float)sad / (float)count; /* :38-40 */
 }
 
+/* ---- whole-frame global motion (no caller in the reference) ------------- */
+
+/* libs/motion.cpp:45-53 */
+void svc_oracle_global_avg(const svc_oracle_vec2f* mv, uint32_t n, svc_oracle_vec2f* avg) {
+  float ax = 0.0f, ay = 0.0f; /* Vec2f avg = {} */
+  for (uint32_t i = 0; i < n; ++i) {
+    float r = 1.0f / (float)(i + 1); /* 1.0f / (i + 1): unsigned -> float, f32 divide */
+    ax = ax + (mv[i].x - ax) * r;    /* avg += (mv - avg) * r, componentwise (math.hpp) */
+    ay = ay + (mv[i].y - ay) * r;
+  }
+  avg->x = ax;
+  avg->y = ay;
+}
+
+/* libs/motion.cpp:55-99 */
+void svc_oracle_global_ebma(const uint8_t* tracked, const uint8_t* anchor, uint32_t w,
+                            uint32_t h, uint32_t search_range, int reference_loop,
+                            svc_oracle_vec2f* gm, float* min_mad) {
+  gm->x = 0.0f; /* :66 */
+  gm->y = 0.0f;
+  *min_mad = FLT_MAX; /* :67 */
+  const int r = (int)search_range;
+  for (int dy = -r;; ++dy) {
+    /* :72 `dy <= search_range` with dy int, search_range unsigned */
+    if (reference_loop ? !((unsigned)dy <= search_range) : !(dy <= r)) break;
+    uint32_t ty0 = (uint32_t)(dy > 0 ? dy : 0);              /* Max(0, dy) :73 */
+    uint32_t ty1 = (uint32_t)((int)h + (dy < 0 ? dy : 0));    /* :74 */
+    uint32_t bh = ty1 - ty0;                                  /* :76 */
+    uint32_t ay0 = (uint32_t)((int)ty0 - dy);                 /* :79 */
+    for (int dx = -r;; ++dx) {
+      if (reference_loop ? !((unsigned)dx <= search_range) : !(dx <= r)) break; /* :81 */
+      uint32_t tx0 = (uint32_t)(dx > 0 ? dx : 0);
+      uint32_t tx1 = (uint32_t)((int)w + (dx < 0 ? dx : 0));
+      uint32_t bw = tx1 - tx0;
+      uint32_t ax0 = (uint32_t)((int)tx0 - dx);
+      float mad = svc_oracle_mad(tracked, anchor, w, tx0, ty0, ax0, ay0, bw, bh); /* :89-90 */
+      if (mad < *min_mad) { /* :92 strict: the first minimum in raster order stays */
+        *min_mad = mad;
+        gm->x = (float)dx;
+        gm->y = (float)dy;
+      }
+    }
+  }
+}
+
+/* libs/motion.cpp:101-142 */
+void svc_oracle_global_hbma(const uint8_t* const* tracked_pyr,
+                            const uint8_t* const* anchor_pyr, uint32_t levels, uint32_t w,
+                            uint32_t h, uint32_t search_range, int reference_loop,
+                            svc_oracle_vec2f* gm) {
+  uint32_t f = 1;
+  for (uint32_t i = 0; i + 1 < levels; ++i) f <<= 1; /* :114-117 */
+  uint32_t fw = w / f, fh = h / f;
+  float mm;
+  svc_oracle_global_ebma(tracked_pyr[levels - 1], anchor_pyr[levels - 1], fw, fh,
+                         search_range / f, reference_loop, gm, &mm); /* :124-129 */
+  for (int l = (int)levels - 2; l >= 0; --l) {
+    svc_oracle_vec2f corr;
+    fh *= 2;
+    fw *= 2;
+    svc_oracle_global_ebma(tracked_pyr[l], anchor_pyr[l], fw, fh, 1, reference_loop, &corr, &mm); /* :136-138 */
+    gm->x = 2.0f * gm->x + corr.x; /* :140 */
+    gm->y = 2.0f * gm->y + corr.y;
+  }
+}
+
 /* libs/motion.cpp:472-510 (Mad16x16Sse2): two row pairs per step, two
  * independent psadbw accumulators, horizontal add, divide by 256.0f. */
 static inline float mad16_sse2(const uint8_t* a, const uint8_t* b,

@@ -93,6 +93,28 @@ void svc_oracle_ransac(const svc_oracle_vec2f* motion_field, uint32_t n,
                        svc_oracle_vec2f* global_motion, uint32_t* inliers,
                        uint32_t* inlier_count);
 
+/* libs/motion.cpp:45-53 (EstimateGlobalMotionAvg): the f32 running mean. */
+void svc_oracle_global_avg(const svc_oracle_vec2f* motion_field, uint32_t n,
+                           svc_oracle_vec2f* avg);
+
+/*
+ * libs/motion.cpp:55-99 (EstimateGlobalMotionExhaustiveSearch).  reference_loop != 0 keeps
+ * the reference's loop conditions `int dy <= unsigned search_range` (:72, :81) literally: the
+ * signed operand converts to unsigned, so for search_range > 0 no candidate is ever visited
+ * and the outputs stay {0, 0}, FLT_MAX -- that form is pinned against the compiled reference.
+ * reference_loop == 0 runs dy, dx over [-R, R] as evidently meant; that form is the checker
+ * of the product's EstimateGlobalMotionExhaustiveSearch (a documented deviation).
+ */
+void svc_oracle_global_ebma(const uint8_t* tracked, const uint8_t* anchor, uint32_t w,
+                            uint32_t h, uint32_t search_range, int reference_loop,
+                            svc_oracle_vec2f* global_motion, float* min_mad);
+
+/* libs/motion.cpp:101-142 (EstimateGlobalMotionHierarchical) over the search above. */
+void svc_oracle_global_hbma(const uint8_t* const* tracked_pyr,
+                            const uint8_t* const* anchor_pyr, uint32_t levels, uint32_t w,
+                            uint32_t h, uint32_t search_range, int reference_loop,
+                            svc_oracle_vec2f* global_motion);
+
 /* libs/encoder.cpp:507-513: fg mask = 255 everywhere except RANSAC inliers. */
 void svc_oracle_fg_mask(const uint32_t* inliers, uint32_t inlier_count,
                         uint32_t n, uint8_t* mask);

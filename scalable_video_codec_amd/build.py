@@ -23,7 +23,7 @@ OBJ = os.path.join(PKG, "_obj")
 LIB_HIP = os.path.join(PKG, "libsvc_hip.so")
 LIB_MOTION = os.path.join(PKG, "libsvc_motion.so")
 
-HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip"]
+HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip", "global_motion.hip"]
 HOST_SOURCES = [os.path.join("host", "motion_hip.cpp")]
 
 # -ffp-contract=off: the reference's float expressions (RANSAC inlier test, quant) are

@@ -259,13 +259,24 @@ static int validate_dct(const void* in, const void* out, uint32_t w, uint32_t h,
   return SVC_OK;
 }
 
+// The 8x8 / 16x16 kernels load 16-byte vectors and store float2; the general kernel has no such needs.
+static int validate_dct_alignment(const uint8_t* d_bgr, uint64_t frame_stride, const float* d_planes, uint32_t w, uint32_t bw,
+                                  uint32_t bh) {
+  if (bw == bh && (bw == 8 || bw == 16) && w % 16 == 0)
+    SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride % 16 == 0 && aligned(d_planes, 8),
+                "dct: frames must be 16-byte aligned (stride too), planes 8-byte aligned");
+  else
+    SVC_REQUIRE(aligned(d_planes, 4), "dct: planes must be 4-byte aligned");
+  return SVC_OK;
+}
+
 int svc_hip_dct_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                        uint32_t frame_h, uint32_t block_w, uint32_t block_h, float* d_planes, void* stream) {
   if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block_w, block_h);
   if (rc) return rc;
-  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_planes, 8),
-              "dct: frames must be 16-byte aligned (stride too), planes 8-byte aligned");
+  rc = validate_dct_alignment(d_bgr, frame_stride_bytes, d_planes, frame_w, block_w, block_h);
+  if (rc) return rc;
   return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block_w, block_h, nullptr, 0, 0, 1, 1,
                     false, d_planes, static_cast<hipStream_t>(stream));
 }
@@ -284,8 +295,8 @@ int svc_hip_dct_quant_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, 
                   frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
               "dct_quant: MV block %ux%u must be a multiple of the transform block %ux%u and divide the frame",
               mv_block_w, mv_block_h, block_w, block_h);
-  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_planes, 8),
-              "dct: frames must be 16-byte aligned (stride too), planes 8-byte aligned");
+  rc = validate_dct_alignment(d_bgr, frame_stride_bytes, d_planes, frame_w, block_w, block_h);
+  if (rc) return rc;
   return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block_w, block_h, d_block_types,
                     mv_block_w, mv_block_h, fg_step, bg_step, true, d_planes, static_cast<hipStream_t>(stream));
 }
@@ -379,6 +390,38 @@ int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_byte
 }
 
 // ---- host-pointer forms -----------------------------------------------------------
+
+// ---- whole-frame global motion (libs/motion.hpp:38-59), see global_motion.hip ---------------------
+static int validate_global_ebma(uint32_t w, uint32_t h, uint32_t range) {
+  SVC_REQUIRE(w > 0 && h > 0, "global ebma: frame %ux%u must be positive", w, h);
+  // motion.cpp:63-64 asserts range <= frame; at range == frame the overlap is empty (0 / 0 in Mad)
+  SVC_REQUIRE(range < w && range < h, "global ebma: search range %u must be smaller than the frame %ux%u (motion.cpp:63-64)", range, w, h);
+  SVC_REQUIRE(range <= 1024, "global ebma: search range %u out of range", range);
+  return SVC_OK;
+}
+
+uint64_t svc_hip_global_ebma_workspace_bytes(uint32_t search_range, uint32_t n_pairs) {
+  return global_ebma_workspace_bytes(search_range, n_pairs);
+}
+
+int svc_hip_global_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride_bytes, uint32_t n_pairs,
+                              uint32_t frame_w, uint32_t frame_h, uint32_t search_range, uint8_t* d_workspace,
+                              uint64_t workspace_bytes, float* d_gm_xy, float* d_min_mad, void* stream) {
+  if (n_pairs == 0) return SVC_OK;
+  SVC_REQUIRE(d_tracked && d_anchor && d_gm_xy && d_workspace, "global ebma: null pointer (motion.cpp:58-61)");
+  int rc = validate_global_ebma(frame_w, frame_h, search_range);
+  if (rc) return rc;
+  SVC_REQUIRE(workspace_bytes >= global_ebma_workspace_bytes(search_range, n_pairs) && aligned(d_workspace, 8),
+              "global ebma: workspace too small or not 8-byte aligned");
+  return launch_global_ebma(d_tracked, d_anchor, pair_stride_bytes, n_pairs, frame_w, frame_h, search_range, d_workspace,
+                            d_gm_xy, d_min_mad, false, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_global_avg_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames, float* d_avg_xy, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  SVC_REQUIRE(d_mv_xy && d_avg_xy, "global avg: null pointer (motion.cpp:46)");
+  return launch_global_avg(d_mv_xy, blocks, n_frames, d_avg_xy, static_cast<hipStream_t>(stream));
+}
 
 int svc_hip_hbma_host(const uint8_t* const* tracked_pyr, const uint8_t* const* anchor_pyr, uint32_t level_count,
                       uint32_t frame_w, uint32_t frame_h, uint32_t search_range, uint32_t block_w,
@@ -534,6 +577,86 @@ int svc_hip_quant_host(float* coeffs, uint64_t n, uint32_t step) {
   SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin, g_stage.dev, n * 4, hipMemcpyDeviceToHost, g_stage.stream));
   SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
   std::memcpy(coeffs, g_stage.pin, n * 4);
+  return SVC_OK;
+}
+
+int svc_hip_global_ebma_host(const uint8_t* tracked, const uint8_t* anchor, uint32_t frame_w, uint32_t frame_h,
+                             uint32_t search_range, float* gm_xy, float* min_mad) {
+  SVC_REQUIRE(tracked && anchor && gm_xy && min_mad, "global ebma: null pointer (motion.cpp:58-61)");
+  int rc = validate_global_ebma(frame_w, frame_h, search_range);
+  if (rc) return rc;
+  if ((rc = require_device())) return rc;
+  const size_t plane = up256((size_t)frame_w * frame_h), ws = up256(global_ebma_workspace_bytes(search_range, 1));
+  if ((rc = g_stage.ensure(2 * plane + ws + 256))) return rc;
+  std::memcpy(g_stage.pin, tracked, (size_t)frame_w * frame_h);
+  std::memcpy(g_stage.pin + plane, anchor, (size_t)frame_w * frame_h);
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, 2 * plane, hipMemcpyHostToDevice, g_stage.stream));
+  float* d_out = reinterpret_cast<float*>(g_stage.dev + 2 * plane + ws);
+  rc = launch_global_ebma(g_stage.dev, g_stage.dev + plane, plane, 1, frame_w, frame_h, search_range, g_stage.dev + 2 * plane,
+                          d_out, d_out + 2, false, g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin, d_out, 12, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(gm_xy, g_stage.pin, 8);
+  std::memcpy(min_mad, g_stage.pin + 8, 4);
+  return SVC_OK;
+}
+
+// motion.cpp:101-142: exhaustive search on the top level with range / 2^(L-1), then on every finer level a +-1 search
+// around ZERO displacement whose result is added to twice the running estimate (:132-140) -- as written there.
+int svc_hip_global_hbma_host(const uint8_t* const* tracked_pyr, const uint8_t* const* anchor_pyr, uint32_t level_count,
+                             uint32_t frame_w, uint32_t frame_h, uint32_t search_range, float* gm_xy) {
+  SVC_REQUIRE(tracked_pyr && anchor_pyr && gm_xy, "global hbma: null pointer (motion.cpp:106-108)");
+  SVC_REQUIRE(level_count > 0 && level_count <= 16, "global hbma: level count %u (motion.cpp:110)", level_count);
+  const uint32_t f = 1u << (level_count - 1);
+  SVC_REQUIRE(frame_w % f == 0 && frame_h % f == 0 && frame_w / f > 0 && frame_h / f > 0,
+              "global hbma: frame %ux%u must be divisible by 2^(levels-1) = %u", frame_w, frame_h, f);
+  for (uint32_t l = 0; l < level_count; ++l)
+    SVC_REQUIRE(tracked_pyr[l] && anchor_pyr[l], "global hbma: null plane at level %u", l);
+  const uint32_t top_range = search_range / f;  // :125
+  int rc = validate_global_ebma(frame_w / f, frame_h / f, top_range);
+  if (rc) return rc;
+  if (level_count > 1 && (rc = validate_global_ebma(frame_w >> (level_count - 2), frame_h >> (level_count - 2), 1))) return rc;
+  if ((rc = require_device())) return rc;
+  const size_t pyr = up256(pyramid_bytes(frame_w, frame_h, level_count));
+  const size_t ws = up256(global_ebma_workspace_bytes(top_range > 1 ? top_range : 1, 1));
+  if ((rc = g_stage.ensure(2 * pyr + ws + 256))) return rc;
+  size_t o = 0;
+  for (uint32_t l = 0; l < level_count; ++l) {
+    const size_t n = (size_t)(frame_w >> l) * (frame_h >> l);
+    std::memcpy(g_stage.pin + o, tracked_pyr[l], n);
+    std::memcpy(g_stage.pin + pyr + o, anchor_pyr[l], n);
+    o += n;
+  }
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, 2 * pyr, hipMemcpyHostToDevice, g_stage.stream));
+  float* d_gm = reinterpret_cast<float*>(g_stage.dev + 2 * pyr + ws);
+  for (int l = (int)level_count - 1; l >= 0; --l) {
+    o -= (size_t)(frame_w >> l) * (frame_h >> l);  // offset of level l inside a packed pyramid
+    const bool top = l == (int)level_count - 1;
+    rc = launch_global_ebma(g_stage.dev + o, g_stage.dev + pyr + o, 0, 1, frame_w >> l, frame_h >> l, top ? top_range : 1,
+                            g_stage.dev + 2 * pyr, d_gm, nullptr, !top, g_stage.stream);
+    if (rc) return rc;
+  }
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin, d_gm, 8, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(gm_xy, g_stage.pin, 8);
+  return SVC_OK;
+}
+
+int svc_hip_global_avg_host(const float* mv_xy, uint32_t blocks, float* avg_xy) {
+  SVC_REQUIRE(mv_xy && avg_xy, "global avg: null pointer (motion.cpp:46)");
+  int rc = require_device();
+  if (rc) return rc;
+  const size_t in_b = up256((size_t)blocks * 8);
+  if ((rc = g_stage.ensure(in_b + 256))) return rc;
+  std::memcpy(g_stage.pin, mv_xy, (size_t)blocks * 8);
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.dev, g_stage.pin, in_b, hipMemcpyHostToDevice, g_stage.stream));
+  float* d_out = reinterpret_cast<float*>(g_stage.dev + in_b);
+  rc = launch_global_avg(reinterpret_cast<const float*>(g_stage.dev), blocks, 1, d_out, g_stage.stream);
+  if (rc) return rc;
+  SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin, d_out, 8, hipMemcpyDeviceToHost, g_stage.stream));
+  SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
+  std::memcpy(avg_xy, g_stage.pin, 8);
   return SVC_OK;
 }
 

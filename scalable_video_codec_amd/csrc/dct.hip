@@ -286,14 +286,146 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   }
 }
 
+// ---- any transform block the reference's Validate admits (libs/encoder.cpp:62-142) ---------------
+// static Dct (libs/encoder.cpp:323-339) loops over ANY block_w x block_h; Validate only asks that the
+// transform block divides the MV block.  8x8 / 16x16 on frames 16 pixels wide are the kernels above;
+// every other shape -- 2x2, 4x4, 16x8, 8x16, 32x32, 1xN ... up to 64x64 -- runs here, straight from the
+// definition Y = Ch X Cw^T in f64 (rounded once to f32, like the fast kernels):
+//   a workgroup owns a strip (bh rows x SW columns, SW a multiple of bw) of one frame; per channel the
+//   strip goes to LDS as f32 (exact), a row pass multiplies every tile row by Cw^T into an f64 strip, a
+//   column pass multiplies by Ch, quantises and stores lane-contiguous f32.  The two basis matrices are
+//   evaluated once per workgroup (cospi on the exactly reduced angle) and kept in LDS; a workgroup walks
+//   several strips, so that cost is amortised.  Not the roofline path: the fast kernels carry BASELINE's
+//   configurations, this one carries the rest of the API.
+struct DctGenArgs {
+  const uint8_t* bgr;
+  uint64_t frame_stride;
+  uint32_t w, h, bw, bh;
+  uint32_t sw;               // strip width, a multiple of bw
+  uint32_t strips_per_band;  // ceil(w / sw)
+  uint32_t bands_per_frame;  // h / bh
+  uint32_t total_strips;
+  float* planes;
+  const uint32_t* types;
+  uint32_t mv_bw, mv_bh, mfw, mv_blocks;
+  float fg_step, bg_step, fg_inv, bg_inv;
+};
+
+// C[k][n] = s_k cos(pi (2n + 1) k / 2N), s_0 = sqrt(1/N), s_k = sqrt(2/N): the orthonormal DCT-II of
+// cv::dct(flags = 0).  (2n + 1) k is reduced mod 4N in integers, so the argument of cospi is in [0, 2).
+__device__ __forceinline__ double dct_basis(uint32_t k, uint32_t n, uint32_t N) {
+  const uint32_t j = ((2 * n + 1) * k) % (4 * N);
+  const double s = k == 0 ? 1.0 / (double)N : 2.0 / (double)N;
+  return __builtin_sqrt(s) * cospi((double)j / (double)(2 * N));
+}
+
+template <bool QUANT>
+__global__ __launch_bounds__(256) void dct_general_kernel(DctGenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t gen_lds[];
+  const uint32_t tid = threadIdx.x, bw = a.bw, bh = a.bh, sw = a.sw;
+  const uint32_t pw = bw + 1, ph = bh + 1;  // odd-ish pitches: rows of a basis matrix fall on different banks
+  double* cw = reinterpret_cast<double*>(gen_lds);  // [bw][pw]
+  double* ch = cw + bw * pw;                        // [bh][ph]
+  double* yrow = ch + bh * ph;                      // [bh][sw] row-pass results
+  float* xin = reinterpret_cast<float*>(yrow + bh * sw);  // [bh][sw] pixels of one channel
+  for (uint32_t i = tid; i < bw * bw; i += 256) cw[(i / bw) * pw + i % bw] = dct_basis(i / bw, i % bw, bw);
+  for (uint32_t i = tid; i < bh * bh; i += 256) ch[(i / bh) * ph + i % bh] = dct_basis(i / bh, i % bh, bh);
+  __syncthreads();
+  for (uint32_t unit = blockIdx.x; unit < a.total_strips; unit += gridDim.x) {
+    const uint32_t band_g = unit / a.strips_per_band, strip = unit - band_g * a.strips_per_band;
+    const uint32_t frame = band_g / a.bands_per_frame, band = band_g - frame * a.bands_per_frame;
+    const uint32_t y0 = band * bh, x0 = strip * sw;
+    const uint32_t cols = a.w - x0 < sw ? a.w - x0 : sw;  // the last strip of a band may be narrower
+    const uint32_t n = bh * cols;
+    const uint8_t* src = a.bgr + (size_t)frame * a.frame_stride;
+    float* out_frame = a.planes + (size_t)frame * 3 * a.w * a.h;
+    for (uint32_t c = 0; c < 3; ++c) {
+      for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t r = i / cols, x = i - r * cols;
+        xin[r * sw + x] = (float)src[((size_t)(y0 + r) * a.w + x0 + x) * 3 + c];
+      }
+      __syncthreads();
+      for (uint32_t i = tid; i < n; i += 256) {  // rows: y[r][t * bw + u] = sum_n Cw[u][n] x[r][t * bw + n]
+        const uint32_t r = i / cols, x = i - r * cols, u = x % bw;
+        const float* xr = xin + r * sw + (x - u);
+        const double* cr = cw + u * pw;
+        double acc = 0.0;
+        for (uint32_t k = 0; k < bw; ++k) acc = __builtin_fma(cr[k], (double)xr[k], acc);
+        yrow[r * sw + x] = acc;
+      }
+      __syncthreads();
+      float* plane = out_frame + (size_t)c * a.w * a.h;
+      for (uint32_t i = tid; i < n; i += 256) {  // columns: Y[v][x] = sum_m Ch[v][m] y[m][x]
+        const uint32_t v = i / cols, x = i - v * cols;
+        const double* cr = ch + v * ph;
+        double acc = 0.0;
+        for (uint32_t m = 0; m < bh; ++m) acc = __builtin_fma(cr[m], yrow[m * sw + x], acc);
+        float f = (float)acc;
+        if (QUANT) {
+          // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249); background (0) takes bg_step
+          const uint32_t t = a.types[(size_t)frame * a.mv_blocks + (y0 / a.mv_bh) * a.mfw + (x0 + x) / a.mv_bw];
+          f = quant1_fast(f, t == 0 ? a.bg_step : a.fg_step, t == 0 ? a.bg_inv : a.fg_inv);
+        }
+        plane[(size_t)(y0 + v) * a.w + x0 + x] = f;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+constexpr uint32_t kDctGenMaxSide = 64;
+
+static int launch_dct_general(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h,
+                              uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw, uint32_t mv_bh,
+                              uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes, hipStream_t stream) {
+  // cv::dct (libs/encoder.cpp:335) takes even sizes, and single rows / columns of even length
+  if ((bw > 1 && bw % 2) || (bh > 1 && bh % 2) || (bw == 1 && bh == 1))
+    return fail(SVC_ERR_INVALID_ARG, "dct: transform block %ux%u: cv::dct implements even sizes only", bw, bh);
+  if (bw > kDctGenMaxSide || bh > kDctGenMaxSide)
+    return fail(SVC_ERR_UNSUPPORTED, "dct: transform block %ux%u exceeds %ux%u", bw, bh, kDctGenMaxSide, kDctGenMaxSide);
+  DctGenArgs a{};
+  a.bgr = d_bgr; a.frame_stride = frame_stride;
+  a.w = w; a.h = h; a.bw = bw; a.bh = bh;
+  // strip: about 4096 samples, at least one tile, whole tiles
+  uint32_t tiles = 4096 / (bw * bh);
+  if (tiles < 1) tiles = 1;
+  if (tiles > w / bw) tiles = w / bw;
+  a.sw = tiles * bw;
+  a.strips_per_band = div_up(w, a.sw);
+  a.bands_per_frame = h / bh;
+  const uint64_t total = (uint64_t)n_frames * a.strips_per_band * a.bands_per_frame;
+  if (total == 0) return SVC_OK;
+  if (total > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "dct: %llu strips exceed one launch", (unsigned long long)total);
+  a.total_strips = (uint32_t)total;
+  a.planes = d_planes;
+  if (quant) {
+    a.types = d_types;
+    a.mv_bw = mv_bw; a.mv_bh = mv_bh;
+    a.mfw = w / mv_bw;
+    a.mv_blocks = a.mfw * (h / mv_bh);
+    a.fg_step = (float)fg_step; a.bg_step = (float)bg_step;
+    a.fg_inv = 1.0f / a.fg_step; a.bg_inv = 1.0f / a.bg_step;
+  }
+  const size_t lds = 8 * ((size_t)bw * (bw + 1) + (size_t)bh * (bh + 1) + (size_t)bh * a.sw) + 4 * (size_t)bh * a.sw;
+  const uint32_t grid = (uint32_t)(total < 4096 ? total : 4096);
+  if (quant) hipLaunchKernelGGL((dct_general_kernel<true>), dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((dct_general_kernel<false>), dim3(grid), dim3(256), lds, stream, a);
+  return check_launch("dct_general_kernel");
+}
+
 int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
                hipStream_t stream, uint8_t* d_records, uint64_t records_stride, uint32_t emit_h) {
-  if (bw != bh || (bw != 8 && bw != 16))
-    return fail(SVC_ERR_UNSUPPORTED, "dct: transform block %ux%u (supported: 8x8, 16x16)", bw, bh);
-  if (w % 16 != 0 || h % bh != 0)
-    return fail(SVC_ERR_UNSUPPORTED, "dct: frame %ux%u must be a multiple of 16 x %u", w, h, bh);
+  const bool wire = d_records != nullptr;
+  const bool fast = bw == bh && (bw == 8 || bw == 16) && w % 16 == 0;
+  if (!fast) {
+    if (wire)
+      return fail(SVC_ERR_UNSUPPORTED, "dct_records: the fused record emitter takes 8x8 / 16x16 blocks on frames a multiple of "
+                                       "16 wide; for %ux%u call svc_hip_dct[_quant]_frames, then svc_hip_serialize_frames", bw, bh);
+    return launch_dct_general(d_bgr, frame_stride, n_frames, w, h, bw, bh, d_types, mv_bw, mv_bh, fg_step, bg_step, quant,
+                              d_planes, stream);
+  }
   DctArgs a{};
   a.bgr = d_bgr;
   a.frame_stride = frame_stride;
@@ -305,7 +437,6 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   if (total > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "dct: %llu segment columns exceed one launch", (unsigned long long)total);
   a.total_segcols = (uint32_t)total;
   a.planes = d_planes;
-  const bool wire = d_records != nullptr;
   a.records = d_records;
   a.records_stride = records_stride;
   a.emit_bands = wire ? div_up(emit_h, bh) : 0;

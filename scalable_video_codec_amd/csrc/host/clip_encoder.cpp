@@ -80,6 +80,7 @@ struct ClipEncoder::Impl {
   HaloFn halo;
   // pipeline progress: steps whose stage has been enqueued
   uint64_t n_luma = 0, n_hbma = 0, n_lat = 0, n_dct = 0;
+  bool fused_records = false;  // wire output straight from the 8x8 / 16x16 transform kernel
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
@@ -182,10 +183,16 @@ struct ClipEncoder::Impl {
     const int b = Par(s);
     const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
     Run(Stage::kTransform, st, timing, [&] {
-      if (c.wire)
+      // records carry RAW coefficients, as the reference's encoder serialises them (libs/encoder.cpp:638-650:
+      // the decoder picks the step per tile, libs/decoder.cpp:130-135); planes carry the quantised ones
+      if (c.wire && fused_records)
         Abi(svc_hip_dct_records_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block,
-                                       c.fg_step, c.bg_step, ph, records.p, record_bytes, st), "svc_hip_dct_records_frames");
-      else
+                                       0, 0, ph, records.p, record_bytes, st), "svc_hip_dct_records_frames");
+      else if (c.wire) {  // any other transform block: Dct, then SerializeEncodedFrame
+        Abi(svc_hip_dct_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, coeffs.p, st), "svc_hip_dct_frames");
+        Abi(svc_hip_serialize_frames(coeffs.p, plane_elems, sh.pairs, types[b].p, pw, ph, c.dct_block_w, c.dct_block_h, mfw, mfh,
+                                     c.mv_block, c.mv_block, records.p, record_bytes, st), "svc_hip_serialize_frames");
+      } else
         Abi(svc_hip_dct_quant_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, types[b].p, c.mv_block,
                                      c.mv_block, c.fg_step, c.bg_step, coeffs.p, st), "svc_hip_dct_quant_frames");
     });
@@ -287,8 +294,6 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
     throw std::runtime_error("svc::ClipEncoder: a clip needs at least two frames and one frame per rank");
   if ((c.dct_block_w == 0) != (c.dct_block_h == 0))
     throw std::runtime_error("svc::ClipEncoder: transform block needs both sides");
-  if (c.wire && c.dct_block_w != c.dct_block_h)
-    throw std::runtime_error("svc::ClipEncoder: the fused record emitter takes square transform blocks");
   m.sh = PlanShard(c.clip_frames, c.world, c.rank);
   const uint32_t f = 1u << (c.levels - 1);
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
@@ -319,9 +324,10 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
     m.mask[b].Alloc((size_t)P * m.blocks); m.count[b].Alloc(P); m.types[b].Alloc((size_t)P * m.blocks);
   }
   m.seg_ws.Alloc(m.seg_ws_bytes);
+  m.fused_records = c.wire && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) && m.pw % 16 == 0;
   if (transform) {
     if (c.wire) m.records.Alloc((size_t)P * m.record_bytes);
-    else m.coeffs.Alloc((size_t)P * 3 * m.plane_elems);
+    if (!c.wire || !m.fused_records) m.coeffs.Alloc((size_t)P * 3 * m.plane_elems);
   }
   // RANSAC draws: distinct within an iteration, a function of (seed, clip frame, iteration) only --
   // the generator of stream_encoder.cpp / pipeline.ransac_samples, indexed by the CLIP-wide pair

@@ -96,6 +96,29 @@ void EstimateGlobalMotionRansac(const Vec2f* motion_field, uint motion_field_sz,
   inlier_indices->swap(inliers);  // motion.cpp:265
 }
 
+Vec2f EstimateGlobalMotionAvg(const Vec2f* motion_field, uint sz) {
+  Vec2f avg{0.0f, 0.0f};
+  if (sz == 0) return avg;  // motion.cpp:48: the loop does not run
+  int rc = svc_hip_global_avg_host(reinterpret_cast<const float*>(motion_field), sz, &avg.x);
+  if (rc) Die("EstimateGlobalMotionAvg", rc);
+  return avg;
+}
+
+void EstimateGlobalMotionExhaustiveSearch(const uchar* tracked_frame, const uchar* anchor_frame, uint frame_w,
+                                          uint frame_h, uint search_range, Vec2f* global_motion, float* min_mad) {
+  int rc = svc_hip_global_ebma_host(tracked_frame, anchor_frame, frame_w, frame_h, search_range,
+                                    reinterpret_cast<float*>(global_motion), min_mad);
+  if (rc) Die("EstimateGlobalMotionExhaustiveSearch", rc);
+}
+
+void EstimateGlobalMotionHierarchical(const uchar* const* tracked_pyramid, const uchar* const* anchor_pyramid,
+                                      uint num_levels, uint base_frame_w, uint base_frame_h, uint base_search_range,
+                                      Vec2f* global_motion) {
+  int rc = svc_hip_global_hbma_host(tracked_pyramid, anchor_pyramid, num_levels, base_frame_w, base_frame_h,
+                                    base_search_range, reinterpret_cast<float*>(global_motion));
+  if (rc) Die("EstimateGlobalMotionHierarchical", rc);
+}
+
 void Dct(const uchar* bgr, uint frame_w, uint frame_h, uint block_w, uint block_h, float* const planes[3]) {
   const size_t plane = static_cast<size_t>(frame_w) * frame_h;
   std::vector<float> packed(plane * 3);

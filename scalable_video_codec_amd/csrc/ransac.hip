@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
     if (tid < nm) {
       float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 m = mv[min(samples[(size_t)(it0 + tid) * a.subset + i], a.blocks)];  // [0, N]: N is the reference's off-by-one (svc_hip.h)
+        const float2 m = mv[min(samples[(size_t)(it0 + tid) * a.subset + i], a.blocks - 1)];  // a draw past the field (the reference's [0, N], motion.cpp:208) never leaves it: svc_hip.h
         sx = sx + m.x;
         sy = sy + m.y;
       }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
       const float ix = a.gm[2 * frame], iy = a.gm[2 * frame + 1];
       float acc = 0.f;
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 m = mv[min(samples[(size_t)best_it * a.subset + i], a.blocks)];
+        const float2 m = mv[min(samples[(size_t)best_it * a.subset + i], a.blocks - 1)];
         const float dx = m.x - ix, dy = m.y - iy;
         acc += dx * dx + dy * dy;
       }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void 
     if (gt < nm) {
       float sx = 0.f, sy = 0.f;  // sequential f32 sum of the subset (motion.cpp:156-160)
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 s = mv[min(samples[(size_t)(it0 + gt) * a.subset + i], a.blocks)];  // [0, N]: N is the reference's off-by-one (svc_hip.h)
+        const float2 s = mv[min(samples[(size_t)(it0 + gt) * a.subset + i], a.blocks - 1)];  // a draw past the field (the reference's [0, N], motion.cpp:208) never leaves it: svc_hip.h
         sx = sx + s.x;
         sy = sy + s.y;
       }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void 
       const float ix = a.gm[2 * f], iy = a.gm[2 * f + 1];
       float e = 0.f;
       for (uint32_t i = 0; i < a.subset; ++i) {
-        const float2 s = fmv[min(fs[(size_t)s_bestit[tid] * a.subset + i], a.blocks)];
+        const float2 s = fmv[min(fs[(size_t)s_bestit[tid] * a.subset + i], a.blocks - 1)];
         const float dx = s.x - ix, dy = s.y - iy;
         e += dx * dx + dy * dy;
       }

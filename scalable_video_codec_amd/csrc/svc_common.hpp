@@ -98,6 +98,11 @@ uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts);
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
                    uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,
                    uint32_t* d_types, hipStream_t stream);
+uint64_t global_ebma_workspace_bytes(uint32_t range, uint32_t n_pairs);
+int launch_global_ebma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride, uint32_t n_pairs, uint32_t w,
+                       uint32_t h, uint32_t range, uint8_t* d_ws, float* d_gm, float* d_min_mad, bool combine,
+                       hipStream_t stream);
+int launch_global_avg(const float* d_mv, uint32_t blocks, uint32_t n_frames, float* d_out, hipStream_t stream);
 int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames,
                         uint32_t w, uint32_t h, uint32_t levels, uint8_t* d_pyr,
                         uint64_t pyr_stride, hipStream_t stream);

@@ -80,6 +80,12 @@ SIGNATURES = {
     "svc_hip_dct_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp]),
     "svc_hip_dct_quant_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp]),
     "svc_hip_quant_host": (C.c_int, [_vp, _u64, _u32]),
+    "svc_hip_global_ebma_workspace_bytes": (_u64, [_u32, _u32]),
+    "svc_hip_global_ebma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "svc_hip_global_avg_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
+    "svc_hip_global_ebma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    "svc_hip_global_hbma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+    "svc_hip_global_avg_host": (C.c_int, [_vp, _u32, _vp]),
     "svc_hip_comm_unique_id": (C.c_int, [_vp]),
     "svc_hip_comm_create": (C.c_int, [_vp, _u32, _u32, C.POINTER(_vp)]),
     "svc_hip_comm_destroy": (C.c_int, [_vp]),
@@ -112,6 +118,11 @@ def _check(rc: int) -> None:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _bwbh(block) -> Tuple[int, int]:
+    """A transform block given as one side (square) or as (block_w, block_h)."""
+    return (block, block) if isinstance(block, int) else (int(block[0]), int(block[1]))
 
 
 def _dev(t: torch.Tensor, dtype) -> int:
@@ -277,22 +288,24 @@ def sse_frames(src_bgr: torch.Tensor, rec: torch.Tensor, region_w: int, region_h
     return out
 
 
-def dct_frames(bgr: torch.Tensor, block: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bgr: (frames, H, W, 3) u8 -> (frames, 3, H, W) f32 coefficient planes."""
+def dct_frames(bgr: torch.Tensor, block, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bgr: (frames, H, W, 3) u8 -> (frames, 3, H, W) f32 coefficient planes.  block: side or (block_w, block_h)."""
     n, h, w, _ = bgr.shape
+    bw, bh = _bwbh(block)
     if out is None:
         out = torch.empty((n, 3, h, w), dtype=torch.float32, device=bgr.device)
-    _check(load().svc_hip_dct_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, block,
+    _check(load().svc_hip_dct_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, bw, bh,
                                      _dev(out, torch.float32), _stream()))
     return out
 
 
-def dct_quant_frames(bgr: torch.Tensor, block: int, block_types: torch.Tensor, mv_block: int, fg_step: int,
+def dct_quant_frames(bgr: torch.Tensor, block, block_types: torch.Tensor, mv_block: int, fg_step: int,
                      bg_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     n, h, w, _ = bgr.shape
+    bw, bh = _bwbh(block)
     if out is None:
         out = torch.empty((n, 3, h, w), dtype=torch.float32, device=bgr.device)
-    _check(load().svc_hip_dct_quant_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, block,
+    _check(load().svc_hip_dct_quant_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, bw, bh,
                                            _dev(block_types, torch.int32), mv_block, mv_block, fg_step, bg_step,
                                            _dev(out, torch.float32), _stream()))
     return out
@@ -371,22 +384,25 @@ def ransac_host(mv, samples, gm_in=(0.0, 0.0), subset_sz=1, inlier_thresh=7.5, s
     return gm, np.float32(rmse.value), inl[:cnt.value].copy()
 
 
-def dct_host(bgr, block: int):
+def dct_host(bgr, block):
     import numpy as np
     bgr = np.ascontiguousarray(bgr, np.uint8)
     h, w, _ = bgr.shape
+    bw, bh = _bwbh(block)
     out = np.empty((3, h, w), np.float32)
-    _check(load().svc_hip_dct_host(_np_ptr(bgr), w, h, block, block, _np_ptr(out)))
+    _check(load().svc_hip_dct_host(_np_ptr(bgr), w, h, bw, bh, _np_ptr(out)))
     return out
 
 
-def dct_quant_host(bgr, block: int, block_types, mv_block: int, fg_step: int, bg_step: int):
+def dct_quant_host(bgr, block, block_types, mv_block, fg_step: int, bg_step: int):
     import numpy as np
     bgr = np.ascontiguousarray(bgr, np.uint8)
     bt = np.ascontiguousarray(block_types, np.uint32)
     h, w, _ = bgr.shape
+    bw, bh = _bwbh(block)
+    mvw, mvh = _bwbh(mv_block)
     out = np.empty((3, h, w), np.float32)
-    _check(load().svc_hip_dct_quant_host(_np_ptr(bgr), w, h, block, block, _np_ptr(bt), mv_block, mv_block,
+    _check(load().svc_hip_dct_quant_host(_np_ptr(bgr), w, h, bw, bh, _np_ptr(bt), mvw, mvh,
                                          fg_step, bg_step, _np_ptr(out)))
     return out
 
@@ -395,4 +411,54 @@ def quant_host(coeffs, step: int):
     import numpy as np
     out = np.ascontiguousarray(coeffs, np.float32).copy()
     _check(load().svc_hip_quant_host(_np_ptr(out), out.size, step))
+    return out
+
+
+def global_ebma_host(tracked, anchor, search_range: int):
+    """EstimateGlobalMotionExhaustiveSearch (libs/motion.hpp:45-49) -> ((dx, dy), min_mad)."""
+    import numpy as np
+    h, w = tracked.shape
+    gm = np.zeros(2, np.float32)
+    mad = C.c_float(0)
+    _check(load().svc_hip_global_ebma_host(_np_ptr(np.ascontiguousarray(tracked)), _np_ptr(np.ascontiguousarray(anchor)), w, h,
+                                           search_range, _np_ptr(gm), C.cast(C.byref(mad), _vp)))
+    return gm, np.float32(mad.value)
+
+
+def global_hbma_host(tracked_pyr, anchor_pyr, search_range: int):
+    """EstimateGlobalMotionHierarchical (libs/motion.hpp:55-59) -> (dx, dy)."""
+    import numpy as np
+    levels = len(tracked_pyr)
+    h, w = tracked_pyr[0].shape
+    tp = (_vp * levels)(*[_np_ptr(np.ascontiguousarray(p)) for p in tracked_pyr])
+    ap = (_vp * levels)(*[_np_ptr(np.ascontiguousarray(p)) for p in anchor_pyr])
+    gm = np.zeros(2, np.float32)
+    _check(load().svc_hip_global_hbma_host(C.cast(tp, _vp), C.cast(ap, _vp), levels, w, h, search_range, _np_ptr(gm)))
+    return gm
+
+
+def global_avg_host(mv):
+    """EstimateGlobalMotionAvg (libs/motion.hpp:38)."""
+    import numpy as np
+    mv = np.ascontiguousarray(mv, np.float32)
+    out = np.zeros(2, np.float32)
+    _check(load().svc_hip_global_avg_host(_np_ptr(mv), len(mv), _np_ptr(out)))
+    return out
+
+
+def global_ebma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_pairs: int, w: int, h: int,
+                      search_range: int):
+    ws = torch.empty(int(load().svc_hip_global_ebma_workspace_bytes(search_range, n_pairs)), dtype=torch.uint8, device=tracked.device)
+    gm = torch.empty((n_pairs, 2), dtype=torch.float32, device=tracked.device)
+    mad = torch.empty(n_pairs, dtype=torch.float32, device=tracked.device)
+    _check(load().svc_hip_global_ebma_pairs(_dev(tracked, torch.uint8), _dev(anchor, torch.uint8), pair_stride, n_pairs, w, h,
+                                            search_range, _dev(ws, torch.uint8), ws.numel(), _dev(gm, torch.float32),
+                                            _dev(mad, torch.float32), _stream()))
+    return gm, mad
+
+
+def global_avg_frames(mv: torch.Tensor) -> torch.Tensor:
+    frames, blocks, _ = mv.shape
+    out = torch.empty((frames, 2), dtype=torch.float32, device=mv.device)
+    _check(load().svc_hip_global_avg_frames(_dev(mv, torch.float32), blocks, frames, _dev(out, torch.float32), _stream()))
     return out

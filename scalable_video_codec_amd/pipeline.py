@@ -213,8 +213,10 @@ class ClipEncoder:
             f0 = self.first_encoded       # encoded frame of pair p is own frame first_encoded + p
             with self._timed("dct_quant", timed):
                 if self.wire:
+                    # records carry RAW coefficients, as the reference's encoder serialises them
+                    # (libs/encoder.cpp:638-650; the decoder picks the step per tile, libs/decoder.cpp:130-135)
                     native.dct_records_frames(self.bgr[f0:f0 + p], c.dct_block, self.types, c.mv_block,
-                                              c.fg_step, c.bg_step, out=self.records)
+                                              0, 0, out=self.records)
                 else:
                     native.dct_quant_frames(self.bgr[f0:f0 + p], c.dct_block, self.types, c.mv_block,
                                             c.fg_step, c.bg_step, out=self.coeffs)

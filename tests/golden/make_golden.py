@@ -16,6 +16,8 @@ Fixtures are data only (inputs + the reference's outputs):
   ransac.npz         EstimateGlobalMotionRansac with its RNG made repeatable (ref_shim.cpp)
                      and the draws mirrored, so the explicit-samples restatement can be
                      checked against the real thing.
+  global_motion.npz  EstimateGlobalMotionAvg on five fields; EstimateGlobalMotionExhaustiveSearch's literal
+                     outputs (its loops only run for search_range 0, libs/motion.cpp:72, :81).
   dct_tiles.npz      sampled tiles + their float64 orthonormal DCT-II (the oracle of
                      record for cv::dct, cross-checked here against scipy.fft.dctn).
   quant.npz          hand vectors of libs/decoder.cpp:140-144.
@@ -148,7 +150,45 @@ def main():
         g2, r2, i2 = orc.ransac(buf, samples, gm_in=(0.25, -0.75), n=n, **p)
         assert g2.tobytes() == gm.tobytes() and r2.tobytes() == rmse.tobytes() and np.array_equal(i2, inl), name
         print("ransac", name, "iters", k, "gm", gm, "inliers", len(inl), "max sample", samples.max(), "n", n)
+    # |best| < subset_sz with every draw inside the field (motion.cpp:240-242 compared on the product path too: the case
+    # above drew index n).  Appended AFTER the cases above so that their draws from the shared engine do not move.
+    for n_scatter in (2048, 2049, 2050, 3000, 4096):
+        mvf = (np.stack([np.arange(n_scatter) * 37 % 1009, np.arange(n_scatter) * 91 % 2003], 1) * 40.0).astype(np.float32)
+        p = dict(DEFAULT_RANSAC, subset_sz=3, inlier_thresh=1.0)
+        k = orc.ransac_iter_count(**p)
+        buf = np.concatenate([mvf, mvf[:1]]).astype(np.float32)
+        gm, rmse, inl = ref.ransac(buf, n_scatter, gm_in=(0.25, -0.75), **p)
+        samples = ref.ransac_draw(n_scatter, p["subset_sz"], k)
+        if int(samples.max()) < n_scatter and len(inl) < p["subset_sz"]:
+            name = "scatter_no_consensus_in_range"
+            rs[f"{name}/mv"] = buf
+            rs[f"{name}/params"] = np.array([p["subset_sz"], p["inlier_thresh"], p["success_prob"], p["inlier_ratio"]], np.float64)
+            rs[f"{name}/samples"] = samples
+            rs[f"{name}/gm"], rs[f"{name}/rmse"], rs[f"{name}/inliers"] = gm, np.array([rmse], np.float32), inl
+            g2, r2, i2 = orc.ransac(buf, samples, gm_in=(0.25, -0.75), n=n_scatter, **p)
+            assert g2.tobytes() == gm.tobytes() and r2.tobytes() == rmse.tobytes() and np.array_equal(i2, inl), name
+            print("ransac", name, "n", n_scatter, "gm", gm, "rmse", rmse, "inliers", len(inl), "max sample", samples.max())
+            break
+    else:
+        raise SystemExit("no in-range |best| < n case found")
     np.savez_compressed(os.path.join(HERE, "ransac.npz"), **rs)
+
+    # ---- the whole-frame estimators of libs/motion.hpp:38-59 (no caller in the reference) -----------------
+    gmz = {}
+    rng_g = np.random.default_rng(0x6D0)  # its own stream: the fixtures made after this block must not move
+    for i, n in enumerate((1, 2, 7, 396, 8160)):
+        mv = (rng_g.integers(-16, 17, (n, 2)) + rng_g.random((n, 2)) * (i % 3)).astype(np.float32)
+        gmz[f"avg{i}/mv"], gmz[f"avg{i}/out"] = mv, ref.global_avg(mv)
+        assert orc.global_avg(mv).tobytes() == gmz[f"avg{i}/out"].tobytes()
+    base = rng_g.integers(0, 256, (80, 120), dtype=np.uint8)
+    t, a = np.ascontiguousarray(base[8:72, 8:104]), np.ascontiguousarray(base[10:74, 5:101])
+    gmz["ebma/t"], gmz["ebma/a"] = t, a
+    for r in (0, 1, 4):  # the reference's literal outputs: only r = 0 visits a candidate (motion.cpp:72, :81)
+        g, m = ref.global_ebma(t, a, r)
+        gmz[f"ebma/r{r}"] = np.array([g[0], g[1], m], np.float32)
+        g2, m2 = orc.global_ebma(t, a, r, reference_loop=True)
+        assert g2.tobytes() == g.tobytes() and np.float32(m2).tobytes() == np.float32(m).tobytes()
+    np.savez_compressed(os.path.join(HERE, "global_motion.npz"), **gmz)
 
     # ---- DCT tiles ----------------------------------------------------------------------
     from scipy.fft import dctn

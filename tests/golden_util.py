@@ -50,3 +50,11 @@ def ransac_cases():
                       success_prob=float(np.float32(p[2])), inlier_ratio=float(np.float32(p[3])))
         yield (name, z[f"{name}/mv"], params, z[f"{name}/samples"], z[f"{name}/gm"],
                np.float32(z[f"{name}/rmse"][0]), z[f"{name}/inliers"])
+
+
+def global_motion_cases():
+    """tests/golden/global_motion.npz: (mv, reference avg) fields; the EBMA planes and the reference's literal outputs."""
+    z = load("global_motion.npz")
+    avgs = [(z[f"avg{i}/mv"], z[f"avg{i}/out"]) for i in range(5)]
+    literal = {int(k.split("/r")[1]): z[k] for k in z.files if k.startswith("ebma/r")}
+    return avgs, z["ebma/t"], z["ebma/a"], literal

@@ -71,7 +71,10 @@ def test_motion_library_exports_reference_symbols():
     for sym in ("_Z26EstimateMotionHierarchicalPKPKhS2_jjjjjjP5Vec2fPf",
                 "_Z35EstimateMotionHierarchical16x16Sse2PKPKhS2_jjjP5Vec2fPf",
                 "_Z30EstimateMotionExhaustiveSearchPKhS0_jjjjjP5Vec2fPf",
-                "_Z26EstimateGlobalMotionRansacPK5Vec2fj12RansacParamsPfPS_PSt6vectorIjSaIjEE"):
+                "_Z26EstimateGlobalMotionRansacPK5Vec2fj12RansacParamsPfPS_PSt6vectorIjSaIjEE",
+                "_Z23EstimateGlobalMotionAvgPK5Vec2fj",                      # libs/motion.hpp:38
+                "_Z36EstimateGlobalMotionExhaustiveSearchPKhS0_jjjP5Vec2fPf",  # :45-49
+                "_Z32EstimateGlobalMotionHierarchicalPKPKhS2_jjjjP5Vec2f"):     # :55-59
         assert sym in out, sym
     ctypes.CDLL(native.MOTION_LIB_PATH)  # resolves its libsvc_hip.so dependency via $ORIGIN
 

@@ -84,6 +84,29 @@ def test_wire_and_no_segmentation(native):
     assert torch.equal(enc.read("records").view(ref.records.shape), ref.records.cpu())
 
 
+@pytest.mark.parametrize("block,wire", [((16, 8), False), ((4, 4), True), ((8, 16), True)])
+def test_general_transform_blocks(native, block, wire):
+    """Transform blocks beyond 8x8 / 16x16 through the driver: planes from the general kernel, records from
+    Dct + SerializeEncodedFrame (two C-ABI calls) -- equal to the stage-by-stage calls."""
+    dev = torch.device("cuda")
+    n = 4
+    frames = _frames(CFG, n, dev)
+    enc = clipmod.Clip(CFG, n, wire=wire, dct_block=block)
+    enc.load_frames(frames)
+    enc.step()
+    enc.sync()
+    types = enc.read("block_types", device=dev).view(n - 1, -1)
+    i = enc.info
+    if wire:
+        planes = native.dct_frames(frames[1:].contiguous(), block)
+        want = native.serialize_frames(planes, types, i.padded_w, i.padded_h, block[0], block[1], i.mv_field_w, i.mv_field_h)
+        assert i.record_bytes == want.shape[1]
+        assert torch.equal(enc.read("records", device=dev).view(n - 1, -1), want)
+    else:
+        want = native.dct_quant_frames(frames[1:].contiguous(), block, types, 16, CFG.fg_step, CFG.bg_step)
+        assert torch.equal(enc.read("coeffs", device=dev).view(want.shape), want)
+
+
 _hip = None
 
 

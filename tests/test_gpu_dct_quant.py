@@ -102,10 +102,68 @@ def test_dct_quant_fused(native, oracle, block):
     assert planes[0].cpu().numpy().tobytes() == exp.tobytes()
 
 
-def test_dct_unsupported(native):
-    with pytest.raises(native.SvcError) as e:
-        native.dct_host(np.zeros((32, 32, 3), np.uint8), 4)
-    assert e.value.status == native.SVC_ERR_UNSUPPORTED
+GENERAL_BLOCKS = [(4, 4), (2, 2), (16, 8), (8, 16), (32, 32), (2, 16), (64, 64), (8, 1), (1, 4), (6, 10), (8, 8), (16, 16)]
+
+
+@pytest.mark.parametrize("bw,bh", GENERAL_BLOCKS)
+def test_dct_general_blocks(native, oracle, bw, bh):
+    """static Dct takes ANY block_w x block_h (libs/encoder.cpp:323-339) and Validate admits every transform block that
+    divides the MV block (:62-142): 4x4, 2x2, non-square, 32x32 on 32x32 MV blocks, single rows / columns.  8x8 / 16x16
+    on a frame that is NOT a multiple of 16 wide takes the general kernel too."""
+    rng = np.random.default_rng(bw * 100 + bh)
+    w = {(8, 8): 88, (16, 16): 112}.get((bw, bh), bw * max(1, 200 // bw))  # 88 = 8 * 11: not a multiple of 16
+    h = bh * max(2, 70 // bh)
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    bgr[:bh, :bw] = 255  # a saturated tile: the largest DC
+    got = native.dct_host(bgr, (bw, bh))
+    _dct_close(got, oracle.dct_frame_f64(bgr, bw, bh))
+    # energy per tile (orthonormal) and the DC of the saturated tile
+    e_in = (bgr.astype(np.float64) ** 2).sum()
+    assert abs(e_in - (got.astype(np.float64) ** 2).sum()) <= 1e-6 * e_in
+    assert np.allclose(got[:, 0, 0], 255.0 * np.sqrt(bw * bh), rtol=1e-6)
+
+
+@pytest.mark.parametrize("bw,bh,mv", [(4, 4, 16), (16, 8, 16), (8, 16, 16), (2, 2, 16), (32, 32, 32), (4, 8, (8, 16))])
+def test_dct_quant_general_blocks(native, oracle, bw, bh, mv):
+    """Fused DCT + quant on the general kernel == the oracle's quant lines applied to the device DCT, bit for bit;
+    batched device entry point == the host one; the reference's serialiser runs on the result (wire records)."""
+    rng = np.random.default_rng(bw + 7 * bh)
+    mvw, mvh = (mv, mv) if isinstance(mv, int) else mv
+    h, w = 3 * mvh * 2, 5 * mvw * 2
+    frames = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    types = rng.integers(0, 3, (2, (h // mvh) * (w // mvw))).astype(np.uint32)
+    dev = torch.device("cuda")
+    bgr = torch.from_numpy(frames).to(dev)
+    t = torch.from_numpy(types.astype(np.int32)).to(dev)
+    n, hh, ww, _ = bgr.shape
+    planes = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
+    native._check(native.load().svc_hip_dct_quant_frames(bgr.data_ptr(), hh * ww * 3, n, ww, hh, bw, bh, t.data_ptr(), mvw, mvh,
+                                                         3, 640, planes.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = planes.cpu().numpy()
+    for f in range(2):
+        dct = native.dct_host(frames[f], (bw, bh))
+        exp = oracle.quant_frame(dct, mvw, mvh, types[f], 3, 640)
+        assert got[f].tobytes() == exp.tobytes()
+        assert native.dct_quant_host(frames[f], (bw, bh), types[f], (mvw, mvh), 3, 640).tobytes() == exp.tobytes()
+    # SerializeEncodedFrame (libs/encoder.cpp:222-269) on these planes; its tile loops swap w / h for the rows, so the
+    # reference itself only handles square transform blocks consistently -- serialise the square cases
+    if bw == bh and mvw == mvh:
+        rec = native.serialize_frames(planes, t, ww, hh, bw, bh, ww // mvw, hh // mvh, mvw).cpu().numpy()
+        exp = oracle.serialize_frame(got[0], types[0], ww, hh, bw, bh, ww // mvw, mvw, mvh)
+        assert rec[0].tobytes() == exp.tobytes()
+
+
+def test_dct_block_preconditions(native):
+    for block, status in (((3, 4), native.SVC_ERR_INVALID_ARG),      # cv::dct: odd sizes are not implemented
+                          ((1, 1), native.SVC_ERR_INVALID_ARG),
+                          ((128, 128), native.SVC_ERR_UNSUPPORTED)):  # beyond the general kernel's 64 x 64
+        with pytest.raises(native.SvcError) as e:
+            native.dct_host(np.zeros((256, 384, 3), np.uint8), block)
+        assert e.value.status == status, block
     with pytest.raises(native.SvcError) as e:
         native.dct_host(np.zeros((30, 32, 3), np.uint8), 8)
     assert e.value.status == native.SVC_ERR_INVALID_ARG
+    with pytest.raises(native.SvcError) as e:  # the fused record emitter is 8x8 / 16x16 only: two calls for the rest
+        native.dct_records_frames(torch.zeros((1, 32, 32, 3), dtype=torch.uint8, device="cuda"), 4,
+                                  torch.zeros((1, 4), dtype=torch.int32, device="cuda"))
+    assert e.value.status == native.SVC_ERR_UNSUPPORTED

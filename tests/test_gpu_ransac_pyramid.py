@@ -102,6 +102,33 @@ def test_ransac_frames_every_launch_shape(native, oracle, frames, n, subset):
         assert np.array_equal(np.flatnonzero(mask[f]), inl_o) and int(count[f]) == len(inl_o), f
 
 
+@pytest.mark.parametrize("frames,n,subset", [(3, 3600, 1), (2, 8160, 3), (5, 40000, 2)])
+def test_ransac_device_draw_past_the_field_stays_inside(native, oracle, frames, n, subset):
+    """A device-side sample index >= blocks (the reference's inclusive draw, motion.cpp:208) cannot be rejected by the
+    device entry point; it must act as index blocks - 1 -- never the next frame's first MV, never past the allocation
+    on the last frame of a batch (include/svc_hip.h).  Every kernel variant, every frame incl. the last."""
+    rng = np.random.default_rng(n + subset)
+    p = dict(DEFAULT_RANSAC, subset_sz=subset)
+    k = oracle.ransac_iter_count(**p)
+    mv = np.stack([_field(rng, n, 0.2 * f) for f in range(frames)])
+    mv[:, -1] = [40.0, -35.0]            # entry blocks - 1 is distinctive, and so is the next frame's entry 0
+    mv[:, 0] = [-50.0, 45.0]
+    samples = np.stack([np.stack([rng.choice(n - 1, subset, replace=False) for _ in range(k)]) for _ in range(frames)]).astype(np.int64)
+    samples[:, -1, 0] = n                # the last iteration wins ties (>=): make it the out-of-range one
+    samples[:, 0, subset - 1] = n + 7
+    clamped = np.minimum(samples, n - 1)
+    dev_mv = torch.from_numpy(mv).cuda()
+    got = native.ransac_frames(dev_mv, torch.from_numpy(samples.astype(np.int32)).cuda(), **p)
+    want = native.ransac_frames(dev_mv, torch.from_numpy(clamped.astype(np.int32)).cuda(), **p)
+    torch.cuda.synchronize()
+    for g, w_ in zip(got, want):
+        assert torch.equal(g, w_)
+    for f in (0, frames - 1):
+        gm_o, rmse_o, inl_o = oracle.ransac(mv[f], clamped[f].astype(np.uint32), **p)
+        assert got[0][f].cpu().numpy().tobytes() == gm_o.tobytes() and got[1][f].cpu().numpy().tobytes() == rmse_o.tobytes()
+        assert np.array_equal(np.flatnonzero(got[2][f].cpu().numpy()), inl_o)
+
+
 # the last three are regressions: frames shorter than one 32-row LDS tile (rows beyond the frame
 # must not be reflected twice), found by tests/test_gpu_misc_property.py
 @pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4), (64, 16, 2), (32, 8, 3), (128, 2, 2)])

@@ -130,3 +130,32 @@ def test_decode_is_the_inverse_of_dct(oracle):
     # background step 640 except inside the gaze rectangle (:130-135, :202)
     rec = oracle.decode_frame(planes, 16, np.zeros(6, np.uint32), 16, 1, 640, gaze=(16, 0, 16, 16))
     assert np.abs(rec[:16, 16:32] - bgr[:16, 16:32]).max() < 1.5 and np.abs(rec[:16, :16] - bgr[:16, :16]).max() > 20
+
+
+@pytest.mark.parametrize("bw,bh", [(4, 4), (2, 2), (16, 8), (8, 16), (32, 32), (8, 1), (1, 4), (6, 10), (64, 64)])
+def test_dct_any_block_matches_scipy(oracle, bw, bh):
+    """The oracle's DCT for every transform block static Dct accepts (libs/encoder.cpp:323-339) against an independent
+    implementation of the orthonormal DCT-II (scipy.fft.dctn; cv::dct itself is not installed: parity unpinned)."""
+    import scipy.fft
+    rng = np.random.default_rng(bw * 64 + bh)
+    h, w = bh * 3, bw * 4
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = oracle.dct_frame_f64(bgr, bw, bh)
+    for c in range(3):
+        for y in range(0, h, bh):
+            for x in range(0, w, bw):
+                ref = scipy.fft.dctn(bgr[y:y + bh, x:x + bw, c].astype(np.float64), type=2, norm="ortho")
+                assert np.abs(got[c, y:y + bh, x:x + bw] - ref).max() <= 1e-9
+
+
+def test_global_motion_golden(oracle):
+    """libs/motion.hpp:38-59 against values the unmodified reference produced (tests/golden/make_golden.py)."""
+    avgs, t, a, literal = G.global_motion_cases()
+    for mv, want in avgs:
+        assert oracle.global_avg(mv).tobytes() == want.tobytes()
+    for r, want in literal.items():
+        gm, mad = oracle.global_ebma(t, a, r, reference_loop=True)
+        assert np.array([gm[0], gm[1], mad], np.float32).tobytes() == want.tobytes(), r
+        if r > 0:  # motion.cpp:72, :81: the reference visits no candidate
+            assert want.tolist() == [0.0, 0.0, float(np.finfo(np.float32).max)]
+    assert oracle.global_ebma(t, a, 4)[0].tolist() == [-3.0, 2.0]  # the search as meant finds the planted shift

@@ -55,3 +55,29 @@ def test_ransac_lockstep(oracle, reference):
         gm_o, rmse_o, inl_o = oracle.ransac(mv, s, n=n, **p)
         assert gm_o.tobytes() == gm_r.tobytes() and rmse_o.tobytes() == rmse_r.tobytes()
         assert np.array_equal(inl_o, inl_r)
+
+
+def test_global_motion_functions(oracle, reference):
+    """libs/motion.hpp:38-59.  The running mean is pinned bit for bit.  The exhaustive search is pinned in the
+    reference's LITERAL form: its `int dy <= unsigned search_range` loops (libs/motion.cpp:72, :81) never run for
+    R > 0, so the unmodified reference answers {0, 0}, FLT_MAX for every input -- shown here on frames with an
+    obvious (+3, -2) shift -- and only R = 0 computes anything (the zero-displacement whole-frame MAD)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 396, 8160):
+        mv = (rng.integers(-16, 17, (n, 2)) + rng.random((n, 2)) * (n % 3)).astype(np.float32)
+        assert oracle.global_avg(mv).tobytes() == reference.global_avg(mv).tobytes()
+    base = rng.integers(0, 256, (80, 120), dtype=np.uint8)
+    t, a = np.ascontiguousarray(base[8:72, 8:104]), np.ascontiguousarray(base[10:74, 5:101])
+    for r in (0, 1, 4, 8):
+        gm_r, mad_r = reference.global_ebma(t, a, r)
+        gm_o, mad_o = oracle.global_ebma(t, a, r, reference_loop=True)
+        assert gm_o.tobytes() == gm_r.tobytes() and mad_o.tobytes() == mad_r.tobytes(), r
+        if r > 0:
+            assert gm_r.tolist() == [0.0, 0.0] and mad_r == np.finfo(np.float32).max  # the reference's loops never run
+    # the search as evidently meant finds the planted shift: tracked(y, x) = anchor(y - dy, x - dx)
+    gm, mad = oracle.global_ebma(t, a, 4)
+    assert gm.tolist() == [-3.0, 2.0] and mad == 0.0
+    pyr_t = [np.ascontiguousarray(t[:: 1 << l, :: 1 << l]) for l in range(3)]
+    pyr_a = [np.ascontiguousarray(a[:: 1 << l, :: 1 << l]) for l in range(3)]
+    assert reference.global_hbma(pyr_t, pyr_a, 8).tobytes() == oracle.global_hbma(pyr_t, pyr_a, 8, reference_loop=True).tobytes()
+    assert reference.global_hbma(pyr_t, pyr_a, 3).tobytes() == oracle.global_hbma(pyr_t, pyr_a, 3, reference_loop=True).tobytes()
