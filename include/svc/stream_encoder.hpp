@@ -30,16 +30,20 @@ struct StreamEncoderConfig {
   uint32_t search_range = 8;
   uint32_t dct_block = 8;          // transform block, 8 or 16
   uint32_t fg_step = 1, bg_step = 640;  // apps/decoder.cpp:22-23
-  bool wire = false;               // serialised records (libs/encoder.cpp:222-269) instead of planes
+  bool wire = false;               // serialised records (libs/encoder.cpp:222-269) instead of planes: RAW
+                                   // coefficients, as the reference's encoder emits them (the decoder picks the
+                                   // quant step per tile, libs/decoder.cpp:130-135), over the PADDED tile grid its
+                                   // decoder parses (libs/decoder.cpp:185-186); fg_step / bg_step apply to planes only
   uint32_t batch = 16;             // encoded frames per batch
-  uint32_t depth = 3;              // batches in flight
+  uint32_t depth = 3;              // batches in flight, >= 3 (H2D, kernels and D2H of three batches overlap)
   uint64_t seed = 0;
   svc_ransac_params ransac{1, 7.5f, 0.99f, 0.5f};
   svc_segment_params segment{3, 3, 10, 3, 10, 1.0f, 4};
 };
 
 // One finished batch; the pointers are pinned host memory owned by the encoder and stay valid
-// until depth - 1 more batches have been delivered.
+// until depth - 2 more batches have been delivered (a slot is re-staged one iteration before its
+// turn to deliver comes again): with the default depth of 3, until the NEXT delivery returns.
 struct EncodedBatch {
   uint32_t first_frame = 0;  // clip index of the batch's first encoded frame (frame 0 is tracked-only)
   uint32_t count = 0;
@@ -50,6 +54,8 @@ struct EncodedBatch {
   const float* coeffs = nullptr;         // [count][3][padded_h][padded_w], planes B,G,R (wire == false)
   const uint8_t* records = nullptr;      // [count][record_bytes] (wire == true)
   uint64_t record_bytes = 0;
+  const svc_wire_header* header = nullptr;  // wire == true, first batch of a clip only: the 32 bytes that
+                                            // open the reference's stream (libs/codec.hpp:8-17, encoder.cpp:360-381)
 };
 
 class StreamEncoder {

@@ -283,7 +283,9 @@ static int launch_wave_level(const uint8_t* d_tracked, const uint8_t* d_anchor,
   if (items == 0) return SVC_OK;
   if (items > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu work items exceed one launch", (unsigned long long)items);
   a.n_items = (uint32_t)items;
-  const bool dw = (bw % 4 == 0) && (fw % 4 == 0) && fw >= 4;
+  // the dword path keeps four SADs in packed u16 lanes and flushes them per row at the latest: one row of a block
+  // wider than 256 would already exceed 65535 in a lane, so such blocks take the byte path
+  const bool dw = (bw % 4 == 0) && (fw % 4 == 0) && fw >= 4 && bw <= 256;
   // lane tasks per block: candidates, or groups of four candidates on the dword path
   const uint64_t tasks_max = dw ? (2ull * range + 1) * ((2ull * range + 1 + 3) / 4) : ncand_max;
   a.gs = tasks_max <= 4 ? 4u : tasks_max <= 8 ? 8u : tasks_max <= 16 ? 16u : tasks_max <= 32 ? 32u : 64u;

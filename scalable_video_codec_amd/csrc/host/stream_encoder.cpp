@@ -83,7 +83,7 @@ StreamEncoder::StreamEncoder(const StreamEncoderConfig& config) : p_(new Impl) {
   Impl& m = *p_;
   m.c = config;
   const StreamEncoderConfig& c = m.c;
-  if (!c.width || !c.height || !c.levels || !c.mv_block || c.batch == 0 || c.depth < 2)
+  if (!c.width || !c.height || !c.levels || !c.mv_block || c.batch == 0 || c.depth < 3)
     throw std::runtime_error("svc::StreamEncoder: invalid configuration");
   const uint32_t f = 1u << (c.levels - 1);
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
@@ -151,9 +151,15 @@ void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& si
     Hip(hipMemcpy(m.samples.p, h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy");
   }
 
+  svc_wire_header header{};
+  if (c.wire)
+    Abi(svc_hip_wire_header(n_frames, c.width, c.height, c.mv_block, c.mv_block, c.levels, c.dct_block, c.dct_block, &header),
+        "svc_hip_wire_header");
+
   auto deliver = [&](Slot& s) {
     Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize");
     EncodedBatch b;
+    b.header = (c.wire && s.first == 1) ? &header : nullptr;
     b.first_frame = s.first; b.count = s.encoded;
     b.padded_w = m.pw; b.padded_h = m.ph; b.mv_field_w = m.mfw; b.mv_field_h = m.mfh;
     b.mv_xy = s.pin_mv.p; b.global_motion = s.pin_gm.p; b.block_types = s.pin_types.p;
@@ -206,7 +212,7 @@ void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& si
     const uint8_t* enc_bgr = s.bgr.p + m.frame_bytes;  // encoded frame of pair p is source frame p + 1
     if (c.wire)
       Abi(svc_hip_dct_records_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, s.types.p, c.mv_block, c.mv_block,
-                                     c.fg_step, c.bg_step, m.ph, s.records.p, m.record_bytes, m.s_compute),
+                                     0, 0, m.ph, s.records.p, m.record_bytes, m.s_compute),  // raw: see the header
           "svc_hip_dct_records_frames");
     else
       Abi(svc_hip_dct_quant_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, c.dct_block, s.types.p, c.mv_block,

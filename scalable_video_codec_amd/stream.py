@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .configs import CodecConfig
+from . import native
 from .pipeline import ClipEncoder, ransac_samples
 
 
@@ -46,12 +47,14 @@ class HostStreamEncoder:
     """encode(frames) yields, batch by batch, dicts of numpy views into pinned memory:
     first (index of the batch's first encoded frame; frame 0 of a clip is tracked-only,
     libs/encoder.cpp:361-367), mv (n, blocks, 2) f32, types (n, blocks) i32, gm (n, 2) f32 and
-    coeffs (n, 3, H, W) f32 or records (n, bytes) u8.  A view is valid until depth - 1 more batches
-    have been yielded."""
+    coeffs (n, 3, H, W) f32 (quantised) or records (n, bytes) u8 -- the serialised RAW coefficients over the
+    PADDED tile grid, what the reference's decoder parses (libs/decoder.cpp:185-186); the first batch of a wire
+    stream also carries "header", the 32 bytes of libs/codec.hpp:8-17.  A view is valid until depth - 2 more
+    batches have been yielded (its slot is re-staged one iteration before its turn to be yielded comes again)."""
 
     def __init__(self, cfg: CodecConfig, batch: int = 32, device=None, wire: bool = False,
                  segmentation: bool = True, depth: int = 3):
-        self.cfg, self.batch, self.depth = cfg, batch, max(2, depth)
+        self.cfg, self.batch, self.depth = cfg, batch, max(3, depth)  # 2 would leave nothing overlapped
         self.dev = device or torch.device("cuda")
         self.slots = [_Slot(cfg, batch, self.dev, wire, segmentation) for _ in range(self.depth)]
         self.copy_in = torch.cuda.Stream(device=self.dev)
@@ -76,6 +79,12 @@ class HostStreamEncoder:
         assert frames.dtype == np.uint8 and frames.shape[3] == 3 and n_total >= 2
         assert frames.shape[1] <= self.cfg.padded[1] and frames.shape[2] <= self.cfg.padded[0]
         samples = ransac_samples(n_total - 1, self._iters, self._subset, self._blocks, self.cfg.seed, self.dev)
+        # the draws (and the slots' zero-initialised buffers) were produced on the caller's current stream:
+        # the worker streams start behind it
+        cur = torch.cuda.current_stream(self.dev)
+        for s in (self.copy_in, self.compute, self.copy_out):
+            s.wait_stream(cur)
+        self._n_total = n_total
         B = self.batch
         pending: List[_Slot] = []
         prev: Optional[_Slot] = None
@@ -97,10 +106,11 @@ class HostStreamEncoder:
                     e.bgr[0].copy_(prev.enc.bgr[prev.count], non_blocking=True)  # its last frame, either way it was laid out
                 slot.h2d_done.record(self.copy_in)
             g0 = first - 1  # global pair index of this batch's first pair
-            e.samples = samples[g0:g0 + e.pairs_per_step] if g0 + e.pairs_per_step <= n_total - 1 else \
-                torch.cat([samples[g0:], samples[:e.pairs_per_step - (n_total - 1 - g0)]])
             e.seg_seed = self._seg_seed0 + g0
             with torch.cuda.stream(self.compute):
+                # sliced on the stream that consumes them (torch.cat is a kernel)
+                e.samples = samples[g0:g0 + e.pairs_per_step] if g0 + e.pairs_per_step <= n_total - 1 else \
+                    torch.cat([samples[g0:], samples[:e.pairs_per_step - (n_total - 1 - g0)]])
                 self.compute.wait_event(slot.h2d_done)
                 e.step()
                 slot.compute_done.record(self.compute)
@@ -128,4 +138,7 @@ class HostStreamEncoder:
                "gm": slot.pin_gm.numpy()[:c]}
         if slot.pin_big is not None:
             out["records" if slot.enc.wire else "coeffs"] = slot.pin_big.numpy()[:c]
+        if slot.enc.wire and slot.first == 1:
+            c_ = self.cfg
+            out["header"] = native.wire_header(self._n_total, c_.width, c_.height, c_.mv_block, c_.levels, c_.dct_block)
         return out

@@ -4,6 +4,7 @@
 //   stream_main <clip.raw> <w> <h> <frames> <levels> <dct_block> <wire 0|1> <batch> <seed> <out_prefix>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -36,8 +37,21 @@ int main(int argc, char** argv) {
     svc::StreamEncoder enc(cfg);
     uint32_t next = 1, total = 0;
     bool dump = true;
+    // the documented lifetime: a delivered view stays valid until depth - 2 = 1 more batch has been delivered
+    const float* held = nullptr;
+    std::vector<float> held_copy;
     auto sink = [&](const svc::EncodedBatch& b) {
       if (b.first_frame != next) { std::fprintf(stderr, "batch out of order: %u, expected %u\n", b.first_frame, next); std::exit(1); }
+      if (held && std::memcmp(held, held_copy.data(), held_copy.size() * sizeof(float)) != 0) {
+        std::fprintf(stderr, "the previous batch's view changed before its lifetime ended\n"); std::exit(1);
+      }
+      held = b.mv_xy;
+      held_copy.assign(b.mv_xy, b.mv_xy + (size_t)b.count * b.mv_field_w * b.mv_field_h * 2);
+      if ((b.header != nullptr) != (cfg.wire && b.first_frame == 1)) { std::fprintf(stderr, "header on the wrong batch\n"); std::exit(1); }
+      if (b.header && dump) {
+        FILE* f_h = std::fopen((prefix + ".hdr").c_str(), "wb");
+        if (f_h) { std::fwrite(b.header, sizeof(*b.header), 1, f_h); std::fclose(f_h); }
+      }
       next += b.count; total += b.count;
       if (!dump) return;
       const size_t blocks = (size_t)b.mv_field_w * b.mv_field_h;
@@ -50,7 +64,7 @@ int main(int argc, char** argv) {
     enc.Encode(clip.data(), n, sink);
     if (total != n - 1) { std::fprintf(stderr, "%u encoded frames, expected %u\n", total, n - 1); return 1; }
     // the same clip again without the file writes: PCIe-inclusive rate of the schedule itself
-    dump = false; next = 1; total = 0;
+    dump = false; next = 1; total = 0; held = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     enc.Encode(clip.data(), n, sink);
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

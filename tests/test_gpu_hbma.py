@@ -57,6 +57,20 @@ def test_hbma_wave_generic_shapes(native, oracle, bw, bh, r, levels):
     _assert_same(mv, mad, exp_mv, exp_mad, f"{bw}x{bh} R={r} L={levels}")
 
 
+@pytest.mark.parametrize("bw,bh,r", [(512, 4, 2), (260, 4, 3), (1024, 2, 1)])
+def test_hbma_wave_blocks_wider_than_256(native, oracle, bw, bh, r):
+    """One row of a block wider than 256 pixels can exceed 65535 in a packed-u16 SAD lane: near-maximal differences
+    (bright anchor, dark tracked frame) must still give the oracle's MVs and MADs (these blocks take the byte path)."""
+    rng = np.random.default_rng(bw)
+    w, h = bw * 3, bh * 5
+    t = [rng.integers(0, 6, (h, w), dtype=np.uint8)]
+    a = [(250 + rng.integers(0, 6, (h, w))).astype(np.uint8)]
+    exp_mv, exp_mad = oracle.hbma(t, a, r, bw, bh)
+    assert exp_mad.min() > 240
+    mv, mad = native.hbma_host(t, a, r, bw, bh)
+    _assert_same(mv, mad, exp_mv, exp_mad, f"{bw}x{bh}")
+
+
 def test_ebma_host(native, oracle):
     rng = np.random.default_rng(7)
     t = rng.integers(0, 256, (96, 160), dtype=np.uint8)

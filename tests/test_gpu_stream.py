@@ -24,7 +24,14 @@ def test_stream_equals_resident(native, batch, wire):
     host = torch.stack(frames).cpu().numpy()
     enc = stream.HostStreamEncoder(cfg, batch=batch, device=dev, wire=wire)
     seen = 0
+    held = None  # a yielded view stays valid until depth - 2 = 1 more batch has been yielded (stream.py)
     for out in enc.encode(host):
+        if held is not None:
+            assert np.array_equal(held[0], held[1]), "the previous batch's view changed inside its documented lifetime"
+        held = (out["mv"], out["mv"].copy())
+        assert ("header" in out) == (wire and out["first"] == 1)
+        if "header" in out:
+            assert np.frombuffer(out["header"], np.uint32).tolist() == [n - 1, cfg.width, cfg.height, pw - cfg.width, ph - cfg.height, 8, 8, 3]
         a = out["first"] - 1
         c = out["mv"].shape[0]
         assert np.array_equal(out["mv"], ref.mv[a:a + c].cpu().numpy())
@@ -69,5 +76,6 @@ def test_cpp_stream_encoder_equals_resident(native, tmp_path, batch, wire):
     assert np.array_equal(np.fromfile(prefix + ".gm", np.float32).reshape(p, 2), ref.gm.cpu().numpy())
     if wire:
         assert np.array_equal(np.fromfile(prefix + ".big", np.uint8).reshape(p, -1), ref.records.cpu().numpy())
+        assert np.fromfile(prefix + ".hdr", np.uint32).tolist() == [n - 1, cfg.width, cfg.height, pw - cfg.width, ph - cfg.height, 8, 8, 3]
     else:
         assert np.array_equal(np.fromfile(prefix + ".big", np.float32).reshape(p, 3, ph, pw), ref.coeffs.cpu().numpy())
