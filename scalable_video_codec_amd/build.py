@@ -32,6 +32,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
                "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
+# A/B experiments: extra device-compile flags (e.g. -DSVC_HBMA_WAVES8) without editing the sources
+EXTRA_FLAGS = os.environ.get("SVC_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -62,7 +66,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or not _newer(obj, [src] + headers):
-            jobs.append([_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj])
+            jobs.append([_hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-c", src, "-o", obj])
     if jobs:
         if verbose:
             print(f"[build] compiling {len(jobs)} HIP translation unit(s) for gfx950", flush=True)

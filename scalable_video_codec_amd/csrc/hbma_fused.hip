@@ -248,8 +248,14 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
   select<RT, true, SHIFT>(w, ax, ay, [&](int d, int j) { return s[d][j]; }, mvx, mvy, best);
 }
 
+#ifdef SVC_HBMA_WAVES8  // A/B switch: force 64 VGPRs (8 waves per SIMD) at the price of a 24-28 B/lane spill
+#define SVC_HBMA_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define SVC_HBMA_OCC
+#endif
+
 template <int L, int RT>
-__global__ __launch_bounds__(256) void hbma_fused16_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256) SVC_HBMA_OCC void hbma_fused16_kernel(FusedArgs a) {
   const uint32_t item = blockIdx.x * 256u + threadIdx.x;
   if (item >= a.n_items) return;
   const uint32_t pair = item / a.blocks;

@@ -146,15 +146,16 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTW = 128, kTH = 32, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
+constexpr int kTW = 128, kTHBgr = 32, kTHPlane = 64, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
-  const uint8_t* bgr;
+  const uint8_t* bgr;      // FROM_BGR: interleaved frames
   uint64_t frame_stride;
   uint8_t* pyr;
   uint64_t pyr_stride;
-  uint64_t l1_off;  // = w * h
-  uint32_t w, h;
+  uint64_t src_off;  // !FROM_BGR: offset of the source plane inside a packed pyramid
+  uint64_t dst_off;  // offset of the plane this kernel's 5x5 pass writes (FROM_BGR: level 1 = w * h)
+  uint32_t w, h;     // size of the source plane (FROM_BGR: the frame)
   uint32_t tiles_x, tiles_per_frame, total_tiles;
 };
 
@@ -162,7 +163,14 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t b, uint32_t g, uint32_t r) 
   return (1868u * b + 9617u * g + 4899u * r + 8192u) >> 14;
 }
 
+// FROM_BGR: luma from the B,G,R frame -> level 0 (stored) -> level 1.  !FROM_BGR: the same tile machinery on an
+// existing pyramid plane (level l -> l + 1): aligned 16-byte loads of the source rows into LDS, the 5x5 pass out of
+// LDS -- instead of pyr_down_kernel's 7 unaligned dwordx4 loads per 8 outputs straight from L2 (2.3 TB/s).
+// TH: tile height.  32 for the BGR pass (taller tiles push the halo re-reads out of L2, see above); the plane-to-plane
+// pass has a third of the bytes per tile and takes 64 rows, so that a lane has two or three loads in flight.
+template <bool FROM_BGR, int TH>
 __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
+  constexpr int kTH = TH;
   __shared__ __attribute__((aligned(16))) uint8_t tile[(kTH + 4) * kPitch];
   const uint32_t tid = threadIdx.x;
   const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -173,10 +181,11 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
   const int w = (int)a.w, h = (int)a.h;
   const int segs = min(kTW, w - x0) / 16;  // 16-pixel segments of this tile inside the frame
   const int xe = x0 + segs * 16;           // first column right of the tile's valid part
-  const uint8_t* src = a.bgr + (size_t)frame * a.frame_stride;
+  const uint8_t* src = FROM_BGR ? a.bgr + (size_t)frame * a.frame_stride
+                                : a.pyr + (size_t)frame * a.pyr_stride + a.src_off;
   uint8_t* y_plane = a.pyr + (size_t)frame * a.pyr_stride;
 
-  // Rows past y = h are never needed (the last level-1 row is centred on h - 2, its taps end at
+  // Rows past y = h are never needed (the last output row is centred on h - 2, its taps end at
   // row h) and must not be touched: reflect101 folds once, so a row further out would index
   // outside the frame (short frames: found by tests/test_gpu_misc_property.py).
   const int rows = min(kTH + 4, h - y0 + 3);  // LDS rows 0 .. rows-1 <-> y = y0 - 2 .. min(y0 + 33, h)
@@ -185,29 +194,38 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     const int r = task / segs, sgm = task - r * segs;
     const int y = y0 - 2 + r, yr = reflect101(y, h);
     const int x = x0 + sgm * 16;
-    const uint4* p = reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3);
-    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-    const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-    uint32_t out[4];
-    luma16(wd, out);
-    const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
+    uint4 o4;
+    if (FROM_BGR) {
+      const uint4* p = reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3);
+      const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+      const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+      uint32_t out[4];
+      luma16(wd, out);
+      o4 = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+      o4 = *reinterpret_cast<const uint4*>(src + (size_t)yr * w + x);
+    }
     *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;  // 16-byte aligned (Guideline 17)
-    if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
+    if (FROM_BGR && r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
   }
   // (b) halo pixels: two columns on each side of the valid part, every row
   for (int task = (int)tid; task < rows * 4; task += 256) {
     const int r = task >> 2, k = task & 3;
     const int yr = reflect101(y0 - 2 + r, h);
     const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
-    const uint8_t* p = src + ((size_t)yr * w + reflect101(x, w)) * 3;
-    tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
+    if (FROM_BGR) {
+      const uint8_t* p = src + ((size_t)yr * w + reflect101(x, w)) * 3;
+      tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
+    } else {
+      tile[r * kPitch + kOff + (x - x0)] = src[(size_t)yr * w + reflect101(x, w)];
+    }
   }
   __syncthreads();
 
-  // (c) level 1: lane = (output row, quad of 4 output columns)
-  constexpr int kQuads = kTW / 8;  // quads of level-1 columns per tile row
+  // (c) next level: lane = (output row, quad of 4 output columns)
+  constexpr int kQuads = kTW / 8;  // quads of output columns per tile row
   const int q = (int)tid % kQuads;
-  const int gx = (x0 >> 1) + 4 * q;  // level-1 coordinates
+  const int gx = (x0 >> 1) + 4 * q;  // output-level coordinates
   if (gx >= (w >> 1)) return;
   const int taps[5] = {1, 4, 6, 4, 1};
   for (int oy = (int)tid / kQuads; oy < kTH / 2; oy += 256 / kQuads) {
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     uint32_t out = 0;
 #pragma unroll
     for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
-    *reinterpret_cast<uint32_t*>(y_plane + a.l1_off + (size_t)gy * (w >> 1) + gx) = out;
+    *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)gy * (w >> 1) + gx) = out;
   }
 }
 static_assert(kPitch % 16 == 0 && kOff % 16 == 0, "LDS rows keep 16-byte alignment for the ds_write_b128");
@@ -262,19 +280,19 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
   uint32_t first_plain_level = 0;
   // level-1 width must be a multiple of 4 for the fused kernel's dword stores
   if (levels >= 2 && (w / 2) % 4 == 0 && h % 2 == 0) {
-    LumaPyr1Args fa;
+    LumaPyr1Args fa{};
     fa.bgr = d_bgr;
     fa.frame_stride = frame_stride;
     fa.pyr = d_pyr;
     fa.pyr_stride = pyr_stride;
-    fa.l1_off = (uint64_t)w * h;
+    fa.dst_off = (uint64_t)w * h;
     fa.w = w; fa.h = h;
     fa.tiles_x = div_up(w, kTW);
-    fa.tiles_per_frame = fa.tiles_x * div_up(h, kTH);
+    fa.tiles_per_frame = fa.tiles_x * div_up(h, kTHBgr);
     const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
     if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many tiles for one launch");
     fa.total_tiles = (uint32_t)tt;
-    hipLaunchKernelGGL(luma_pyr1_kernel, dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+    hipLaunchKernelGGL((luma_pyr1_kernel<true, kTHBgr>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
     if ((rc = check_launch("luma_pyr1_kernel"))) return rc;
     first_plain_level = 1;
   } else {
@@ -294,6 +312,24 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     pa.dst_off = off;
     pa.quads_per_row = pa.dw / 4;
     if (l < first_plain_level) continue;  // produced by luma_pyr1_kernel
+    // the LDS-tiled pass: source rows are read as aligned 16-byte segments
+    if (pa.sw % 16 == 0 && pa.sh % 2 == 0 && pa.dw % 4 == 0 && pa.src_off % 16 == 0 && pyr_stride % 16 == 0 &&
+        (reinterpret_cast<uintptr_t>(d_pyr) & 15) == 0 && pa.sh >= 3) {
+      LumaPyr1Args fa{};
+      fa.pyr = d_pyr;
+      fa.pyr_stride = pyr_stride;
+      fa.src_off = pa.src_off;
+      fa.dst_off = pa.dst_off;
+      fa.w = pa.sw; fa.h = pa.sh;
+      fa.tiles_x = div_up(pa.sw, kTW);
+      fa.tiles_per_frame = fa.tiles_x * div_up(pa.sh, kTHPlane);
+      const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
+      if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many tiles for one launch");
+      fa.total_tiles = (uint32_t)tt;
+      hipLaunchKernelGGL((luma_pyr1_kernel<false, kTHPlane>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+      if ((rc = check_launch("luma_pyr1_kernel<false>"))) return rc;
+      continue;
+    }
     if (pa.quads_per_row < 2) return fail(SVC_ERR_UNSUPPORTED, "pyramid: level %u is narrower than 16 pixels", l);
     const uint64_t tot = (uint64_t)n_frames * ((pa.dh + 1) / 2) * pa.quads_per_row;
     if (tot > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many pixels for one launch");
