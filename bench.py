@@ -267,8 +267,11 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     enc.reset_timers()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        enc.step(timed=not args.graph)
+    # HIP events around every stage cost 20-45 us per step (tools/diag_step_overhead.py): they are recorded on every
+    # `stride`-th step of the timed region, which is what the per-kernel averages below are taken over
+    stride = 1 if args.steps < 8 else args.time_every
+    for k in range(args.steps):
+        enc.step(timed=(not args.graph) and k % stride == 0)
     enc.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -280,10 +283,12 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(encoded, op=dist.ReduceOp.SUM)
     st = enc.stage_times_ms()
+    timed_steps = len(range(0, args.steps, stride))
     res = {
         "elapsed": float(t.item()), "encoded_per_step": float(encoded.item()), "info": info, "halo": halo,
-        "stage_ms_per_step": {k: v[0] / args.steps for k, v in st.items()},
-        "launches_per_step": {k: v[1] / args.steps for k, v in st.items()},
+        "stage_ms_per_step": {k: v[0] / timed_steps for k, v in st.items()},
+        "launches_per_step": {k: v[1] / timed_steps for k, v in st.items()},
+        "timed_steps": timed_steps,
         "sample_frames": sample_frames, "clip_frames": clip_frames,
     }
     enc.close()
@@ -308,6 +313,7 @@ def main() -> None:
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
+    ap.add_argument("--time-every", type=int, default=4, help="record the per-stage HIP events on every n-th timed step (every step when --steps < 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     args = ap.parse_args()
@@ -336,11 +342,33 @@ def main() -> None:
     native.load()
     clipmod.load()
     torch.set_num_threads(min(8, torch.get_num_threads()))  # CPU share of a 1-GPU box is small
+    comm_note = None
     if world > 1 and backend == "nccl" and os.environ.get("SVC_HALO", "rccl") == "rccl":
-        # the C ABI's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
-        box = [clipmod.comm_unique_id() if rank == 0 else None]
+        # the C ABI's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes.  Every rank
+        # learns whether EVERY rank got its communicator; if not, all of them use the torch.distributed transport
+        # (also RCCL) -- the decision must be collective or the ranks would wait on different transports.
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            box = [clipmod.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            box, comm_note = [None], f"svc_hip_comm_unique_id failed: {e}"
         dist.broadcast_object_list(box, src=0, device=dev)
-        comm = clipmod.comm_create(box[0], rank, world)
+        if box[0] is not None:
+            try:
+                comm = clipmod.comm_create(box[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                ok.zero_()
+                comm_note = f"svc_hip_comm_create failed on rank {rank}: {e}"
+        else:
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                clipmod.comm_destroy(comm)
+            comm = None
+            comm_note = comm_note or "another rank could not create its communicator"
+            if rank == 0:
+                print(f"bench.py: C-ABI RCCL communicator unavailable ({comm_note}); halo via torch.distributed P2P", file=sys.stderr)
 
     cfg = configs.ALL[args.config]
     modes = ["strong"] if world == 1 else (["strong", "weak"] if args.scaling == "both" else [args.scaling])
@@ -382,6 +410,7 @@ def main() -> None:
                 "parallelism": f"frame-sharded x{world}" + (f", halo = 1 pyramid/rank/step via {r['halo']}" if world > 1 else ""),
             },
             "kernel_ms_per_step": kt,
+            "kernel_timing": f"HIP events on the launch streams, {r['timed_steps']} of the {args.steps} timed steps",
         }
         if world > 1:
             out["halo_exchange_ms"] = kt.get("halo_exchange")
