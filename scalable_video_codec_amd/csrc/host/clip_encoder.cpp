@@ -309,7 +309,9 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   m.seg_ws_bytes = c.segmentation ? svc_hip_segment_workspace_bytes(m.mfw, m.mfh, std::max(P, 1u), c.segment.attempt_count) : 0;
   // All three at the default priority.  Measured on MI355X (38-frame shard, pipelined): raising the second and
   // the communication stream stretched the main stream's HBM-bound kernels 1.8x (0.41 -> 0.64 ms per step), and
-  // a low-priority main stream was slower still (0.79).
+  // a low-priority main stream was slower still (0.79).  Confining the second stream to every 2nd / 4th / 8th CU
+  // (hipExtStreamCreateWithCUMask) cost as much: 0.37 -> 0.52-0.55 ms at 38 frames, 2.52 -> 2.76-2.78 ms at 300
+  // (profiles/r02_cu_mask.txt).
   for (hipStream_t* s : {&m.sM, &m.sL, &m.sC}) Hip(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreate");
   for (hipEvent_t* e : {&m.e_pyr[0], &m.e_pyr[1], &m.e_halo[0], &m.e_halo[1], &m.e_fork, &m.e_join[0], &m.e_join[1]})
     Hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");

@@ -38,7 +38,9 @@ def test_bench_line_contract():
     assert d["hbm_streaming_measured"]["read_only"] > 1000
     assert not any(k.startswith("frac_of_streaming") for k in r)
     assert "traffic_source" in r and d["config"]["driver"].startswith("svc::ClipEncoder")
-    assert set(d["kernel_ms_per_step"]) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
+    assert set(d["kernel_ms_per_step"]) == {"luma_pyramid", "hbma", "dct_quant"}  # the main stream, back to back
+    assert set(d["overlapped_ms_per_step"]) == {"ransac", "segment", "note"}        # beside it (pipelined schedule)
+    assert sum(d["kernel_ms_per_step"].values()) <= d["ms_per_step"] * 1.02
 
 
 def test_bench_other_config_and_flags():
@@ -49,6 +51,7 @@ def test_bench_other_config_and_flags():
 def test_bench_serial_schedule_and_graph():
     d = _run("--frames", "10", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--schedule", "serial", "--no-hbm-probe")
     assert "roofline" in d and "one stream" in d["config"]["schedule"]
+    assert set(d["kernel_ms_per_step"]) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"} and "overlapped_ms_per_step" not in d
     g = _run("--frames", "10", "--steps", "6", "--warmup", "4", "--no-cpu-baseline", "--graph", "--no-hbm-probe")
     assert "roofline" not in g and "hipGraph" in g["config"]["schedule"] and g["value"] > 0
 
