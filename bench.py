@@ -411,7 +411,7 @@ def main() -> None:
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
                 "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-3) back to back on one stream; "
-                             "RANSAC+segmentation(s-2) beside them on a second; halo(s) on a third" if args.schedule == "pipelined"
+                             "RANSAC+segmentation(s-2) beside them on a second (forked behind the motion search when a whole long clip is on the GPU, at the start of the iteration on shards); halo(s) on a third" if args.schedule == "pipelined"
                              else "one stream, stages back to back") + ("; steady-state iteration replayed from a hipGraph" if args.graph else ""),
                 "driver": "svc::ClipEncoder (C++, include/svc/clip_encoder.hpp)",
                 "parallelism": f"frame-sharded x{world}" + (f", halo = 1 pyramid/rank/step via {r['halo']}" if world > 1 else ""),
@@ -453,7 +453,7 @@ def main() -> None:
                 "avg_launch_ms": hbma_ms,
                 "launches_per_step": nl["hbma"],
                 "note": "HBM is the stated bound; measured VALU busy ~86 % (byte-SAD ops issue at 4 cycles/wave): VALU time ~= HBM floor, DESIGN.md 4.1"
-                        + ("; timed beside the previous step's RANSAC + segmentation kernels (pipelined schedule)" if args.schedule == "pipelined" else ""),
+                        + ("; on shards (N > 1, short clips) it is timed beside the previous step's RANSAC + segmentation kernels (pipelined schedule, early fork)" if args.schedule == "pipelined" else ""),
             }
             if "dct_quant" in kt:
                 dct_bytes = cfg.dct_bytes_per_frame() * info.pairs

@@ -80,6 +80,11 @@ struct ClipEncoder::Impl {
   HaloFn halo;
   // pipeline progress: steps whose stage has been enqueued
   uint64_t n_luma = 0, n_hbma = 0, n_lat = 0, n_dct = 0;
+  // Where RANSAC + segmentation fork off the main stream.  Measured at C3 (ms per step, late / early fork): 300 frames
+  // 2.558 / 2.554, 150 frames 1.353 / 1.310, 75 frames 0.726 / 0.689, 38 frames 0.419 / 0.376.  With a whole clip on the
+  // GPU the two are equal and the late fork keeps the MAD kernel alone on the chip (0.274 vs 0.297 ms); on the shards of
+  // a multi-GPU run the early fork gives the latency-bound stages the whole iteration to hide behind.
+  bool fork_early = false;
   bool fused_records = false;  // wire output straight from the 8x8 / 16x16 transform kernel
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
@@ -198,7 +203,8 @@ struct ClipEncoder::Impl {
     });
   }
 
-  // RANSAC + segmentation of step l on the second stream, behind everything the main stream holds so far;
+  // RANSAC + segmentation of step l on the second stream, behind everything the main stream holds so far (the
+  // motion search of this iteration included);
   // the main stream picks the result up (JoinLat) only where it is needed, an iteration later.
   void ForkLat(uint64_t l, bool timing) {
     Hip(hipEventRecord(e_fork, sM), "hipEventRecord");
@@ -217,8 +223,8 @@ struct ClipEncoder::Impl {
   // step h on the main stream with the transform of step h - 2 behind it, RANSAC + segmentation of step
   // h - 1 beside them on the second stream.
   void Block(uint64_t h, uint64_t l, uint64_t d) {
-    ForkLat(l, false);
     Hbma(h, sM, false);
+    ForkLat(l, false);
     Transform(d, sM, false);
     JoinLat(l);
   }
@@ -226,13 +232,13 @@ struct ClipEncoder::Impl {
   // One iteration of the software pipeline.  Buffer hazards (sets alternate with the step's parity):
   //   lat(l) reads mv[l], writes mask/types[l]   | beside it: hbma(l + 1) writes mv[l + 1], transform(l - 1)
   //   reads types[l - 1] -- disjoint; the NEXT iteration's hbma(l + 2) and transform(l) touch set l again, so the
-  //   main stream joins lat(l) there, after the next luma: lat(l) has luma + hbma + transform + luma to hide behind.
+  //   main stream joins lat(l) there, after the next luma: lat(l) has the transform + the next luma to hide behind.
   void Iterate(bool new_step, bool timing) {
     const uint64_t lumas = n_luma, hbmas = n_hbma, lats = n_lat;
     const bool do_hbma = n_hbma < lumas, do_lat = n_lat < hbmas, do_dct = n_dct < lats;
     const uint64_t h = n_hbma, l = n_lat, d = n_dct;
     const bool replay = c.graph && do_hbma && do_lat && do_dct && !timing;
-    if (do_lat && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
+    if (do_lat && fork_early && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
     if (new_step) {
       const uint64_t s = n_luma;
       const int b = Par(s);
@@ -263,6 +269,9 @@ struct ClipEncoder::Impl {
       Hip(hipGraphLaunch(gexec[b], sM), "hipGraphLaunch");
     } else {
       if (do_hbma) Hbma(h, sM, timing);
+      // big shards: forked BEHIND the motion search -- RANSAC + segmentation run beside the transform (the long,
+      // store-bound kernel) and the next step's luma + pyramid, never beside the MAD kernel
+      if (do_lat && !fork_early) ForkLat(l, timing);
       if (do_dct) Transform(d, sM, timing);
     }
     n_hbma += do_hbma; n_lat += do_lat; n_dct += do_dct;
@@ -295,6 +304,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   if ((c.dct_block_w == 0) != (c.dct_block_h == 0))
     throw std::runtime_error("svc::ClipEncoder: transform block needs both sides");
   m.sh = PlanShard(c.clip_frames, c.world, c.rank);
+  m.fork_early = c.world > 1 || (uint64_t)m.sh.pairs * ((uint64_t)((c.width + c.mv_block - 1) / c.mv_block) * ((c.height + c.mv_block - 1) / c.mv_block)) < 1600000ull;
   const uint32_t f = 1u << (c.levels - 1);
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
   m.ph = ClosestLargerDivisible(c.height, c.mv_block, f);
