@@ -17,6 +17,9 @@ groups=(
   "TCC_HIT_sum TCC_MISS_sum"
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
   "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum"
+  "GRBM_TA_BUSY"  # the TA_* block counters hang rocprofv3 on this pool (two 300 s timeouts): not collected
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+  "TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
 )
 for i in ${PMC_GROUPS:-1 2 3 4 5}; do
   grp=${groups[$((i-1))]}
