@@ -26,6 +26,8 @@
 // dyadic rational; the MAD carried across levels (libs/motion.cpp:401 compares a
 // level-l MAD with the level-(l+1) minimum) is kept as the integer sad << 2l
 // (units of 1/256) and converted once at the end: bit-identical to the float path.
+#include <cstdlib>
+
 #include "svc_common.hpp"
 
 namespace svc {
@@ -38,6 +40,8 @@ struct FusedArgs {
   const uint8_t* anchor;
   uint64_t pair_stride;
   uint32_t n_items;  // pairs * blocks
+  uint32_t n_pairs;
+  uint32_t wgs_per_region;  // 0: pair-major order; else workgroups of a frame per XCD region (see the kernel)
   uint32_t blocks;
   uint32_t mfw;
   uint32_t w, h;     // base-level frame size
@@ -256,10 +260,24 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
 
 template <int L, int RT>
 __global__ __launch_bounds__(256) SVC_HBMA_OCC void hbma_fused16_kernel(FusedArgs a) {
-  const uint32_t item = blockIdx.x * 256u + threadIdx.x;
-  if (item >= a.n_items) return;
-  const uint32_t pair = item / a.blocks;
-  const uint32_t blk = item - pair * a.blocks;
+  uint32_t item, pair, blk;
+  if (a.wgs_per_region) {
+    // Region-major order.  Workgroups are dealt round-robin over the 8 XCDs, so XCD x gets blockIdx 8k + x: it is
+    // given the x-th eighth of the frame (a band of block rows) of EVERY pair, pairs in order.  The pyramid of frame
+    // p + 1 is the anchor of pair p and the tracked frame of pair p + 1: the two workgroups that read a band of it are
+    // neighbours in one XCD's dispatch sequence, so the second read is served by that XCD's L2 instead of crossing the
+    // fabric again.  Speed only: any placement gives the same result.
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    pair = k / a.wgs_per_region;
+    blk = (xcd * a.wgs_per_region + (k - pair * a.wgs_per_region)) * 256u + threadIdx.x;
+    if (pair >= a.n_pairs || blk >= a.blocks) return;
+    item = pair * a.blocks + blk;
+  } else {
+    item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= a.n_items) return;
+    pair = item / a.blocks;
+    blk = item - pair * a.blocks;
+  }
   const int by = (int)(blk / a.mfw), bx = (int)(blk - (uint32_t)by * a.mfw);
 
   const uint8_t* trk = a.tracked + (size_t)pair * a.pair_stride;
@@ -313,7 +331,12 @@ int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_
   a.w = w; a.h = h;
   a.mv = d_mv;
   a.mad = d_mad;
-  const dim3 grid(div_up(a.n_items, 256)), block(256);
+  a.n_pairs = n_pairs;
+  const char* order = std::getenv("SVC_HBMA_ORDER");  // A/B switch: "pair" = the round-1 pair-major order
+  a.wgs_per_region = (order && order[0] == 'p') ? 0u : div_up(div_up(a.blocks, 256), 8);
+  const uint64_t wgs = a.wgs_per_region ? (uint64_t)8 * a.wgs_per_region * n_pairs : div_up(a.n_items, 256);
+  if (wgs > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu workgroups exceed one launch", (unsigned long long)wgs);
+  const dim3 grid((uint32_t)wgs), block(256);
   const uint32_t rt = range >> (levels - 1);
   if (levels == 3 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<3, 2>), grid, block, 0, stream, a);
   else if (levels == 3 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<3, 1>), grid, block, 0, stream, a);
