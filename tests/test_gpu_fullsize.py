@@ -100,7 +100,7 @@ def test_dct_energy_dc_and_quant_properties(native, encoded):
 
 
 def test_wire_mode_agrees_with_the_plain_step(native):
-    """The fused record output is a layout choice: the records must be the planar step's coefficients serialised
+    """The fused record output is a layout choice: the records must be the raw transform's coefficients serialised
     (schedules -- serial, pipelined, hipGraph -- are checked in tests/test_gpu_clip.py)."""
     cfg = configs.C2
     dev = torch.device("cuda")
@@ -116,8 +116,13 @@ def test_wire_mode_agrees_with_the_plain_step(native):
     wired.step()
     torch.cuda.synchronize()
     assert torch.equal(base.types, wired.types)
-    want = native.serialize_frames(base.coeffs, base.types, pw, ph, 8, 8, base.mfw, base.mfh)
+    # records carry the RAW coefficients, as the reference's encoder serialises them (libs/encoder.cpp:638-650)
+    raw = native.dct_frames(base.bgr[1:].contiguous(), 8)
+    want = native.serialize_frames(raw, base.types, pw, ph, 8, 8, base.mfw, base.mfh)
     assert torch.equal(wired.records, want)
+    q = raw.clone()
+    native.quant_frames_(q, base.types, cfg.mv_block, cfg.fg_step, cfg.bg_step)
+    assert torch.equal(q, base.coeffs)  # ... and the planar output is their quantised form
 
 
 def test_8k_frame_pair(native, oracle):
