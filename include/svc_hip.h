@@ -128,6 +128,17 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
                           uint8_t* d_inlier_mask, uint32_t* d_inlier_count,
                           void* stream);
 
+/* The same with launch flags.  SVC_LAUNCH_BESIDE: the caller runs this launch on a second stream BESIDE
+ * bandwidth-bound kernels (a software-pipelined encoder): pick workgroup shapes that fit on a CU next to them (256
+ * lanes, one wave per SIMD, a few KB of LDS) instead of the shapes that are fastest alone (1024-lane workgroups that
+ * need a whole CU's registers and would not start until the other kernel drains).  Results are identical. */
+#define SVC_LAUNCH_BESIDE 1u
+int svc_hip_ransac_frames_ex(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
+                             svc_ransac_params params, const uint32_t* d_samples,
+                             uint32_t iter_count, float* d_gm_xy, float* d_rmse,
+                             uint8_t* d_inlier_mask, uint32_t* d_inlier_count, uint32_t flags,
+                             void* stream);
+
 /* In-repo part of the segmentation glue, libs/encoder.cpp:507-513 + :549-551:
  * foreground = not a RANSAC inlier; d_block_types [n_frames][blocks] gets 0
  * (BLOCK_TYPE_BACKGROUND, libs/codec.hpp:6) for inliers and region id 1 for the
@@ -151,6 +162,14 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy,
                            svc_segment_params params, uint64_t seed,
                            uint8_t* d_workspace, uint64_t workspace_bytes,
                            uint32_t* d_block_types, void* stream);
+
+/* svc_hip_segment_frames with launch flags (SVC_LAUNCH_BESIDE, see svc_hip_ransac_frames_ex). */
+int svc_hip_segment_frames_ex(const uint8_t* d_inlier_mask, const float* d_mv_xy,
+                              uint32_t mv_field_w, uint32_t mv_field_h, uint32_t n_frames,
+                              uint32_t mv_block_w, uint32_t mv_block_h,
+                              svc_segment_params params, uint64_t seed,
+                              uint8_t* d_workspace, uint64_t workspace_bytes,
+                              uint32_t* d_block_types, uint32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Transform.  d_bgr: n_frames frames of H x W x 3 u8, interleaved B,G,R (the

@@ -149,6 +149,13 @@ uint32_t svc_hip_ransac_iter_count(svc_ransac_params p) {
 int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
                           const uint32_t* d_samples, uint32_t iter_count, float* d_gm_xy, float* d_rmse,
                           uint8_t* d_inlier_mask, uint32_t* d_inlier_count, void* stream) {
+  return svc_hip_ransac_frames_ex(d_mv_xy, blocks, n_frames, params, d_samples, iter_count, d_gm_xy, d_rmse, d_inlier_mask,
+                                  d_inlier_count, 0, stream);
+}
+
+int svc_hip_ransac_frames_ex(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
+                             const uint32_t* d_samples, uint32_t iter_count, float* d_gm_xy, float* d_rmse,
+                             uint8_t* d_inlier_mask, uint32_t* d_inlier_count, uint32_t flags, void* stream) {
   if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_mv_xy && d_gm_xy && d_rmse && d_inlier_mask && d_inlier_count, "ransac: null pointer (motion.cpp:189-192)");
   SVC_REQUIRE(iter_count == 0 || d_samples, "ransac: null samples");
@@ -156,7 +163,7 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
               "ransac: motion field of %u smaller than subset %u (motion.cpp:194)", blocks, params.subset_sz);
   SVC_REQUIRE(aligned(d_mv_xy, 8), "ransac: motion field must be 8-byte aligned");
   return launch_ransac(d_mv_xy, blocks, n_frames, params, d_samples, iter_count, d_gm_xy, d_rmse,
-                       d_inlier_mask, d_inlier_count, static_cast<hipStream_t>(stream));
+                       d_inlier_mask, d_inlier_count, flags, static_cast<hipStream_t>(stream));
 }
 
 int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks, uint32_t n_frames,
@@ -233,6 +240,14 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, u
                            uint32_t mv_field_h, uint32_t n_frames, uint32_t mv_block_w, uint32_t mv_block_h,
                            svc_segment_params params, uint64_t seed, uint8_t* d_workspace,
                            uint64_t workspace_bytes, uint32_t* d_block_types, void* stream) {
+  return svc_hip_segment_frames_ex(d_inlier_mask, d_mv_xy, mv_field_w, mv_field_h, n_frames, mv_block_w, mv_block_h, params,
+                                   seed, d_workspace, workspace_bytes, d_block_types, 0, stream);
+}
+
+int svc_hip_segment_frames_ex(const uint8_t* d_inlier_mask, const float* d_mv_xy, uint32_t mv_field_w,
+                              uint32_t mv_field_h, uint32_t n_frames, uint32_t mv_block_w, uint32_t mv_block_h,
+                              svc_segment_params params, uint64_t seed, uint8_t* d_workspace,
+                              uint64_t workspace_bytes, uint32_t* d_block_types, uint32_t flags, void* stream) {
   if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue
   SVC_REQUIRE(d_inlier_mask && d_mv_xy && d_block_types && d_workspace, "segment: null pointer");
   SVC_REQUIRE(mv_field_w > 0 && mv_field_h > 0 && mv_block_w > 0 && mv_block_h > 0, "segment: empty motion field");
@@ -249,7 +264,7 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, u
               (unsigned long long)svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames, params.attempt_count));
   SVC_REQUIRE(aligned(d_workspace, 16) && aligned(d_mv_xy, 8), "segment: workspace must be 16-byte, motion field 8-byte aligned");
   return launch_segment(d_inlier_mask, d_mv_xy, mv_field_w, mv_field_h, n_frames, mv_block_w, mv_block_h, params,
-                        seed, d_workspace, d_block_types, static_cast<hipStream_t>(stream));
+                        seed, d_workspace, d_block_types, flags, static_cast<hipStream_t>(stream));
 }
 
 static int validate_dct(const void* in, const void* out, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh) {
@@ -507,7 +522,7 @@ int svc_hip_ransac_host(const float* mv_xy, uint32_t blocks, svc_ransac_params p
   uint8_t* d = g_stage.dev;
   float* d_misc = reinterpret_cast<float*>(d + mv_b + smp_b + mask_b);
   rc = launch_ransac(reinterpret_cast<const float*>(d), blocks, 1, params, reinterpret_cast<const uint32_t*>(d + mv_b),
-                     iter_count, d_misc, d_misc + 2, d + mv_b + smp_b, reinterpret_cast<uint32_t*>(d_misc + 3),
+                     iter_count, d_misc, d_misc + 2, d + mv_b + smp_b, reinterpret_cast<uint32_t*>(d_misc + 3), 0,
                      g_stage.stream);
   if (rc) return rc;
   SVC_HIP_TRY(hipMemcpyAsync(p + mv_b + smp_b, d + mv_b + smp_b, mask_b + misc_b, hipMemcpyDeviceToHost, g_stage.stream));

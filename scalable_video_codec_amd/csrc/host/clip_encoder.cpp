@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -85,6 +86,8 @@ struct ClipEncoder::Impl {
   // GPU the two are equal and the late fork keeps the MAD kernel alone on the chip (0.274 vs 0.297 ms); on the shards of
   // a multi-GPU run the early fork gives the latency-bound stages the whole iteration to hide behind.
   bool fork_early = false;
+  // pipelined schedule: RANSAC + segmentation run beside the main stream's kernels and ask for shapes that fit there
+  uint32_t lat_flags = 0;
   bool fused_records = false;  // wire output straight from the 8x8 / 16x16 transform kernel
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
@@ -171,13 +174,14 @@ struct ClipEncoder::Impl {
     const uint64_t g0 = sh.first_encoded - 1;  // clip-wide index of the shard's first pair
     Run(Stage::kRansac, st, timing, [&] {
       Hip(hipMemsetAsync(gm[b].p, 0, gm[b].bytes(), st), "hipMemsetAsync");  // in/out, libs/motion.cpp:241-242
-      Abi(svc_hip_ransac_frames(mv[b].p, blocks, sh.pairs, c.ransac, samples.p, iters, gm[b].p, rmse[b].p, mask[b].p,
-                                count[b].p, st), "svc_hip_ransac_frames");
+      Abi(svc_hip_ransac_frames_ex(mv[b].p, blocks, sh.pairs, c.ransac, samples.p, iters, gm[b].p, rmse[b].p, mask[b].p,
+                                   count[b].p, lat_flags, st), "svc_hip_ransac_frames");
     });
     Run(Stage::kSegment, st, timing, [&] {
       if (c.segmentation)
-        Abi(svc_hip_segment_frames(mask[b].p, mv[b].p, mfw, mfh, sh.pairs, c.mv_block, c.mv_block, c.segment,
-                                   c.seed * 1000003ull + g0, seg_ws.p, seg_ws_bytes, types[b].p, st), "svc_hip_segment_frames");
+        Abi(svc_hip_segment_frames_ex(mask[b].p, mv[b].p, mfw, mfh, sh.pairs, c.mv_block, c.mv_block, c.segment,
+                                      c.seed * 1000003ull + g0, seg_ws.p, seg_ws_bytes, types[b].p, lat_flags, st),
+            "svc_hip_segment_frames");
       else
         Abi(svc_hip_block_types_frames(mask[b].p, blocks, sh.pairs, types[b].p, st), "svc_hip_block_types_frames");
     });
@@ -304,6 +308,10 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   if ((c.dct_block_w == 0) != (c.dct_block_h == 0))
     throw std::runtime_error("svc::ClipEncoder: transform block needs both sides");
   m.sh = PlanShard(c.clip_frames, c.world, c.rank);
+  {
+    const char* e = std::getenv("SVC_LAUNCH_BESIDE");  // A/B switch: "0" keeps the stand-alone shapes
+    m.lat_flags = (c.schedule == Schedule::kPipelined && !(e && e[0] == '0')) ? SVC_LAUNCH_BESIDE : 0u;
+  }
   m.fork_early = c.world > 1 || (uint64_t)m.sh.pairs * ((uint64_t)((c.width + c.mv_block - 1) / c.mv_block) * ((c.height + c.mv_block - 1) / c.mv_block)) < 1600000ull;
   const uint32_t f = 1u << (c.levels - 1);
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168

@@ -477,7 +477,7 @@ int launch_block_types(const uint8_t* d_mask, uint64_t n, uint32_t* d_types, hip
 
 int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
                   const uint32_t* d_samples, uint32_t iters, float* d_gm, float* d_rmse,
-                  uint8_t* d_mask, uint32_t* d_count, hipStream_t stream) {
+                  uint8_t* d_mask, uint32_t* d_count, uint32_t flags, hipStream_t stream) {
   if (n_frames == 0) return SVC_OK;
   RansacArgs a;
   a.mv = d_mv;
@@ -491,7 +491,13 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ran
   a.mask = d_mask;
   a.count = d_count;
   constexpr size_t kStage = kChunk * sizeof(float2);
-  if (blocks <= 8 * 256)
+  // SVC_LAUNCH_BESIDE: 256 lanes x 32 blocks in registers -- one wave per SIMD, which fits next to the transform
+  // kernel's waves; a 1 024-lane workgroup of this kernel (4 waves x 114-128 VGPRs on every SIMD) needs an empty CU and
+  // would only start once the kernel it was meant to run beside has drained.  Alone it is slower (0.10 vs 0.08 ms for
+  // 300 frames at 1080p: a quarter of the lanes for the parallel phases, the same serial RMSE chain).
+  if ((flags & SVC_LAUNCH_BESIDE) && blocks > 8 * 256 && blocks <= 32 * 256)
+    hipLaunchKernelGGL((ransac_reg_kernel<256, 32, 1>), dim3(n_frames), dim3(256), kStage, stream, a, n_frames);
+  else if (blocks <= 8 * 256)
     hipLaunchKernelGGL((ransac_reg_kernel<256, 8, 1>), dim3(n_frames), dim3(256), kStage, stream, a, n_frames);
   else if (blocks <= 8 * 1024 && n_frames <= 256)  // one workgroup per CU as it is
     hipLaunchKernelGGL((ransac_reg_kernel<1024, 8, 1>), dim3(n_frames), dim3(1024), kStage, stream, a, n_frames);

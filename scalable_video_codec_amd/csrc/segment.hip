@@ -39,6 +39,7 @@ struct SegArgs {
   uint32_t lds_bytes;    // dynamic LDS of the attempt kernel
   uint32_t bits_bytes;   // ... of which the bit fields at its start
   uint32_t packable;     // host check: field <= 512 x 512 blocks and x_px, y_px < 2^14 (32-bit distances)
+  uint32_t take_all;     // the 256-lane attempt kernel also takes the heavy frames (no 1024-lane launch)
 };
 
 constexpr uint32_t kMaxK = 64;
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const uint32_t nf = *ws.nf();
-  if (nf == 0 || (nf > kLightMax) != (T == kTA)) return;
+  if (nf == 0 || (!a.take_all && (nf > kLightMax) != (T == kTA))) return;
   const uint32_t te = T == kTA ? kTA : nf <= 256 ? 64u : 256u;  // one wave: no barrier ever waits
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
   uint8_t* lab = ws.lab(att);
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   if (packed && nf <= kRegPts * te) {
     compact = kmeans_regs<kRegPts>(ws.pk(), lab, L, a, nf, k, aseed, tid, te, stamps);
   } else if (packed) {
-    const size_t lds_cap = T == kTA ? a.lds_bytes : 8 * kLightMax;
+    const size_t lds_cap = T == kTA ? a.lds_bytes : 0;  // the 256-lane launch has no dynamic LDS: workspace
     uint32_t* pk = ws.pk();
     uint32_t* dmin = ws.dmin(att);
     if (4 * (size_t)nf <= lds_cap) {
@@ -1093,7 +1094,7 @@ uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts) {
 
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
                    uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,
-                   uint32_t* d_types, hipStream_t stream) {
+                   uint32_t* d_types, uint32_t flags, hipStream_t stream) {
   if (n_frames == 0) return SVC_OK;
   if (p.cluster_count > kMaxK)
     return fail(SVC_ERR_UNSUPPORTED, "segment: cluster_count %u exceeds %u", p.cluster_count, kMaxK);
@@ -1125,9 +1126,21 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   if (a.bits_bytes + 4096 > kLdsBig)
     return fail(SVC_ERR_UNSUPPORTED, "segment: motion field of %u x %u blocks is too large", mfw, mfh);
   a.lds_bytes = (uint32_t)(a.bits_bytes + 4 * n4 <= kLdsBig ? a.bits_bytes + 4 * n4 : kLdsBig);
+  // SVC_LAUNCH_BESIDE (fields of at most 8 192 blocks): shapes that fit on a CU NEXT TO the bandwidth kernels of a
+  // pipelined schedule -- the transform kernel leaves 4 wave slots and 256 VGPRs per SIMD and 12 KB of LDS.  The
+  // foreground list and the labelling arrays go to the workspace instead of 33-41 KB of LDS, and ONE 256-lane attempt
+  // launch takes every frame: the 1 024-lane launch needs an EMPTY CU for each of its frames x attempts workgroups (4
+  // waves x 128 VGPRs on every SIMD), even those that exit at once, so beside a kernel that keeps every CU partly
+  // occupied it does not start until that kernel drains.  Scene cuts then run on the 256-lane workspace path (slower
+  // alone, hidden beside the transform).
+  const bool small = (flags & SVC_LAUNCH_BESIDE) != 0 && a.n <= kRegPts * kTA;
+  a.take_all = small ? 1u : 0u;
+  if (small) a.lds_bytes = a.bits_bytes + 16;  // the foreground list goes to the workspace
   hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);
   a.lds_bytes = 0;
-  if (a.n > kLightMax) {
+  if (small) {
+    hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
+  } else if (a.n > kLightMax) {
     // The two attempt launches are independent (each frame belongs to exactly one): the heavy one goes to a
     // side stream, forked after the prepare kernel and joined before the labelling, so a scene cut's long
     // workgroups run beside the light frames instead of after them.  Not while `stream` is being captured
@@ -1154,7 +1167,9 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   } else {
     hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
   }
-  if (5 * n4 <= kLdsBig)
+  if (small)
+    hipLaunchKernelGGL((segment_label_kernel<false, false>), dim3(n_frames), dim3(kTA), 0, stream, a);
+  else if (5 * n4 <= kLdsBig)
     hipLaunchKernelGGL((segment_label_kernel<true, true>), dim3(n_frames), dim3(kTA), 5 * n4, stream, a);
   else if (4 * n4 <= kLdsBig)
     hipLaunchKernelGGL((segment_label_kernel<true, false>), dim3(n_frames), dim3(kTA), 4 * n4, stream, a);

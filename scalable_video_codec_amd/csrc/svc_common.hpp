@@ -83,7 +83,7 @@ int launch_quant_frames(float* d_planes, uint32_t n_frames, uint32_t w, uint32_t
 int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames,
                   svc_ransac_params params, const uint32_t* d_samples, uint32_t iters,
                   float* d_gm, float* d_rmse, uint8_t* d_mask, uint32_t* d_count,
-                  hipStream_t stream);
+                  uint32_t flags, hipStream_t stream);
 int launch_block_types(const uint8_t* d_mask, uint64_t n, uint32_t* d_types, hipStream_t stream);
 int launch_serialize(const float* d_planes, uint64_t plane_elems, uint32_t n_frames, const uint32_t* d_types,
                      uint32_t mv_blocks, uint32_t frame_w, uint32_t frame_h, uint32_t tbw, uint32_t tbh,
@@ -97,7 +97,7 @@ int launch_sse(const uint8_t* d_src, uint64_t src_stride, const float* d_rec, ui
 uint64_t segment_workspace_per_frame(uint32_t n, uint32_t attempts);
 int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames,
                    uint32_t mv_bw, uint32_t mv_bh, const svc_segment_params& p, uint64_t seed, uint8_t* d_ws,
-                   uint32_t* d_types, hipStream_t stream);
+                   uint32_t* d_types, uint32_t flags, hipStream_t stream);
 uint64_t global_ebma_workspace_bytes(uint32_t range, uint32_t n_pairs);
 int launch_global_ebma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride, uint32_t n_pairs, uint32_t w,
                        uint32_t h, uint32_t range, uint8_t* d_ws, float* d_gm, float* d_min_mad, bool combine,

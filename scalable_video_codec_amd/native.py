@@ -59,6 +59,8 @@ SIGNATURES = {
     "svc_hip_ebma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "svc_hip_ransac_frames_ex": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "svc_hip_segment_frames_ex": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, SegmentParams, _u64, _vp, _u64, _vp, _u32, _vp]),
     "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
     "svc_hip_probe_stream": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp]),
     "svc_hip_segment_workspace_bytes": (_u64, [_u32, _u32, _u32, _u32]),
@@ -172,8 +174,11 @@ def ebma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_
     return mv, mad
 
 
+LAUNCH_BESIDE = 1
+
+
 def ransac_frames(mv: torch.Tensor, samples: torch.Tensor, gm_in: Optional[torch.Tensor] = None,
-                  subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5, out=None):
+                  subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5, out=None, flags: int = 0):
     """mv: (frames, blocks, 2) f32; samples: (frames, iters, subset) i32/u32 as int32 storage."""
     frames, blocks, _ = mv.shape
     iters = samples.shape[1] if samples.numel() else 0
@@ -185,9 +190,9 @@ def ransac_frames(mv: torch.Tensor, samples: torch.Tensor, gm_in: Optional[torch
     else:
         gm, rmse, mask, count = out
     p = RansacParams(subset_sz, inlier_thresh, success_prob, inlier_ratio)
-    _check(load().svc_hip_ransac_frames(_dev(mv, torch.float32), blocks, frames, p, _dev(samples, torch.int32),
-                                        iters, _dev(gm, torch.float32), _dev(rmse, torch.float32),
-                                        _dev(mask, torch.uint8), _dev(count, torch.int32), _stream()))
+    _check(load().svc_hip_ransac_frames_ex(_dev(mv, torch.float32), blocks, frames, p, _dev(samples, torch.int32),
+                                           iters, _dev(gm, torch.float32), _dev(rmse, torch.float32),
+                                           _dev(mask, torch.uint8), _dev(count, torch.int32), flags, _stream()))
     return gm, rmse, mask, count
 
 
@@ -211,7 +216,8 @@ def segment_workspace_bytes(mfw: int, mfh: int, frames: int, attempts: int = 3) 
 
 
 def segment_frames(mask: torch.Tensor, mv: torch.Tensor, mfw: int, mfh: int, mv_block: int = 16, seed: int = 0,
-                   out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, **params) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, flags: int = 0,
+                   **params) -> torch.Tensor:
     """mask (frames, blocks) u8 inlier mask + mv (frames, blocks, 2) f32 -> (frames, blocks) i32 region ids."""
     frames, blocks = mask.shape
     assert blocks == mfw * mfh
@@ -221,9 +227,9 @@ def segment_frames(mask: torch.Tensor, mv: torch.Tensor, mfw: int, mfh: int, mv_
         workspace = torch.empty(need, dtype=torch.uint8, device=mask.device)
     if out is None:
         out = torch.empty((frames, blocks), dtype=torch.int32, device=mask.device)
-    _check(load().svc_hip_segment_frames(_dev(mask, torch.uint8), _dev(mv, torch.float32), mfw, mfh, frames,
-                                         mv_block, mv_block, p, seed, _dev(workspace, torch.uint8),
-                                         workspace.numel(), _dev(out, torch.int32), _stream()))
+    _check(load().svc_hip_segment_frames_ex(_dev(mask, torch.uint8), _dev(mv, torch.float32), mfw, mfh, frames,
+                                            mv_block, mv_block, p, seed, _dev(workspace, torch.uint8),
+                                            workspace.numel(), _dev(out, torch.int32), flags, _stream()))
     return out
 
 

@@ -74,7 +74,8 @@ def test_ransac_frames_batched(native, oracle):
 
 @pytest.mark.parametrize("frames,n", [(1, 2048), (3, 2049), (257, 8160), (300, 3600), (259, 8192), (5, 8200), (3, 32768), (2, 33000)])
 @pytest.mark.parametrize("subset", [1, 3])
-def test_ransac_frames_every_launch_shape(native, oracle, frames, n, subset):
+@pytest.mark.parametrize("flags", [0, 1], ids=["alone", "beside"])
+def test_ransac_frames_every_launch_shape(native, oracle, frames, n, subset, flags):
     """Every kernel variant (256 / 1024 lanes, 8 / 16 / 32 blocks per lane, one or two frames per workgroup with an odd
     frame left over, the L2-walking fallback), frames that take the integer fast path next to frames that need the
     in-order walk, and frames where no iteration gathers a subset (motion.cpp:240-242)."""
@@ -91,8 +92,9 @@ def test_ransac_frames_every_launch_shape(native, oracle, frames, n, subset):
             mv[f] = (rng.random((n, 2)) * 1e4).astype(np.float32)          # scattered: too few inliers for subset 3
     samples = np.stack([np.stack([rng.choice(n, subset, replace=False) for _ in range(k)]) for _ in range(frames)]).astype(np.int32)
     gm_in = rng.integers(-3, 4, (frames, 2)).astype(np.float32)
+    # flags = SVC_LAUNCH_BESIDE: 256 lanes x 32 blocks in registers for fields of 2 049 .. 8 192 blocks
     gm, rmse, mask, count = native.ransac_frames(torch.from_numpy(mv).cuda(), torch.from_numpy(samples).cuda(),
-                                                 gm_in=torch.from_numpy(gm_in).cuda(), **p)
+                                                 gm_in=torch.from_numpy(gm_in).cuda(), flags=flags, **p)
     torch.cuda.synchronize()
     gm, rmse, mask, count = gm.cpu().numpy(), rmse.cpu().numpy(), mask.cpu().numpy(), count.cpu().numpy()
     for f in check:

@@ -23,13 +23,14 @@ def _scene(rng, mfw, mfh, n_rects, salt):
 
 @pytest.mark.parametrize("mfw,mfh", [(120, 68), (80, 45), (22, 18), (240, 135)])
 @pytest.mark.parametrize("conn", [4, 8])
-def test_segment_matches_oracle(native, oracle, mfw, mfh, conn):
+@pytest.mark.parametrize("flags", [0, 1], ids=["alone", "beside"])
+def test_segment_matches_oracle(native, oracle, mfw, mfh, conn, flags):
     rng = np.random.default_rng(mfw * 7 + conn)
     frames = 5
     masks, mvs = zip(*[_scene(rng, mfw, mfh, 1 + f, 0.01 * f) for f in range(frames)])
     masks, mvs = np.stack(masks), np.stack(mvs)
     got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh,
-                                seed=1234, connectivity=conn).cpu().numpy()
+                                seed=1234, connectivity=conn, flags=flags).cpu().numpy()
     for f in range(frames):
         want = oracle.segment(masks[f], mvs[f], mfw, mfh, connectivity=conn, seed=1234 + f)
         assert np.array_equal(got[f].astype(np.uint32), want), f"frame {f}: {(got[f] != want).sum()} blocks differ"
@@ -70,7 +71,8 @@ def test_segment_edge_cases(native, oracle):
 @pytest.mark.parametrize("mfw,mfh,density", [(120, 68, 0.45), (120, 68, 0.7), (120, 68, 0.93), (120, 68, 1.0),
                                              (240, 135, 0.6), (240, 135, 0.97), (33, 31, 0.8),
                                              (480, 270, 0.35), (480, 270, 0.12)])
-def test_segment_heavy_frames(native, oracle, mfw, mfh, density):
+@pytest.mark.parametrize("flags", [0, 1], ids=["alone", "beside"])
+def test_segment_heavy_frames(native, oracle, mfw, mfh, density, flags):
     """Scene-cut-like frames: much of the field is foreground (the 1024-lane launch; above 8 192 blocks the
     points leave the registers for LDS and, at 8K, the workspace), next to a light and an empty frame."""
     rng = np.random.default_rng(int(density * 100) + mfw)
@@ -85,7 +87,10 @@ def test_segment_heavy_frames(native, oracle, mfw, mfh, density):
                        rng.integers(-9, 10, (mfh, mfw))], -1).astype(np.float32).reshape(n, 2)
         masks.append(mask); mvs.append(mv)
     masks, mvs = np.stack(masks), np.stack(mvs)
-    got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh, seed=77).cpu().numpy()
+    # flags = SVC_LAUNCH_BESIDE: the shapes that fit next to bandwidth kernels (one 256-lane attempt launch for every
+    # frame, lists and labelling arrays in the workspace) must give the same region ids
+    got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh, seed=77,
+                                flags=flags).cpu().numpy()
     for f in range(3):
         want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=77 + f)
         assert np.array_equal(got[f].astype(np.uint32), want), f"frame {f}: {(got[f] != want).sum()} blocks differ"
