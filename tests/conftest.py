@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built libraries (they are git-ignored): build them once, here, rather than fail every
+    test that loads them (hipcc cross-compiles gfx950 without a GPU; a minute the first time)."""
+    from scalable_video_codec_amd import build as b
+    if not (os.path.exists(b.LIB_HIP) and os.path.exists(b.LIB_MOTION)):
+        b.build_all(verbose=True)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The C restatement (oracle/libsvc_oracle.so); built on demand with gcc."""
