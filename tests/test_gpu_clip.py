@@ -23,6 +23,18 @@ def _frames(cfg, n, dev):
                         for t in range(n)]).contiguous()
 
 
+_hip = None
+
+
+def _hip_memcpy_async(dst, src, nbytes, stream):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so.7")  # the HIP runtime already in the process
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rc = _hip.hipMemcpyAsync(dst, src, nbytes, 3, stream)  # hipMemcpyDeviceToDevice
+    assert rc == 0, rc
+
+
 def _reference_outputs(native, cfg, frames):
     """The same clip through the stage-by-stage C-ABI calls of the Python harness (pipeline.ClipEncoder)."""
     n = frames.shape[0]
@@ -67,6 +79,43 @@ def test_schedules_equal_stagewise_calls(native, schedule, graph, steps):
     enc.close()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_pipeline_state_machine_fuzz(native, graph):
+    """Bursts of steps of random length, random timing flags, syncs and output reads at random points, a halo that
+    arrives through the transport hook on every step: whatever the interleaving, the newest finished step's outputs are
+    the clip's (the double-buffered sets, the deferred join of the second stream and the drain must never mix steps)."""
+    dev = torch.device("cuda")
+    n = 9
+    frames = _frames(CFG, n, dev)
+    whole = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL)
+    whole.load_frames(frames)
+    whole.step()
+    whole.sync()
+    want = whole.outputs()
+    want_coeffs = whole.read("coeffs")
+    pyr = whole.read("pyramids", device=dev)
+    first, cnt, pairs, first_encoded = clipmod.plan_shard(n, 2, 1)
+    enc = clipmod.Clip(CFG, n, rank=1, world=2, graph=graph)
+    enc.load_frames(frames[first:first + cnt].contiguous())
+    stride = enc.info.pyramid_stride
+    enc.set_halo_transport(lambda send, recv, nbytes, stream: _hip_memcpy_async(recv, pyr.data_ptr() + first * stride, nbytes, stream))
+    rng = np.random.default_rng(17)
+    g0 = first_encoded - 1
+    per = 3 * enc.info.padded_w * enc.info.padded_h
+    for burst in range(12):
+        for _ in range(int(rng.integers(1, 8))):
+            enc.step(timed=bool(rng.integers(0, 2)) and not graph)
+        if rng.integers(0, 3) == 0:
+            enc.flush()
+        out = enc.outputs()  # syncs
+        for k in want:
+            assert torch.equal(out[k], want[k][g0:g0 + pairs]), (burst, k)
+        assert torch.equal(enc.read("coeffs").view(pairs, per), want_coeffs.view(n - 1, per)[g0:g0 + pairs]), burst
+        if rng.integers(0, 2):
+            enc.reset_timers()
+    enc.close()
+
+
 def test_wire_and_no_segmentation(native):
     dev = torch.device("cuda")
     n = 6
@@ -105,18 +154,6 @@ def test_general_transform_blocks(native, block, wire):
     else:
         want = native.dct_quant_frames(frames[1:].contiguous(), block, types, 16, CFG.fg_step, CFG.bg_step)
         assert torch.equal(enc.read("coeffs", device=dev).view(want.shape), want)
-
-
-_hip = None
-
-
-def _hip_memcpy_async(dst, src, nbytes, stream):
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so.7")  # the HIP runtime already in the process
-        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    rc = _hip.hipMemcpyAsync(dst, src, nbytes, 3, stream)  # hipMemcpyDeviceToDevice
-    assert rc == 0, rc
 
 
 @pytest.mark.parametrize("world,total,schedule", [(2, 11, clipmod.SERIAL), (3, 11, clipmod.PIPELINED), (4, 5, clipmod.PIPELINED),
