@@ -71,12 +71,17 @@ struct ClipEncoder::Impl {
   Shard sh;
   uint32_t pw = 0, ph = 0, mfw = 0, mfh = 0, blocks = 0, iters = 0;
   uint64_t pyr_stride = 0, frame_bytes = 0, plane_elems = 0, record_bytes = 0, seg_ws_bytes = 0;
-  hipStream_t sM = nullptr, sL = nullptr, sC = nullptr;
-  DevBuf<uint8_t> bgr, pyr[2], mask[2], seg_ws, records;
-  DevBuf<float> mv[2], mad[2], gm[2], rmse[2], coeffs;
-  DevBuf<uint32_t> count[2], types[2], samples;
-  hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[2] = {nullptr, nullptr};
-  bool halo_recorded[2] = {false, false}, join_pending[2] = {false, false};
+  // Pipelined schedule: RANSAC + segmentation of a step get `depth` iterations to finish, on `depth` streams (step l on
+  // stream l % depth), and the small per-step buffers exist in depth + 2 sets (step s uses set s % nsets).
+  static constexpr int kMaxDepth = 3, kSets = kMaxDepth + 2;
+  int depth = 1, nsets = 1;
+  hipStream_t sM = nullptr, sL[kMaxDepth] = {nullptr, nullptr, nullptr}, sC = nullptr;
+  DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records;
+  DevBuf<float> mv[kSets], mad[kSets], gm[kSets], rmse[kSets], coeffs;
+  DevBuf<uint32_t> count[kSets], types[kSets], samples;
+  hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {};
+  bool halo_recorded[2] = {false, false}, join_pending[kSets] = {};
+  uint64_t iter = 0, fork_iter[kSets] = {};
   void* comm = nullptr;
   HaloFn halo;
   // pipeline progress: steps whose stage has been enqueued
@@ -94,22 +99,22 @@ struct ClipEncoder::Impl {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
   std::vector<hipEvent_t> event_pool;
   // graph of the steady-state block, one per buffer parity
-  hipGraphExec_t gexec[2] = {nullptr, nullptr};
-  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t gexec[kSets] = {};
+  hipGraph_t graph[kSets] = {};
 
   ~Impl() {
-    for (hipStream_t s : {sM, sL, sC})
+    for (hipStream_t s : {sM, sL[0], sL[1], sL[2], sC})
       if (s) (void)hipStreamSynchronize(s);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < kSets; ++b) {
       if (gexec[b]) (void)hipGraphExecDestroy(gexec[b]);
       if (graph[b]) (void)hipGraphDestroy(graph[b]);
     }
     for (auto& v : timed)
       for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {e_pyr[0], e_pyr[1], e_halo[0], e_halo[1], e_fork, e_join[0], e_join[1]})
+    for (hipEvent_t e : {e_pyr[0], e_pyr[1], e_halo[0], e_halo[1], e_fork, e_join[0], e_join[1], e_join[2], e_join[3], e_join[4]})
       if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {sM, sL, sC})
+    for (hipStream_t s : {sM, sL[0], sL[1], sL[2], sC})
       if (s) (void)hipStreamDestroy(s);
   }
 
@@ -130,8 +135,10 @@ struct ClipEncoder::Impl {
     timed[(uint32_t)st].emplace_back(a, b);
   }
 
-  // buffer set of step s: the pipelined schedule alternates two, the serial one has one
+  // pyramid set of step s: the pipelined schedule alternates two, the serial one has one
   int Par(uint64_t s) const { return c.schedule == Schedule::kPipelined ? (int)(s & 1) : 0; }
+  // set of the small per-step buffers (motion field, RANSAC outputs, region ids) of step s
+  int Set(uint64_t s) const { return (int)(s % (uint64_t)nsets); }
 
   // ---- the stages; `s` is the step index, its buffers are those of set Par(s) ---------------
   void Luma(uint64_t s, hipStream_t st, bool timing) {
@@ -159,18 +166,19 @@ struct ClipEncoder::Impl {
 
   void Hbma(uint64_t s, hipStream_t st, bool timing) {
     if (!sh.pairs) return;
-    const int b = Par(s);
+    const int b = Par(s), q = Set(s);
     const uint64_t t0 = sh.needs_halo ? 0 : 1;  // slot of the first tracked pyramid
     Run(Stage::kHbma, st, timing, [&] {
       Abi(svc_hip_hbma_pairs(pyr[b].p + t0 * pyr_stride, pyr[b].p + (t0 + 1) * pyr_stride, pyr_stride, sh.pairs, c.levels, pw, ph,
-                             c.search_range, c.mv_block, c.mv_block, mv[b].p, mad[b].p, SVC_HBMA_AUTO, st), "svc_hip_hbma_pairs");
+                             c.search_range, c.mv_block, c.mv_block, mv[q].p, mad[q].p, SVC_HBMA_AUTO, st), "svc_hip_hbma_pairs");
     });
   }
 
   // RANSAC + region ids: one workgroup per frame, latency-bound
   void Lat(uint64_t s, hipStream_t st, bool timing) {
     if (!sh.pairs) return;
-    const int b = Par(s);
+    const int b = Set(s);
+    DevBuf<uint8_t>& ws = seg_ws[c.schedule == Schedule::kPipelined ? (int)(s % (uint64_t)depth) : 0];  // one per stream
     const uint64_t g0 = sh.first_encoded - 1;  // clip-wide index of the shard's first pair
     Run(Stage::kRansac, st, timing, [&] {
       Hip(hipMemsetAsync(gm[b].p, 0, gm[b].bytes(), st), "hipMemsetAsync");  // in/out, libs/motion.cpp:241-242
@@ -180,7 +188,7 @@ struct ClipEncoder::Impl {
     Run(Stage::kSegment, st, timing, [&] {
       if (c.segmentation)
         Abi(svc_hip_segment_frames_ex(mask[b].p, mv[b].p, mfw, mfh, sh.pairs, c.mv_block, c.mv_block, c.segment,
-                                      c.seed * 1000003ull + g0, seg_ws.p, seg_ws_bytes, types[b].p, lat_flags, st),
+                                      c.seed * 1000003ull + g0, ws.p, seg_ws_bytes, types[b].p, lat_flags, st),
             "svc_hip_segment_frames");
       else
         Abi(svc_hip_block_types_frames(mask[b].p, blocks, sh.pairs, types[b].p, st), "svc_hip_block_types_frames");
@@ -189,7 +197,7 @@ struct ClipEncoder::Impl {
 
   void Transform(uint64_t s, hipStream_t st, bool timing) {
     if (!sh.pairs || !c.dct_block_w) return;
-    const int b = Par(s);
+    const int b = Set(s);
     const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
     Run(Stage::kTransform, st, timing, [&] {
       // records carry RAW coefficients, as the reference's encoder serialises them (libs/encoder.cpp:638-650:
@@ -207,25 +215,26 @@ struct ClipEncoder::Impl {
     });
   }
 
-  // RANSAC + segmentation of step l on the second stream, behind everything the main stream holds so far (the
-  // motion search of this iteration included);
-  // the main stream picks the result up (JoinLat) only where it is needed, an iteration later.
+  // RANSAC + segmentation of step l on its latency stream, behind everything the main stream holds so far; the main
+  // stream picks the result up (JoinLat) only where it is needed: in front of the transform of step l, `depth`
+  // iterations later.
   void ForkLat(uint64_t l, bool timing) {
+    hipStream_t st = sL[l % (uint64_t)depth];
     Hip(hipEventRecord(e_fork, sM), "hipEventRecord");
-    Hip(hipStreamWaitEvent(sL, e_fork, 0), "hipStreamWaitEvent");
-    Lat(l, sL, timing);
-    Hip(hipEventRecord(e_join[l & 1], sL), "hipEventRecord");
-    join_pending[l & 1] = true;
+    Hip(hipStreamWaitEvent(st, e_fork, 0), "hipStreamWaitEvent");
+    Lat(l, st, timing);
+    Hip(hipEventRecord(e_join[Set(l)], st), "hipEventRecord");
+    join_pending[Set(l)] = true;
+    fork_iter[Set(l)] = iter;
   }
   void JoinLat(uint64_t l) {
-    if (!join_pending[l & 1]) return;
-    Hip(hipStreamWaitEvent(sM, e_join[l & 1], 0), "hipStreamWaitEvent");
-    join_pending[l & 1] = false;
+    if (!join_pending[Set(l)]) return;
+    Hip(hipStreamWaitEvent(sM, e_join[Set(l)], 0), "hipStreamWaitEvent");
+    join_pending[Set(l)] = false;
   }
 
-  // The steady-state iteration as ONE fork/join block (what the hipGraph option captures): motion search of
-  // step h on the main stream with the transform of step h - 2 behind it, RANSAC + segmentation of step
-  // h - 1 beside them on the second stream.
+  // The steady-state iteration as ONE fork/join block (what the hipGraph option captures; depth 1): motion search of
+  // step h on the main stream with the transform of step h - 2 behind it, RANSAC + segmentation of step h - 1 beside them.
   void Block(uint64_t h, uint64_t l, uint64_t d) {
     Hbma(h, sM, false);
     ForkLat(l, false);
@@ -233,14 +242,18 @@ struct ClipEncoder::Impl {
     JoinLat(l);
   }
 
-  // One iteration of the software pipeline.  Buffer hazards (sets alternate with the step's parity):
-  //   lat(l) reads mv[l], writes mask/types[l]   | beside it: hbma(l + 1) writes mv[l + 1], transform(l - 1)
-  //   reads types[l - 1] -- disjoint; the NEXT iteration's hbma(l + 2) and transform(l) touch set l again, so the
-  //   main stream joins lat(l) there, after the next luma: lat(l) has the transform + the next luma to hide behind.
+  // One iteration of the software pipeline: luma + pyramid of step s, motion search of s - 1, fork of RANSAC +
+  // segmentation of s - 2, transform of s - 2 - depth.  Buffer hazards (a step's small buffers are set s % (depth + 2)):
+  //   lat(l) reads mv[l], writes mask / types[l] on stream l % depth, and must be done before transform(l) reads types[l]:
+  //     joined there, `depth` iterations after its fork;
+  //   hbma(h) writes mv[h]: the set's last reader lat(h - depth - 2) was joined an iteration earlier;
+  //   up to `depth` lats are in flight on their own streams, each with its own segmentation workspace.
   void Iterate(bool new_step, bool timing) {
     const uint64_t lumas = n_luma, hbmas = n_hbma, lats = n_lat;
-    const bool do_hbma = n_hbma < lumas, do_lat = n_lat < hbmas, do_dct = n_dct < lats;
+    const bool do_hbma = n_hbma < lumas, do_lat = n_lat < hbmas;
     const uint64_t h = n_hbma, l = n_lat, d = n_dct;
+    // draining (no new step) joins at once; otherwise the transform of step d waits until lat(d) has had its iterations
+    const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Set(d)] >= (uint64_t)depth);
     const bool replay = c.graph && do_hbma && do_lat && do_dct && !timing;
     if (do_lat && fork_early && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
     if (new_step) {
@@ -252,11 +265,11 @@ struct ClipEncoder::Impl {
       if (c.world > 1) Halo(s, timing);
       ++n_luma;
     }
-    if (l > 0) JoinLat(l - 1);  // set (l - 1) & 1 is about to be written by hbma(l + 1) and read by transform(l - 1)
     if (do_hbma && c.world > 1)  // the halo of step h has had a whole iteration to arrive
       Hip(hipStreamWaitEvent(sM, e_halo[Par(h)], 0), "hipStreamWaitEvent");
     if (replay) {
-      const int b = Par(h);
+      JoinLat(d);  // a lat forked by an eager iteration (fill, timed step) is picked up outside the graph
+      const int b = Set(h);
       if (!gexec[b]) {
         Hip(hipStreamBeginCapture(sM, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
         try {
@@ -269,6 +282,8 @@ struct ClipEncoder::Impl {
         }
         Hip(hipStreamEndCapture(sM, &graph[b]), "hipStreamEndCapture");
         Hip(hipGraphInstantiate(&gexec[b], graph[b], nullptr, nullptr, 0), "hipGraphInstantiate");
+      } else {
+        fork_iter[Set(l)] = iter;  // what ForkLat records when the block is captured
       }
       Hip(hipGraphLaunch(gexec[b], sM), "hipGraphLaunch");
     } else {
@@ -276,9 +291,13 @@ struct ClipEncoder::Impl {
       // big shards: forked BEHIND the motion search -- RANSAC + segmentation run beside the transform (the long,
       // store-bound kernel) and the next step's luma + pyramid, never beside the MAD kernel
       if (do_lat && !fork_early) ForkLat(l, timing);
-      if (do_dct) Transform(d, sM, timing);
+      if (do_dct) {
+        JoinLat(d);
+        Transform(d, sM, timing);
+      }
     }
     n_hbma += do_hbma; n_lat += do_lat; n_dct += do_dct;
+    ++iter;
   }
 
   void SerialStep(bool timing) {
@@ -330,20 +349,37 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   // a low-priority main stream was slower still (0.79).  Confining the second stream to every 2nd / 4th / 8th CU
   // (hipExtStreamCreateWithCUMask) cost as much: 0.37 -> 0.52-0.55 ms at 38 frames, 2.52 -> 2.76-2.78 ms at 300
   // (profiles/r02_cu_mask.txt).
-  for (hipStream_t* s : {&m.sM, &m.sL, &m.sC}) Hip(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreate");
-  for (hipEvent_t* e : {&m.e_pyr[0], &m.e_pyr[1], &m.e_halo[0], &m.e_halo[1], &m.e_fork, &m.e_join[0], &m.e_join[1]})
+  // How many iterations RANSAC + segmentation of a step may take (and how many streams they alternate on).  With the
+  // shapes that fit beside the bandwidth kernels (fields up to 8 192 blocks) one iteration hides them unless the shard
+  // is tiny; a 4K field keeps 1 024-lane workgroups that need whole CUs and get them only where a main-stream kernel
+  // drains (profiles/r02_timeline_C5.txt), so its chain of four launches spans more than one iteration.  Two is never
+  // worse and is what the tiny and the 4K shards need (ms per step at depth 1 / 2 / 3, profiles/r02_ab_lat_depth.txt:
+  // C5 2.83 / 2.44 / 2.70, C5 8-frame shard 1.07 / 0.65 / 0.81, C3 2.57 / 2.56 / 2.56, C3 38 frames 0.371 / 0.370 /
+  // 0.373, C3 19 frames 0.236 / 0.208 / 0.207).  SVC_LAT_DEPTH overrides (A/B runs).
+  const bool pipelined = c.schedule == Schedule::kPipelined;
+  m.depth = 1;
+  if (pipelined && !c.graph) {
+    m.depth = 2;
+    if (const char* e = std::getenv("SVC_LAT_DEPTH")) m.depth = std::min(std::max(std::atoi(e), 1), (int)Impl::kMaxDepth);
+  }
+  m.nsets = !pipelined ? 1 : c.graph ? 4 : m.depth + 2;  // hipGraph replay: the set must also fix the pyramid parity
+  Hip(hipStreamCreateWithFlags(&m.sM, hipStreamNonBlocking), "hipStreamCreate");
+  Hip(hipStreamCreateWithFlags(&m.sC, hipStreamNonBlocking), "hipStreamCreate");
+  for (int k = 0; k < m.depth; ++k) Hip(hipStreamCreateWithFlags(&m.sL[k], hipStreamNonBlocking), "hipStreamCreate");
+  for (hipEvent_t* e : {&m.e_pyr[0], &m.e_pyr[1], &m.e_halo[0], &m.e_halo[1], &m.e_fork})
     Hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+  for (int b = 0; b < m.nsets; ++b) Hip(hipEventCreateWithFlags(&m.e_join[b], hipEventDisableTiming), "hipEventCreate");
   m.bgr.Alloc((size_t)N * m.frame_bytes);
-  const int sets = c.schedule == Schedule::kPipelined ? 2 : 1;
-  for (int b = 0; b < 2; ++b) {
-    if (b >= sets) continue;
+  for (int b = 0; b < (pipelined ? 2 : 1); ++b) {
     m.pyr[b].Alloc((size_t)(N + 1) * m.pyr_stride);  // slot 0 = halo, slots 1..N = own frames
     Hip(hipMemset(m.pyr[b].p, 0, (size_t)(N + 1) * m.pyr_stride), "hipMemset");
+  }
+  for (int b = 0; b < m.nsets; ++b) {
     m.mv[b].Alloc((size_t)P * m.blocks * 2); m.mad[b].Alloc((size_t)P * m.blocks);
     m.gm[b].Alloc((size_t)P * 2); m.rmse[b].Alloc(P);
     m.mask[b].Alloc((size_t)P * m.blocks); m.count[b].Alloc(P); m.types[b].Alloc((size_t)P * m.blocks);
   }
-  m.seg_ws.Alloc(m.seg_ws_bytes);
+  for (int k = 0; k < m.depth; ++k) m.seg_ws[k].Alloc(m.seg_ws_bytes);
   m.fused_records = c.wire && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) && m.pw % 16 == 0;
   if (transform) {
     if (c.wire) m.records.Alloc((size_t)P * m.record_bytes);
@@ -401,7 +437,8 @@ void ClipEncoder::Flush() {
 
 void ClipEncoder::Sync() {
   Flush();
-  for (hipStream_t s : {p_->sC, p_->sL, p_->sM}) Hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+  for (hipStream_t s : {p_->sC, p_->sL[0], p_->sL[1], p_->sL[2], p_->sM})
+    if (s) Hip(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 
 void ClipEncoder::StageTime(Stage s, double* total_ms, uint32_t* launches) {
@@ -427,7 +464,7 @@ void ClipEncoder::ResetTimers() {
 void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
   Impl& m = *p_;
   Sync();
-  const int par = m.n_dct ? m.Par(m.n_dct - 1) : 0;
+  const int par = m.n_dct ? m.Set(m.n_dct - 1) : 0, ppar = m.n_dct ? m.Par(m.n_dct - 1) : 0;
   void* ptr = nullptr;
   uint64_t n = 0;
   switch (b) {
@@ -440,7 +477,7 @@ void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
     case Buffer::kBlockTypes: ptr = m.types[par].p; n = m.types[par].bytes(); break;
     case Buffer::kCoeffs: ptr = m.coeffs.p; n = m.coeffs.bytes(); break;
     case Buffer::kRecords: ptr = m.records.p; n = m.records.bytes(); break;
-    case Buffer::kPyramids: ptr = m.pyr[par].p; n = m.pyr[par].bytes(); break;
+    case Buffer::kPyramids: ptr = m.pyr[ppar].p; n = m.pyr[ppar].bytes(); break;
     case Buffer::kBgr: ptr = m.bgr.p; n = m.bgr.bytes(); break;
     default: throw std::runtime_error("svc::ClipEncoder: unknown buffer");
   }

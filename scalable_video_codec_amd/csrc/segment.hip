@@ -1073,12 +1073,25 @@ struct SideStream {
   hipEvent_t fork = nullptr, join = nullptr;
 };
 
-static SideStream* side_stream() {
-  constexpr int kMaxDevices = 64;
-  static thread_local SideStream per_device[kMaxDevices];
+// A few per device, one per caller stream (least recently used slot for a new caller): launches enqueued
+// on different streams (a pipelined encoder runs the segmentation of consecutive steps on streams of their own) must
+// not queue their heavy attempts behind each other on ONE side stream.
+static SideStream* side_stream(hipStream_t caller) {
+  constexpr int kMaxDevices = 64, kPool = 4;
+  struct Slot { hipStream_t caller = nullptr; uint64_t last_use = 0; SideStream s; };
+  static thread_local Slot per_device[kMaxDevices][kPool];
+  static thread_local uint64_t tick = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-  SideStream& s = per_device[dev];
+  Slot* slot = nullptr;
+  for (int i = 0; i < kPool; ++i) {  // this caller's slot, else the least recently used one (stream order makes reuse safe)
+    Slot& c = per_device[dev][i];
+    if (c.last_use && c.caller == caller) { slot = &c; break; }
+    if (!slot || c.last_use < slot->last_use) slot = &c;
+  }
+  slot->caller = caller;
+  slot->last_use = ++tick;
+  SideStream& s = slot->s;
   if (!s.stream) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
@@ -1152,7 +1165,7 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
     // more than kRegPts points per lane are possible: LDS for the large-frame path
     if (a.n > kRegPts * kTA) heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
     if (capturing == hipStreamCaptureStatusNone) {
-      SideStream* side = side_stream();
+      SideStream* side = side_stream(stream);
       if (!side) return fail(SVC_ERR_HIP, "segment: cannot create the side stream");
       SVC_HIP_TRY(hipEventRecord(side->fork, stream));
       SVC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
