@@ -12,6 +12,13 @@
 // Both are HBM-bound byte work: 3 B in / 1 B out, then 1 B in / 0.25 B out.
 #include "svc_common.hpp"
 
+#ifndef SVC_PYR_TW  // tile of the plane-to-plane pyramid pass (A/B knobs)
+#define SVC_PYR_TW 512
+#endif
+#ifndef SVC_PYR_TH
+#define SVC_PYR_TH 32
+#endif
+
 namespace svc {
 
 struct LumaArgs {
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTW = 128, kTHBgr = 32, kTHPlane = 64, kOff = 16, kPitch = kTW + 2 * kOff;  // LDS column c <-> x = x0 - kOff + c
+constexpr int kTWBgr = 128, kTHBgr = 32, kTWPlane = SVC_PYR_TW, kTHPlane = SVC_PYR_TH, kOff = 16;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
   const uint8_t* bgr;      // FROM_BGR: interleaved frames
@@ -166,11 +173,14 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t b, uint32_t g, uint32_t r) 
 // FROM_BGR: luma from the B,G,R frame -> level 0 (stored) -> level 1.  !FROM_BGR: the same tile machinery on an
 // existing pyramid plane (level l -> l + 1): aligned 16-byte loads of the source rows into LDS, the 5x5 pass out of
 // LDS -- instead of pyr_down_kernel's 7 unaligned dwordx4 loads per 8 outputs straight from L2 (2.3 TB/s).
-// TH: tile height.  32 for the BGR pass (taller tiles push the halo re-reads out of L2, see above); the plane-to-plane
-// pass has a third of the bytes per tile and takes 64 rows, so that a lane has two or three loads in flight.
-template <bool FROM_BGR, int TH>
+// TW x TH: the tile.  128 x 32 for the BGR pass (bigger tiles push the halo re-reads out of L2, see above); the
+// plane-to-plane pass has a third of the bytes per pixel and takes 512 x 32, so that a lane has four or five loads in flight
+// (per launch at C3, 1080p level 1 -> 2: 128x64 75.6 us, 256x64 66.4, 256x32 67.0, 128x128 71.6, 512x32 64.2, 256x128 76.0;
+// profiles/r02_ab_pyr_tile.txt).
+template <bool FROM_BGR, int TW, int TH>
 __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
-  constexpr int kTH = TH;
+  constexpr int kTW = TW, kTH = TH, kPitch = TW + 2 * kOff;
+  static_assert(kPitch % 16 == 0 && kOff % 16 == 0, "LDS rows keep 16-byte alignment for the ds_write_b128");
   __shared__ __attribute__((aligned(16))) uint8_t tile[(kTH + 4) * kPitch];
   const uint32_t tid = threadIdx.x;
   const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -257,8 +267,6 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)gy * (w >> 1) + gx) = out;
   }
 }
-static_assert(kPitch % 16 == 0 && kOff % 16 == 0, "LDS rows keep 16-byte alignment for the ds_write_b128");
-
 int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                         uint32_t h, uint32_t levels, uint8_t* d_pyr, uint64_t pyr_stride,
                         hipStream_t stream) {
@@ -287,12 +295,12 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     fa.pyr_stride = pyr_stride;
     fa.dst_off = (uint64_t)w * h;
     fa.w = w; fa.h = h;
-    fa.tiles_x = div_up(w, kTW);
+    fa.tiles_x = div_up(w, kTWBgr);
     fa.tiles_per_frame = fa.tiles_x * div_up(h, kTHBgr);
     const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
     if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many tiles for one launch");
     fa.total_tiles = (uint32_t)tt;
-    hipLaunchKernelGGL((luma_pyr1_kernel<true, kTHBgr>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+    hipLaunchKernelGGL((luma_pyr1_kernel<true, kTWBgr, kTHBgr>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
     if ((rc = check_launch("luma_pyr1_kernel"))) return rc;
     first_plain_level = 1;
   } else {
@@ -321,12 +329,12 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
       fa.src_off = pa.src_off;
       fa.dst_off = pa.dst_off;
       fa.w = pa.sw; fa.h = pa.sh;
-      fa.tiles_x = div_up(pa.sw, kTW);
+      fa.tiles_x = div_up(pa.sw, kTWPlane);
       fa.tiles_per_frame = fa.tiles_x * div_up(pa.sh, kTHPlane);
       const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
       if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many tiles for one launch");
       fa.total_tiles = (uint32_t)tt;
-      hipLaunchKernelGGL((luma_pyr1_kernel<false, kTHPlane>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+      hipLaunchKernelGGL((luma_pyr1_kernel<false, kTWPlane, kTHPlane>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
       if ((rc = check_launch("luma_pyr1_kernel<false>"))) return rc;
       continue;
     }
