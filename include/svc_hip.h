@@ -69,7 +69,7 @@ typedef struct svc_segment_params {
 #define SVC_HBMA_FORCE_FUSED 2u          /* fused all-level kernel; UNSUPPORTED if the shape does not fit */
 
 const char* svc_hip_last_error(void);
-int svc_hip_abi_version(void);
+int svc_hip_abi_version(void); /* 2 (round 2: additions only -- *_ex launch flags, global motion, comm / halo shift) */
 int svc_hip_device_count(int* count);
 
 /* Measurement aid, not part of the hot path: one launch of a plain streaming kernel (dwordx4 per lane,

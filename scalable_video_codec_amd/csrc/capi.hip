@@ -95,7 +95,7 @@ using namespace svc;
 extern "C" {
 
 const char* svc_hip_last_error(void) { return g_err; }
-int svc_hip_abi_version(void) { return 1; }
+int svc_hip_abi_version(void) { return 2; }  // 2: + *_ex launch flags, global-motion entries, comm / halo shift
 
 int svc_hip_device_count(int* count) {
   SVC_REQUIRE(count, "device_count: null output");
