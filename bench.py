@@ -7,7 +7,8 @@ One "step" = one pass of the hot path over this rank's shard of the clip, reside
   luma + pyramid (all frames) -> [N>1: halo shift of the previous rank's last pyramid, RCCL
   send/recv on its own stream] -> fused HBMA (all frame pairs) -> RANSAC (per frame) ->
   segmentation (mask, close/open, k-means, connected components -> region ids) -> fused DCT +
-  quant (per encoded frame).
+  quant (per encoded frame).  Default schedule: consecutive steps are software-pipelined; every
+  step's work is enqueued and finished inside the timed region.
 The driver of a step is C++ (svc::ClipEncoder, include/svc/clip_encoder.hpp) behind the C handle
 API of include/svc_clip.h; this file loads frames, calls step() and reports.
 
@@ -410,8 +411,9 @@ def main() -> None:
                 "encoded_frames_per_step": r["encoded_per_step"],
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
-                "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-3) back to back on one stream; "
-                             "RANSAC+segmentation(s-2) beside them on a second (forked behind the motion search when a whole long clip is on the GPU, at the start of the iteration on shards); halo(s) on a third" if args.schedule == "pipelined"
+                "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-4) back to back on one stream; "
+                             "RANSAC+segmentation(s-2) beside them for up to two iterations, consecutive steps on two alternating streams (forked behind the "
+                             "motion search when a whole long clip is on the GPU, at the start of the iteration on shards); halo(s) on its own stream" if args.schedule == "pipelined"
                              else "one stream, stages back to back") + ("; steady-state iteration replayed from a hipGraph" if args.graph else ""),
                 "driver": "svc::ClipEncoder (C++, include/svc/clip_encoder.hpp)",
                 "parallelism": f"frame-sharded x{world}" + (f", halo = 1 pyramid/rank/step via {r['halo']}" if world > 1 else ""),
