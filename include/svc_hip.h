@@ -133,6 +133,11 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
  * lanes, one wave per SIMD, a few KB of LDS) instead of the shapes that are fastest alone (1024-lane workgroups that
  * need a whole CU's registers and would not start until the other kernel drains).  Results are identical. */
 #define SVC_LAUNCH_BESIDE 1u
+/* SVC_LAUNCH_NO_FORK: keep every kernel of the call on `stream` (the segmentation otherwise forks its heavy attempts to an
+ * internal side stream).  For callers that already run the call on a stream of its own: HIP multiplexes streams onto a
+ * few hardware queues, and an internal stream that lands on the queue of the caller's MAIN stream holds that stream's
+ * next kernel back for the length of an attempt kernel. */
+#define SVC_LAUNCH_NO_FORK 2u
 int svc_hip_ransac_frames_ex(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
                              svc_ransac_params params, const uint32_t* d_samples,
                              uint32_t iter_count, float* d_gm_xy, float* d_rmse,

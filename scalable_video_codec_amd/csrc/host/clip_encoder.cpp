@@ -330,6 +330,8 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   {
     const char* e = std::getenv("SVC_LAUNCH_BESIDE");  // A/B switch: "0" keeps the stand-alone shapes
     m.lat_flags = (c.schedule == Schedule::kPipelined && !(e && e[0] == '0')) ? SVC_LAUNCH_BESIDE : 0u;
+    const char* f = std::getenv("SVC_LAUNCH_NO_FORK");  // A/B switch: "0" lets the segmentation fork its side stream
+    if (c.schedule == Schedule::kPipelined && !(f && f[0] == '0')) m.lat_flags |= SVC_LAUNCH_NO_FORK;
   }
   m.fork_early = c.world > 1 || (uint64_t)m.sh.pairs * ((uint64_t)((c.width + c.mv_block - 1) / c.mv_block) * ((c.height + c.mv_block - 1) / c.mv_block)) < 1600000ull;
   const uint32_t f = 1u << (c.levels - 1);
@@ -419,6 +421,9 @@ void ClipEncoder::LoadFrames(const uint8_t* src, uint32_t first_local, uint32_t 
   Sync();
   Hip(hipMemcpy(m.bgr.p + (size_t)first_local * m.frame_bytes, src, (size_t)n * m.frame_bytes,
                 src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "hipMemcpy");
+  // a device-to-device hipMemcpy returns before the copy has run, and the streams of Step() do not order behind the
+  // null stream: without this the first luma kernel can read frames that have not landed (and `src` could be freed)
+  Hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
 }
 
 void ClipEncoder::SetComm(void* nccl_comm) { p_->comm = nccl_comm; }
@@ -605,6 +610,7 @@ int svc_clip_read(svc_clip* clip, uint32_t buffer, uint64_t offset, void* dst, u
     const uint8_t* p = static_cast<const uint8_t*>(clip->enc->Output((svc::Buffer)buffer, &have));
     if (offset + bytes > have) throw std::runtime_error("svc_clip_read: range exceeds the buffer");
     svc::Hip(hipMemcpy(dst, p + offset, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost), "hipMemcpy");
+    if (dst_on_device) svc::Hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");  // the next Step() may overwrite the source
   });
 }
 

@@ -1164,7 +1164,7 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
     SegArgs heavy = a;
     // more than kRegPts points per lane are possible: LDS for the large-frame path
     if (a.n > kRegPts * kTA) heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
-    if (capturing == hipStreamCaptureStatusNone) {
+    if (capturing == hipStreamCaptureStatusNone && !(flags & SVC_LAUNCH_NO_FORK)) {
       SideStream* side = side_stream(stream);
       if (!side) return fail(SVC_ERR_HIP, "segment: cannot create the side stream");
       SVC_HIP_TRY(hipEventRecord(side->fork, stream));

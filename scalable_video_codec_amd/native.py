@@ -175,6 +175,7 @@ def ebma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_
 
 
 LAUNCH_BESIDE = 1
+LAUNCH_NO_FORK = 2  # segmentation keeps its heavy attempts on the caller's stream (include/svc_hip.h)
 
 
 def ransac_frames(mv: torch.Tensor, samples: torch.Tensor, gm_in: Optional[torch.Tensor] = None,

@@ -23,7 +23,7 @@ def _scene(rng, mfw, mfh, n_rects, salt):
 
 @pytest.mark.parametrize("mfw,mfh", [(120, 68), (80, 45), (22, 18), (240, 135)])
 @pytest.mark.parametrize("conn", [4, 8])
-@pytest.mark.parametrize("flags", [0, 1], ids=["alone", "beside"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3], ids=["alone", "beside", "nofork", "beside-nofork"])
 def test_segment_matches_oracle(native, oracle, mfw, mfh, conn, flags):
     rng = np.random.default_rng(mfw * 7 + conn)
     frames = 5
@@ -71,7 +71,7 @@ def test_segment_edge_cases(native, oracle):
 @pytest.mark.parametrize("mfw,mfh,density", [(120, 68, 0.45), (120, 68, 0.7), (120, 68, 0.93), (120, 68, 1.0),
                                              (240, 135, 0.6), (240, 135, 0.97), (33, 31, 0.8),
                                              (480, 270, 0.35), (480, 270, 0.12)])
-@pytest.mark.parametrize("flags", [0, 1], ids=["alone", "beside"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3], ids=["alone", "beside", "nofork", "beside-nofork"])
 def test_segment_heavy_frames(native, oracle, mfw, mfh, density, flags):
     """Scene-cut-like frames: much of the field is foreground (the 1024-lane launch; above 8 192 blocks the
     points leave the registers for LDS and, at 8K, the workspace), next to a light and an empty frame."""
