@@ -469,6 +469,15 @@ def main() -> None:
                     "traffic_source": out["roofline"]["traffic_source"],
                     "algorithmic_bytes_per_launch": dct_bytes, "avg_launch_ms": dct_ms, "launches_per_step": nl["dct_quant"],
                 }
+        if world == 1 and "hbma" in kt and "dct_quant" in kt:
+            # the whole step against the same peak: the three main-stream kernels run back to back and are all
+            # HBM-bound, so (their algorithmic bytes) / (step time) says how far the STEP is from the roofline
+            step_bytes = cfg.luma_pyramid_bytes_per_frame() * info.frames + hbma_bytes + dct_bytes
+            step_gbps = step_bytes / (r["elapsed"] / args.steps) / 1e9
+            out["roofline_step"] = {"bound": "hbm", "achieved": step_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": step_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
+                                    "note": "luma+pyramid, motion search and transform of one step / ms_per_step; "
+                                            "RANSAC + segmentation move < 1 % of these bytes"}
         if world == 1 and not args.no_hbm_probe:
             # context only: what plain streaming kernels get from this box's HBM (not a ceiling: the DCT kernel beats the 1:4 probe)
             out["hbm_streaming_measured"] = {"unit": "GB/s", **hbm_streaming_rates(dev),

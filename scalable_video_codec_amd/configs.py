@@ -54,6 +54,11 @@ class CodecConfig:
         pw, ph = self.padded
         return 2 * sum((pw >> l) * (ph >> l) for l in range(self.levels)) + 12 * self.blocks
 
+    def luma_pyramid_bytes_per_frame(self) -> int:
+        """u8 BGR in, every pyramid level out once (level l + 1 is built from level l while it is on chip)."""
+        pw, ph = self.padded
+        return 3 * pw * ph + sum((pw >> l) * (ph >> l) for l in range(self.levels))
+
     def dct_bytes_per_frame(self) -> int:
         """u8 BGR in, f32 planar out: 5 * 3 * W * H (+ 4 B per MV block of types)."""
         pw, ph = self.padded
