@@ -68,6 +68,12 @@ class Oracle:
                                         _f32p, _f32p, _u32p, _u32p]
         L.svc_oracle_fg_mask.restype = None
         L.svc_oracle_fg_mask.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_luma.restype = None
+        L.svc_oracle_luma.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_pyr_down.restype = None
+        L.svc_oracle_pyr_down.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_luma_pyramid.restype = None
+        L.svc_oracle_luma_pyramid.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _u8p]
         L.svc_oracle_global_avg.restype = None
         L.svc_oracle_global_avg.argtypes = [_f32p, C.c_uint32, _f32p]
         L.svc_oracle_global_ebma.restype = None
@@ -132,6 +138,34 @@ class Oracle:
         if rc:
             raise ValueError("svc_oracle_hbma16_sse2: precondition violated")
         return mv, mad
+
+    # -- luma + pyramid (libs/encoder.cpp:468-470; OpenCV steps, parity unpinned) --
+    def luma(self, bgr):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        y = np.empty((h, w), np.uint8)
+        self.lib.svc_oracle_luma(_ptr(bgr, _u8p), w, h, _ptr(y, _u8p))
+        return y
+
+    def pyr_down(self, plane):
+        plane = np.ascontiguousarray(plane, np.uint8)
+        h, w = plane.shape
+        out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.svc_oracle_pyr_down(_ptr(plane, _u8p), w, h, _ptr(out, _u8p))
+        return out
+
+    def luma_pyramid(self, bgr, levels):
+        """Level planes of one B,G,R frame, level 0 first (w, h divisible by 2^(levels - 1))."""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        sizes = [((h >> l), (w >> l)) for l in range(levels)]
+        packed = np.empty(sum(a * b for a, b in sizes), np.uint8)
+        self.lib.svc_oracle_luma_pyramid(_ptr(bgr, _u8p), w, h, levels, _ptr(packed, _u8p))
+        out, o = [], 0
+        for a, b in sizes:
+            out.append(packed[o:o + a * b].reshape(a, b))
+            o += a * b
+        return out
 
     # -- whole-frame global motion (libs/motion.cpp:45-142) --
     def global_avg(self, mv):

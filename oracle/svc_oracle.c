@@ -403,6 +403,53 @@ void svc_oracle_ransac(const svc_oracle_vec2f* motion_field, uint32_t n,
   free(best);
 }
 
+/* ---- luma + pyramid (OpenCV steps, parity unpinned: see svc_oracle.h) ----- */
+
+void svc_oracle_luma(const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* y) {
+  const uint64_t n = (uint64_t)w * h;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+    y[i] = (uint8_t)((b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14); /* <= 255: the weights sum to 2^14 */
+  }
+}
+
+static int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+void svc_oracle_pyr_down(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
+  static const int k[5] = {1, 4, 6, 4, 1};
+  const uint32_t dw = (w + 1) / 2, dh = (h + 1) / 2;
+  int* rows = (int*)malloc((size_t)h * dw * sizeof(int)); /* horizontal pass of every source row */
+  for (uint32_t y = 0; y < h; ++y)
+    for (uint32_t x = 0; x < dw; ++x) {
+      int s = 0;
+      for (int t = 0; t < 5; ++t) s += k[t] * src[(size_t)y * w + reflect101(2 * (int)x + t - 2, (int)w)];
+      rows[(size_t)y * dw + x] = s;
+    }
+  for (uint32_t y = 0; y < dh; ++y)
+    for (uint32_t x = 0; x < dw; ++x) {
+      int s = 0;
+      for (int t = 0; t < 5; ++t) s += k[t] * rows[(size_t)reflect101(2 * (int)y + t - 2, (int)h) * dw + x];
+      dst[(size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
+    }
+  free(rows);
+}
+
+void svc_oracle_luma_pyramid(const uint8_t* bgr, uint32_t w, uint32_t h, uint32_t levels, uint8_t* packed) {
+  svc_oracle_luma(bgr, w, h, packed);
+  uint8_t* lvl = packed;
+  for (uint32_t l = 1; l < levels; ++l) {
+    uint8_t* next = lvl + (size_t)w * h;
+    svc_oracle_pyr_down(lvl, w, h, next);
+    lvl = next;
+    w = (w + 1) / 2;
+    h = (h + 1) / 2;
+  }
+}
+
 void svc_oracle_fg_mask(const uint32_t* inliers, uint32_t inlier_count,
                         uint32_t n, uint8_t* mask) {
   memset(mask, 255, n);

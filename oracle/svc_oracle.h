@@ -14,6 +14,10 @@
  *       the reference produced (tests/golden/, made by tests/golden/make_golden.py).
  *   quantisation : restated from libs/decoder.cpp:130-144, pinned by the hand
  *       vectors of SURVEY.md 8(c) (the TU needs OpenCV, so it cannot be built).
+ *   luma + pyramid : PARITY UNPINNED.  cv::cvtColor(BGR2YUV) + extractChannel +
+ *       cv::buildPyramid (libs/encoder.cpp:468-470) live in OpenCV 3.4.x (README:
+ *       3.4.16), neither vendored nor installed; restated from its published 8-bit
+ *       fixed-point algorithms (svc_oracle_luma / svc_oracle_pyr_down below).
  *   DCT : PARITY UNPINNED.  The arithmetic lives in OpenCV 3.4.x cv::dct
  *       (libs/encoder.cpp:335), which is neither vendored nor installed.  The
  *       oracle of record is the float64 orthonormal DCT-II from its definition.
@@ -114,6 +118,29 @@ void svc_oracle_global_hbma(const uint8_t* const* tracked_pyr,
                             const uint8_t* const* anchor_pyr, uint32_t levels, uint32_t w,
                             uint32_t h, uint32_t search_range, int reference_loop,
                             svc_oracle_vec2f* global_motion);
+
+/*
+ * libs/encoder.cpp:468-469: cv::cvtColor(frame, yuv, COLOR_BGR2YUV); cv::extractChannel(yuv, y, 0).
+ * OpenCV 3.4's 8-bit path is fixed point with 14 fractional bits: Y = (B * 1868 + G * 9617 +
+ * R * 4899 + (1 << 13)) >> 14 (coefficients 0.114 / 0.587 / 0.299 scaled by 2^14 and rounded).
+ * bgr: h x w x 3 interleaved B,G,R; y: h x w.
+ */
+void svc_oracle_luma(const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* y);
+
+/*
+ * One level of libs/encoder.cpp:470 cv::buildPyramid = cv::pyrDown with the default border:
+ * the separable 5-tap kernel [1 4 6 4 1] / 16 in both directions on integers, taps outside the
+ * plane taken by BORDER_REFLECT_101 (index -i -> i, n - 1 + i -> n - 1 - i), every second sample
+ * kept, dst = (sum + 128) >> 8.  src: h x w, dst: ((h + 1) / 2) x ((w + 1) / 2).
+ */
+void svc_oracle_pyr_down(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);
+
+/*
+ * libs/encoder.cpp:468-470 for one frame: luma, then `levels - 1` pyrDowns, the level planes written
+ * back to back (level 0 first) -- the packed layout of include/svc_hip.h.  w and h must be divisible
+ * by 2^(levels - 1) (the encoder pads to that, libs/encoder.cpp:164-168).
+ */
+void svc_oracle_luma_pyramid(const uint8_t* bgr, uint32_t w, uint32_t h, uint32_t levels, uint8_t* packed);
 
 /* libs/encoder.cpp:507-513: fg mask = 255 everywhere except RANSAC inliers. */
 void svc_oracle_fg_mask(const uint32_t* inliers, uint32_t inlier_count,

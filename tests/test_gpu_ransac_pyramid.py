@@ -1,5 +1,7 @@
 """GPU parity of RANSAC (libs/motion.cpp:182-266, draws made explicit) and of the
 luma/pyramid pre-step (this repo's fixed-point definitions, synth.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -134,15 +136,37 @@ def test_ransac_device_draw_past_the_field_stays_inside(native, oracle, frames, 
 # the last three are regressions: frames shorter than one 32-row LDS tile (rows beyond the frame
 # must not be reflected twice), found by tests/test_gpu_misc_property.py
 @pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4), (64, 16, 2), (32, 8, 3), (128, 2, 2)])
-def test_luma_pyramid(native, w, h, levels):
+def test_luma_pyramid(native, oracle, w, h, levels):
+    """svc_hip_luma_pyramid_frames against the oracle's restatement of cvtColor + buildPyramid (libs/encoder.cpp:468-470)."""
     rng = np.random.default_rng(w * 31 + h)
-    frames = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for _ in range(2)]
-    bgr = torch.stack(frames).cuda()
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(2)]
+    bgr = torch.from_numpy(np.stack(frames)).cuda()
     buf, stride = native.luma_pyramid_frames(bgr, levels)
     torch.cuda.synchronize()
     offs = synth.level_offsets(w, h, levels)
     for i, f in enumerate(frames):
-        pyr = synth.build_pyramid(synth.bgr_to_y(f), levels)
-        for l, p in enumerate(pyr):
-            got = buf[i * stride + offs[l]: i * stride + offs[l] + p.numel()].cpu().reshape(p.shape)
-            assert torch.equal(got, p), f"frame {i} level {l}: {(got != p).sum().item()} px differ"
+        for l, p in enumerate(oracle.luma_pyramid(f, levels)):
+            got = buf[i * stride + offs[l]: i * stride + offs[l] + p.size].cpu().numpy().reshape(p.shape)
+            assert np.array_equal(got, p), f"frame {i} level {l}: {(got != p).sum()} px differ"
+
+
+def test_luma_pyramid_golden(native):
+    """The committed fixture (tests/golden/luma_pyramid.npz, expected values from an independent numpy / scipy formulation):
+    the frames wide enough for the device entry point, through the C ABI."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "luma_pyramid.npz"))
+    ran = 0
+    for n in sorted({k.split("/")[0] for k in z.files if k.startswith("pyr_")}):
+        bgr = z[f"{n}/bgr"]
+        levels = sum(1 for k in z.files if k.startswith(f"{n}/level"))
+        h, w, _ = bgr.shape
+        try:
+            buf, stride = native.luma_pyramid_frames(torch.from_numpy(bgr[None]).cuda(), levels)
+        except native.SvcError as e:  # widths that are not a multiple of 16: a clean refusal
+            assert e.status in (native.SVC_ERR_UNSUPPORTED, native.SVC_ERR_INVALID_ARG)
+            continue
+        offs = synth.level_offsets(w, h, levels)
+        for l in range(levels):
+            want = z[f"{n}/level{l}"]
+            assert np.array_equal(buf[offs[l]:offs[l] + want.size].cpu().numpy().reshape(want.shape), want), (n, l)
+        ran += 1
+    assert ran >= 2

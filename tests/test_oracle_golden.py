@@ -159,3 +159,26 @@ def test_global_motion_golden(oracle):
         if r > 0:  # motion.cpp:72, :81: the reference visits no candidate
             assert want.tolist() == [0.0, 0.0, float(np.finfo(np.float32).max)]
     assert oracle.global_ebma(t, a, 4)[0].tolist() == [-3.0, 2.0]  # the search as meant finds the planted shift
+
+
+def test_luma_pyramid_golden(oracle):
+    """libs/encoder.cpp:468-470 (cvtColor BGR2YUV + extractChannel + buildPyramid; OpenCV steps, parity unpinned): the C
+    restatement against the committed fixture, whose expected values come from an independent numpy / scipy formulation
+    (tests/golden/make_luma_pyramid_golden.py), and the product package's generator against both."""
+    import torch
+    from scalable_video_codec_amd import synth
+    z = G.load("luma_pyramid.npz")
+    for f, want in zip(z["known/bgr"], z["known/y"]):
+        assert np.array_equal(oracle.luma(f), want)
+    names = sorted({k.split("/")[0] for k in z.files if k.startswith("pyr_")})
+    assert len(names) == 4
+    for n in names:
+        bgr = z[f"{n}/bgr"]
+        levels = sum(1 for k in z.files if k.startswith(f"{n}/level"))
+        got = oracle.luma_pyramid(bgr, levels)
+        gen = synth.build_pyramid(synth.bgr_to_y(torch.from_numpy(bgr)), levels)
+        for l in range(levels):
+            assert np.array_equal(got[l], z[f"{n}/level{l}"]), (n, l)
+            assert np.array_equal(gen[l].numpy(), z[f"{n}/level{l}"]), (n, l)
+    for n in ("odd", "row", "col", "two", "const"):
+        assert np.array_equal(oracle.pyr_down(z[f"down_{n}/in"]), z[f"down_{n}/out"]), n
