@@ -57,14 +57,17 @@ __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) {
 // plane of a packed pyramid): every dword's column is clamped into the row, so
 // nothing past the pyramid is ever touched; a clamped dword only feeds masked
 // candidates.
+// Addresses are `plane + 32-bit offset`: the plane pointer is uniform over the wavefront in the region-major kernel (the
+// pair comes from blockIdx alone), so the loads take the scalar-base + 32-bit-VGPR-offset form and no 64-bit address is
+// ever built in vector registers.
 template <int N, bool CLAMP>
-__device__ __forceinline__ void load_row(const uint8_t* row, int a0, int fw, uint32_t (&m)[N]) {
+__device__ __forceinline__ void load_row(const uint8_t* plane, uint32_t row_off, int a0, int fw, uint32_t (&m)[N]) {
   if (CLAMP) {
 #pragma unroll
     for (int k = 0; k < N; ++k)
-      m[k] = *reinterpret_cast<const uint32_t*>(row + min(a0 + 4 * k, fw - 4));
+      m[k] = *reinterpret_cast<const uint32_t*>(plane + (row_off + (uint32_t)min(a0 + 4 * k, fw - 4)));
   } else {
-    const uint8_t* p = row + a0;
+    const uint8_t* p = plane + (row_off + (uint32_t)a0);
     if (N == 6) {
       u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
       u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(p + 16);
@@ -175,14 +178,13 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
 #pragma unroll
   for (int d = 0; d < NDY; ++d) { acc4[d] = 0; acc1[d] = 0; }
   uint32_t a[B][NW];
-  const uint8_t* tp = trk + (size_t)w.wy * fw;
-  const uint8_t* ap = anc + (size_t)ay * fw + ax;
+  const uint32_t to = (uint32_t)(w.wy * fw), ao = (uint32_t)(ay * fw + ax);  // a plane is far below 2^32 bytes
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     uint32_t m[ND], v[NW + 1];
-    load_row<ND, TOP>(tp + (size_t)t * fw, a0, fw, m);
-    if (t < B) load_anchor_row<NW>(ap + (size_t)t * fw, a[t < B ? t : 0]);
+    load_row<ND, TOP>(trk, to + (uint32_t)(t * fw), a0, fw, m);
+    if (t < B) load_anchor_row<NW>(anc + (ao + (uint32_t)(t * fw)), a[t < B ? t : 0]);
 #pragma unroll
     for (int k = 0; k <= NW; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
 #pragma unroll
@@ -226,12 +228,12 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
   uint32_t a[B];
 #pragma unroll
   for (int r = 0; r < B; ++r)
-    a[r] = *reinterpret_cast<const uint16_t*>(anc + (size_t)(ay + r) * fw + ax);
-  const uint8_t* tp = trk + (size_t)w.wy * fw;
+    a[r] = *reinterpret_cast<const uint16_t*>(anc + (uint32_t)((ay + r) * fw + ax));
+  const uint32_t to = (uint32_t)(w.wy * fw);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     uint32_t m[3];
-    load_row<3, true>(tp + (size_t)t * fw, a0, fw, m);
+    load_row<3, true>(trk, to + (uint32_t)(t * fw), a0, fw, m);
     // window bytes 0 .. 2RT+1 (<= 6) as two dwords starting at the window origin
     const uint32_t v0 = __builtin_amdgcn_alignbyte(m[1], m[0], sh);
     const uint32_t v1 = __builtin_amdgcn_alignbyte(m[2], m[1], sh);
@@ -258,10 +260,10 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
 #define SVC_HBMA_OCC
 #endif
 
-template <int L, int RT>
+template <int L, int RT, bool REGION>
 __global__ __launch_bounds__(256) SVC_HBMA_OCC void hbma_fused16_kernel(FusedArgs a) {
   uint32_t item, pair, blk;
-  if (a.wgs_per_region) {
+  if (REGION) {
     // Region-major order.  Workgroups are dealt round-robin over the 8 XCDs, so XCD x gets blockIdx 8k + x: it is
     // given the x-th eighth of the frame (a band of block rows) of EVERY pair, pairs in order.  The pyramid of frame
     // p + 1 is the anchor of pair p and the tracked frame of pair p + 1: the two workgroups that read a band of it are
@@ -338,11 +340,17 @@ int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_
   if (wgs > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu workgroups exceed one launch", (unsigned long long)wgs);
   const dim3 grid((uint32_t)wgs), block(256);
   const uint32_t rt = range >> (levels - 1);
-  if (levels == 3 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<3, 2>), grid, block, 0, stream, a);
-  else if (levels == 3 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<3, 1>), grid, block, 0, stream, a);
-  else if (levels == 4 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<4, 1>), grid, block, 0, stream, a);
-  else if (levels == 4 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<4, 2>), grid, block, 0, stream, a);
+#define SVC_FUSED_LAUNCH(LV, R)                                                                        \
+  do {                                                                                                 \
+    if (a.wgs_per_region) hipLaunchKernelGGL((hbma_fused16_kernel<LV, R, true>), grid, block, 0, stream, a); \
+    else hipLaunchKernelGGL((hbma_fused16_kernel<LV, R, false>), grid, block, 0, stream, a);           \
+  } while (0)
+  if (levels == 3 && rt == 2) SVC_FUSED_LAUNCH(3, 2);
+  else if (levels == 3 && rt == 1) SVC_FUSED_LAUNCH(3, 1);
+  else if (levels == 4 && rt == 1) SVC_FUSED_LAUNCH(4, 1);
+  else if (levels == 4 && rt == 2) SVC_FUSED_LAUNCH(4, 2);
   else return fail(SVC_ERR_UNSUPPORTED, "hbma fused: levels=%u r_top=%u not instantiated", levels, rt);
+#undef SVC_FUSED_LAUNCH
   return check_launch("hbma_fused16_kernel");
 }
 
