@@ -121,6 +121,22 @@ def test_hbma_pairs_batched_clip(native, oracle, levels):
         _assert_same(mvw[p].cpu().numpy(), madw[p].cpu().numpy(), exp_mv, exp_mad, f"wave pair {p}")
 
 
+@pytest.mark.parametrize("levels,search", [(3, 8), (3, 4), (4, 8), (4, 16)])
+def test_hbma_fused_pair_major_instantiation(native, levels, search, monkeypatch):
+    """SVC_HBMA_ORDER=pair (the A/B switch of tools/ab_hbma_order.sh) launches a separate instantiation of the fused kernel
+    -- workgroups may straddle pairs, per-lane plane bases -- that the default order never runs: same results, including a
+    block count that is not a multiple of 256 and pairs that end inside a workgroup."""
+    n = 4
+    _, pyrs, (pw, ph) = util.clip_frames(352, 208, n, 0x5EED + levels, levels)
+    stride = native.pyramid_stride(pw, ph, levels)
+    buf = util.pack_clip(pyrs, stride, "cuda")
+    mv, mad = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, search)
+    monkeypatch.setenv("SVC_HBMA_ORDER", "pair")
+    mvp, madp = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, search)
+    torch.cuda.synchronize()
+    assert torch.equal(mv, mvp) and torch.equal(mad, madp)
+
+
 def test_invalid_args(native):
     t = [np.zeros((64, 64), np.uint8)]
     with pytest.raises(native.SvcError) as e:
