@@ -77,9 +77,8 @@ template <> struct RecDc<16> { static constexpr double v = kDctRec16_Dc; };
 // of a level act on the differences x[i] - x[M-1-i], the even rows are a scaled M/2-point DCT of the
 // sums (86 multiplies for 16 points instead of 128, 22 instead of 32 for 8).  x holds the M inputs
 // of level L, y the N outputs: level L produces the rows k = 2^L * odd.
-// T = float for the row pass: the inputs are integers <= 255, so the sums and differences of every
-// level are integers <= 4080, exact in f32 (half the cost of f64 on this chip); only the operands of
-// the multiplies are widened.
+// T = int for the row pass: the inputs are bytes, so the sums and differences of every level are integers <= 4080 (byte
+// extraction folds into the adds as SDWA operands); each operand of a multiply is widened once (v_cvt_f64_i32).
 template <int N, int M, int L, typename T>
 __device__ __forceinline__ void dct_level(const T* __restrict__ x, double* __restrict__ y) {
   if constexpr (M == 1) {
@@ -129,6 +128,20 @@ __device__ __forceinline__ float quant1_fast(float c, float step, float inv) {
   float q = __builtin_fmaf(r, inv, q0);
   q = __builtin_truncf(q + __builtin_copysignf(0.49999997f, q));
   return q * step;
+}
+
+// Two coefficients of one tile at a time: the same five steps as v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, which issue
+// like one f32 instruction on gfx950 (copysign and trunc have no packed form) -- 9 instructions per pair instead of 14.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 quant2_fast(f32x2 c, float step, float inv) {
+  const f32x2 s2 = {step, step}, i2 = {inv, inv};
+  const f32x2 q0 = c * i2;
+  const f32x2 r = __builtin_elementwise_fma(-q0, s2, c);
+  f32x2 q = __builtin_elementwise_fma(r, i2, q0);
+  const f32x2 h = {__builtin_copysignf(0.49999997f, q.x), __builtin_copysignf(0.49999997f, q.y)};
+  q = q + h;
+  q = f32x2{__builtin_truncf(q.x), __builtin_truncf(q.y)};
+  return q * s2;
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -214,6 +227,7 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
+#ifdef SVC_DCT_ROW_F32  // A/B switch: the round-1 form (butterflies in f32: two conversions per multiply operand)
     float x[16];
     double r[16];
 #pragma unroll
@@ -224,6 +238,18 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
     } else {
       dct1d<16, float>(x, r);
     }
+#else
+    int x[16];
+    double r[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) x[p] = (int)((wds[(3 * p + c) >> 2] >> (8 * ((3 * p + c) & 3))) & 0xFFu);
+    if (N == 8) {
+      dct1d<8, int>(x, r);
+      dct1d<8, int>(x + 8, r + 8);
+    } else {
+      dct1d<16, int>(x, r);
+    }
+#endif
 #ifdef SVC_DCT_SLAB32
     int4* row = reinterpret_cast<int4*>(slab + j * kRowPitch);
 #pragma unroll
@@ -260,7 +286,10 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 #pragma unroll
       for (int v = 0; v < 8; ++v) {
         float fa = (float)ya[v], fb = (float)yb[v];
-        if (QUANT) { fa = quant1_fast(fa, step, inv_step); fb = quant1_fast(fb, step, inv_step); }
+        if (QUANT) {
+          const f32x2 qq = quant2_fast(f32x2{fa, fb}, step, inv_step);
+          fa = qq.x; fb = qq.y;
+        }
         if (WIRE) *reinterpret_cast<float2*>(slab + v * 64 + j * 8) = make_float2(fa, fb);
         else *reinterpret_cast<float2*>(dst + (size_t)v * a.w) = make_float2(fa, fb);
       }
@@ -289,11 +318,16 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
       float* dst = plane + (size_t)y_pix * a.w + x_pix + j;
       if (WIRE) wave_lds_sync();
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        float f = (float)yy[v];
-        if (QUANT) f = quant1_fast(f, step, inv_step);
-        if (WIRE) *reinterpret_cast<float*>(slab + v * 64 + j * 4) = f;
-        else dst[(size_t)v * a.w] = f;
+      for (int v = 0; v < 16; v += 2) {
+        f32x2 f = {(float)yy[v], (float)yy[v + 1]};
+        if (QUANT) f = quant2_fast(f, step, inv_step);
+        if (WIRE) {
+          *reinterpret_cast<float*>(slab + v * 64 + j * 4) = f.x;
+          *reinterpret_cast<float*>(slab + (v + 1) * 64 + j * 4) = f.y;
+        } else {
+          dst[(size_t)v * a.w] = f.x;
+          dst[(size_t)(v + 1) * a.w] = f.y;
+        }
       }
       if (WIRE) {
         wave_lds_sync();
