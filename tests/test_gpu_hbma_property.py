@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
+from tests.util import FUZZ_RANDOM, fuzz_examples
+
 pytestmark = pytest.mark.gpu
 
 
@@ -43,7 +45,7 @@ def _planes(kind, rng, w, h, levels):
     return pyr(base_t), pyr(base_a)
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+@settings(max_examples=fuzz_examples(60), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=not FUZZ_RANDOM)
 @given(case=hbma_case())
 def test_hbma_random_shapes(native, oracle, case):
     levels, bw, bh, w, h, r, seed, kind = case
@@ -54,7 +56,7 @@ def test_hbma_random_shapes(native, oracle, case):
         assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (case, flags)
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+@settings(max_examples=fuzz_examples(40), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=not FUZZ_RANDOM)
 @given(levels=st.sampled_from([3, 4]), rt=st.sampled_from([1, 2]), nbx=st.integers(2, 9), nby=st.integers(1, 6),
        seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["noise", "shifted", "flat", "periodic"]))
 def test_fused_kernel_random_frames(native, oracle, levels, rt, nbx, nby, seed, kind):

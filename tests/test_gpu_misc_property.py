@@ -5,13 +5,15 @@ import pytest
 import torch
 from hypothesis import HealthCheck, given, settings, strategies as st
 
+from tests.util import FUZZ_RANDOM, fuzz_examples
+
 from scalable_video_codec_amd import synth
 
 pytestmark = pytest.mark.gpu
-_S = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+_S = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=not FUZZ_RANDOM)
 
 
-@settings(max_examples=40, **_S)
+@settings(max_examples=fuzz_examples(40), **_S)
 @given(kx=st.integers(1, 20), ky=st.integers(1, 12), levels=st.integers(1, 4), frames=st.integers(1, 3),
        seed=st.integers(0, 2 ** 31 - 1))
 def test_luma_pyramid_random_sizes(native, oracle, kx, ky, levels, frames, seed):
@@ -32,7 +34,7 @@ def test_luma_pyramid_random_sizes(native, oracle, kx, ky, levels, frames, seed)
             assert np.array_equal(got, ref), (w, h, levels, i, l)
 
 
-@settings(max_examples=30, **_S)
+@settings(max_examples=fuzz_examples(30), **_S)
 @given(kx=st.integers(1, 8), ky=st.integers(1, 6), block=st.sampled_from([8, 16]), seed=st.integers(0, 2 ** 31 - 1),
        fg=st.sampled_from([1, 2, 7]), bg=st.sampled_from([1, 640, 65535]))
 def test_dct_quant_decode_random_sizes(native, oracle, kx, ky, block, seed, fg, bg):
@@ -53,7 +55,7 @@ def test_dct_quant_decode_random_sizes(native, oracle, kx, ky, block, seed, fg, 
     assert (np.abs(rec - ref_rec) <= 1e-4 * np.maximum(1.0, np.abs(ref_rec))).all()
 
 
-@settings(max_examples=40, **_S)
+@settings(max_examples=fuzz_examples(40), **_S)
 @given(mfw=st.integers(1, 48), mfh=st.integers(1, 40), density=st.floats(0.0, 1.0), seed=st.integers(0, 2 ** 31 - 1),
        conn=st.sampled_from([4, 8]), k=st.integers(1, 12), attempts=st.integers(1, 4))
 def test_segment_random_fields(native, oracle, mfw, mfh, density, seed, conn, k, attempts):
@@ -67,7 +69,7 @@ def test_segment_random_fields(native, oracle, mfw, mfh, density, seed, conn, k,
     assert np.array_equal(got.astype(np.uint32), want), (mfw, mfh, density, conn, k, attempts)
 
 
-@settings(max_examples=60, **_S)
+@settings(max_examples=fuzz_examples(60), **_S)
 @given(mfw=st.integers(50, 140), mfh=st.integers(30, 75), density=st.floats(0.05, 1.0), blobs=st.integers(0, 4),
        seed=st.integers(0, 2 ** 31 - 1), conn=st.sampled_from([4, 8]), k=st.integers(2, 14), attempts=st.integers(1, 3),
        mw=st.integers(1, 5), mh=st.integers(1, 5), iters=st.integers(1, 12))
@@ -97,7 +99,7 @@ def test_segment_random_large_fields(native, oracle, mfw, mfh, density, blobs, s
         assert np.array_equal(got[f].astype(np.uint32), want), (f, mfw, mfh, density, blobs, conn, k, attempts, mw, mh, iters)
 
 
-@settings(max_examples=25, **_S)
+@settings(max_examples=fuzz_examples(25), **_S)
 @given(kx=st.integers(1, 6), ky=st.integers(1, 5), block=st.sampled_from([8, 16]), cut=st.integers(0, 1),
        seed=st.integers(0, 2 ** 31 - 1), quant=st.booleans())
 def test_records_random_sizes(native, oracle, kx, ky, block, cut, seed, quant):

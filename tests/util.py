@@ -1,6 +1,8 @@
 """Shared helpers for the parity tests: seeded clips -> numpy pyramids."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -34,3 +36,12 @@ def pack_clip(pyrs, stride, device):
                           for p in pyr])
         buf[i * stride:i * stride + flat.numel()] = flat
     return buf.to(device)
+
+
+# One-off deep fuzz of the hypothesis suites: SVC_FUZZ_SCALE=10 SVC_FUZZ_RANDOM=1 python -m pytest tests -m gpu -k "property or random"
+# (default: the committed example counts, derandomised so that every run checks the same cases).
+FUZZ_RANDOM = os.environ.get("SVC_FUZZ_RANDOM", "0") == "1"
+
+
+def fuzz_examples(n: int) -> int:
+    return n * max(1, int(os.environ.get("SVC_FUZZ_SCALE", "1")))
