@@ -224,8 +224,12 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     n_cfg = args.frames or cfg.frames
     clip_frames = n_cfg if mode == "strong" else n_cfg * world
     schedule = clipmod.SERIAL if args.schedule == "serial" else clipmod.PIPELINED
+    hbma_flags = {"auto": native.HBMA_AUTO, "tiled": native.HBMA_FORCE_TILED, "lane": native.HBMA_FORCE_LANE,
+                  "wave": native.HBMA_FORCE_WAVE_PER_BLOCK}[args.hbma_kernel]
+    tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule, graph=args.graph,
-                       segmentation=not args.no_segmentation, wire=args.wire)
+                       segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
+                       lat_depth=args.lat_depth, tuning=tuning)
     info = enc.info
     src = synth.SynthClip(cfg.width, cfg.height, clip_frames, cfg.seed, device=dev)
     pw, ph = cfg.padded
@@ -319,6 +323,17 @@ def main() -> None:
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-stage HIP events on every n-th timed step (every step when --steps < 8)")
+    # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The
+    # environment variables of the round-2 scripts under tools/ are honoured HERE as defaults, not inside the library.
+    ap.add_argument("--hbma-kernel", choices=("auto", "tiled", "lane", "wave"), default=os.environ.get("SVC_HBMA_KERNEL", "auto"),
+                    help="motion search kernel: auto (LDS-tiled for 4 levels / r_top 1, lane-per-block for the other fused shapes), "
+                         "tiled, lane (lane-per-block, no LDS), wave (per-level general kernel)")
+    ap.add_argument("--lat-depth", type=int, default=int(os.environ.get("SVC_LAT_DEPTH", "0")),
+                    help="pipelined: iterations RANSAC + segmentation get to finish (1..3; 0 = default 2)")
+    ap.add_argument("--standalone-shapes", action="store_true", default=os.environ.get("SVC_LAUNCH_BESIDE", "1") == "0",
+                    help="pipelined: keep the stand-alone launch shapes of RANSAC / segmentation")
+    ap.add_argument("--segment-fork", action="store_true", default=os.environ.get("SVC_LAUNCH_NO_FORK", "1") == "0",
+                    help="pipelined: let the segmentation fork its heavy attempts to a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     args = ap.parse_args()
@@ -442,9 +457,11 @@ def main() -> None:
             hbma_bytes = cfg.hbma_bytes_per_frame() * info.pairs
             hbma_ms = kt["hbma"] / nl["hbma"]
             hbma_gbps = hbma_bytes / (hbma_ms * 1e-3) / 1e9
-            fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2)
+            fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2) and args.hbma_kernel != "wave"
+            tiled = fused and cfg.levels == 4 and cfg.r_top == 1 and pw % 64 == 0 and args.hbma_kernel in ("auto", "tiled")
             out["roofline"] = {
-                "kernel": "hbma_fused16_kernel (MAD search, all pyramid levels)" if fused else
+                "kernel": "hbma_tile16_kernel (MAD search, all pyramid levels, windows staged in LDS)" if tiled else
+                          "hbma_fused16_kernel (MAD search, all pyramid levels, lane per block)" if fused else
                           "hbma_wave_level_kernel (LDS-staged wave-per-block search)",
                 "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": hbma_gbps / HBM_PEAK_GBPS,

@@ -66,6 +66,11 @@ struct ClipEncoderConfig {
   uint32_t rank = 0, world = 1;
   Schedule schedule = Schedule::kPipelined;
   bool graph = false;         // replay the steady-state iteration from a captured hipGraph
+  // Tuning (the A/B switches of the measurements under profiles/; results never depend on them)
+  uint32_t hbma_flags = SVC_HBMA_AUTO;  // kernel choice of the motion search, SVC_HBMA_*
+  uint32_t lat_depth = 0;               // pipelined: iterations RANSAC + segmentation get, 1..3; 0 = 2 (1 with graph)
+  bool standalone_shapes = false;       // pipelined: keep the latency-bound stages' stand-alone launch shapes
+  bool segment_fork = false;            // pipelined: let the segmentation fork its heavy attempts to a side stream
 };
 
 enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kCount };

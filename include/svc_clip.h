@@ -26,6 +26,9 @@ typedef struct svc_clip svc_clip;
 #define SVC_CLIP_SERIAL 0u    /* a step's stages back to back on one stream */
 #define SVC_CLIP_PIPELINED 1u /* software pipeline over consecutive steps, see clip_encoder.hpp */
 
+#define SVC_CLIP_TUNE_STANDALONE_SHAPES 1u /* pipelined: RANSAC / segmentation keep their stand-alone launch shapes */
+#define SVC_CLIP_TUNE_SEGMENT_FORK 2u      /* pipelined: the segmentation may fork its heavy attempts to a side stream */
+
 typedef struct svc_clip_config {
   uint32_t width, height; /* source size (padded per libs/encoder.cpp:164-168) */
   uint32_t levels, mv_block, search_range;
@@ -40,6 +43,11 @@ typedef struct svc_clip_config {
   uint32_t rank, world; /* this handle holds shard `rank` of `world` */
   uint32_t schedule;    /* SVC_CLIP_SERIAL / SVC_CLIP_PIPELINED */
   uint32_t graph;       /* 1: replay the steady-state iteration from a captured hipGraph */
+  /* Tuning; all zero = the defaults.  These are the A/B switches of the measurements under profiles/ -- they change
+   * launch shapes and kernel choice, never results. */
+  uint32_t hbma_flags;  /* SVC_HBMA_* passed to svc_hip_hbma_pairs (0 = SVC_HBMA_AUTO) */
+  uint32_t lat_depth;   /* pipelined: iterations RANSAC + segmentation get to finish, 1..3 (0 = 2; ignored with graph) */
+  uint32_t tuning;      /* SVC_CLIP_TUNE_* bits */
 } svc_clip_config;
 
 typedef struct svc_clip_info {

@@ -67,6 +67,8 @@ typedef struct svc_segment_params {
 #define SVC_HBMA_AUTO 0u
 #define SVC_HBMA_FORCE_WAVE_PER_BLOCK 1u /* per-level LDS-staged kernel (any shape) */
 #define SVC_HBMA_FORCE_FUSED 2u          /* fused all-level kernel; UNSUPPORTED if the shape does not fit */
+#define SVC_HBMA_FORCE_TILED 4u          /* fused kernel, LDS-tiled form (4 levels, r_top 1); UNSUPPORTED elsewhere */
+#define SVC_HBMA_FORCE_LANE 8u           /* fused kernel, lane-per-block form without LDS (every fused shape) */
 
 const char* svc_hip_last_error(void);
 int svc_hip_abi_version(void); /* 2 (round 2: additions only -- *_ex launch flags, global motion, comm / halo shift) */

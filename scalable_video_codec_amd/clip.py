@@ -19,6 +19,7 @@ from .native import RansacParams, SegmentParams
 _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
 
 SERIAL, PIPELINED = 0, 1
+TUNE_STANDALONE_SHAPES, TUNE_SEGMENT_FORK = 1, 2  # svc_clip_config.tuning bits
 STAGES = ("luma_pyramid", "halo_exchange", "hbma", "ransac", "segment", "dct_quant")
 BUFFERS = {"mv": (0, torch.float32), "min_mad": (1, torch.float32), "global_motion": (2, torch.float32),
            "rmse": (3, torch.float32), "inlier_mask": (4, torch.uint8), "inlier_count": (5, torch.int32),
@@ -31,7 +32,8 @@ class ClipConfig(C.Structure):
     _fields_ = [("width", _u32), ("height", _u32), ("levels", _u32), ("mv_block", _u32), ("search_range", _u32),
                 ("dct_block_w", _u32), ("dct_block_h", _u32), ("fg_step", _u32), ("bg_step", _u32), ("wire", _u32),
                 ("segmentation", _u32), ("seed", _u64), ("ransac", RansacParams), ("segment", SegmentParams),
-                ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("graph", _u32)]
+                ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("graph", _u32),
+                ("hbma_flags", _u32), ("lat_depth", _u32), ("tuning", _u32)]
 
 
 class ClipInfo(C.Structure):
@@ -128,7 +130,8 @@ class Clip:
 
     def __init__(self, cfg: CodecConfig, clip_frames: int, rank: int = 0, world: int = 1, schedule: int = PIPELINED,
                  graph: bool = False, segmentation: bool = True, wire: bool = False, seed: Optional[int] = None,
-                 ransac: Optional[dict] = None, segment: Optional[dict] = None, dct_block: Optional[Tuple[int, int]] = None):
+                 ransac: Optional[dict] = None, segment: Optional[dict] = None, dct_block: Optional[Tuple[int, int]] = None,
+                 hbma_flags: int = 0, lat_depth: int = 0, tuning: int = 0):
         self.cfg = cfg
         r = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
         r.update(ransac or {})
@@ -138,7 +141,7 @@ class Clip:
         self.config = ClipConfig(cfg.width, cfg.height, cfg.levels, cfg.mv_block, cfg.search_range, bw, bh,
                                  cfg.fg_step, cfg.bg_step, int(wire), int(segmentation),
                                  cfg.seed if seed is None else seed, RansacParams(**r), SegmentParams(**s),
-                                 clip_frames, rank, world, schedule, int(graph))
+                                 clip_frames, rank, world, schedule, int(graph), hbma_flags, lat_depth, tuning)
         self._h = _vp()
         self._cb = None  # keeps the ctypes callback alive
         _check(load().svc_clip_create(C.byref(self.config), C.byref(self._h)))

@@ -26,8 +26,6 @@
 // dyadic rational; the MAD carried across levels (libs/motion.cpp:401 compares a
 // level-l MAD with the level-(l+1) minimum) is kept as the integer sad << 2l
 // (units of 1/256) and converted once at the end: bit-identical to the float path.
-#include <cstdlib>
-
 #include "svc_common.hpp"
 
 namespace svc {
@@ -41,7 +39,7 @@ struct FusedArgs {
   uint64_t pair_stride;
   uint32_t n_items;  // pairs * blocks
   uint32_t n_pairs;
-  uint32_t wgs_per_region;  // 0: pair-major order; else workgroups of a frame per XCD region (see the kernel)
+  uint32_t wgs_per_region;  // workgroups of one frame pair per XCD region (see the kernels)
   uint32_t blocks;
   uint32_t mfw;
   uint32_t w, h;     // base-level frame size
@@ -210,33 +208,45 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
 
 // Top level of a 4-level pyramid: 2x2 blocks (reference motion.cpp:719-720).  Two
 // bytes per anchor row do not fill a QSAD word, so this level uses v_sad_u8 on
-// 16-bit slices; it is 1/64 of the pixels of level 0.
-template <int RT, int SHIFT>
-__device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
-                                              const uint8_t* __restrict__ anc, int fw, int fh,
-                                              int bx, int by, int& mvx, int& mvy, uint32_t& best) {
-  constexpr int B = 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+// 16-bit slices; it is 1/64 of the pixels of level 0.  Loading and searching are
+// separate steps so that a caller can put other loads between them.
+template <int RT>
+struct TopB2 {
+  static constexpr int NT = 2 + 2 * RT;
+  Window w;
+  uint32_t m[NT][3];
+  uint32_t a[2];
+};
+
+template <int RT>
+__device__ __forceinline__ void load_top_b2(const uint8_t* __restrict__ trk, const uint8_t* __restrict__ anc, int fw,
+                                            int fh, int bx, int by, TopB2<RT>& s) {
+  constexpr int B = 2, NT = TopB2<RT>::NT;
   const int ax = bx * B, ay = by * B;
-  const Window w = make_window<B, RT>(ax, ay, fw, fh);
-  const int a0 = w.wx & ~3;
-  const uint32_t sh = (uint32_t)(w.wx & 3);
-  uint32_t s[NDY][NDY];
+  s.w = make_window<B, RT>(ax, ay, fw, fh);
+  const int a0 = s.w.wx & ~3;
+#pragma unroll
+  for (int r = 0; r < B; ++r)
+    s.a[r] = *reinterpret_cast<const uint16_t*>(anc + (uint32_t)((ay + r) * fw + ax));
+  const uint32_t to = (uint32_t)(s.w.wy * fw);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) load_row<3, true>(trk, to + (uint32_t)(t * fw), a0, fw, s.m[t]);
+}
+
+template <int RT, int SHIFT>
+__device__ __forceinline__ void search_top_b2(const TopB2<RT>& s, int bx, int by, int& mvx, int& mvy, uint32_t& best) {
+  constexpr int B = 2, NDY = 2 * RT + 1, NT = TopB2<RT>::NT;
+  const uint32_t sh = (uint32_t)(s.w.wx & 3);
+  uint32_t sad[NDY][NDY];
 #pragma unroll
   for (int d = 0; d < NDY; ++d)
 #pragma unroll
-    for (int j = 0; j < NDY; ++j) s[d][j] = 0;
-  uint32_t a[B];
-#pragma unroll
-  for (int r = 0; r < B; ++r)
-    a[r] = *reinterpret_cast<const uint16_t*>(anc + (uint32_t)((ay + r) * fw + ax));
-  const uint32_t to = (uint32_t)(w.wy * fw);
+    for (int j = 0; j < NDY; ++j) sad[d][j] = 0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    uint32_t m[3];
-    load_row<3, true>(trk, to + (uint32_t)(t * fw), a0, fw, m);
     // window bytes 0 .. 2RT+1 (<= 6) as two dwords starting at the window origin
-    const uint32_t v0 = __builtin_amdgcn_alignbyte(m[1], m[0], sh);
-    const uint32_t v1 = __builtin_amdgcn_alignbyte(m[2], m[1], sh);
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(s.m[t][1], s.m[t][0], sh);
+    const uint32_t v1 = __builtin_amdgcn_alignbyte(s.m[t][2], s.m[t][1], sh);
     uint32_t tj[NDY];
 #pragma unroll
     for (int j = 0; j < NDY; ++j)
@@ -247,39 +257,26 @@ __device__ __forceinline__ void search_top_b2(const uint8_t* __restrict__ trk,
       if (r >= 0 && r < B) {
 #pragma unroll
         for (int j = 0; j < NDY; ++j)
-          s[d][j] = __builtin_amdgcn_sad_u8(tj[j], a[r >= 0 && r < B ? r : 0], s[d][j]);
+          sad[d][j] = __builtin_amdgcn_sad_u8(tj[j], s.a[r >= 0 && r < B ? r : 0], sad[d][j]);
       }
     }
   }
-  select<RT, true, SHIFT>(w, ax, ay, [&](int d, int j) { return s[d][j]; }, mvx, mvy, best);
+  select<RT, true, SHIFT>(s.w, bx * B, by * B, [&](int d, int j) { return sad[d][j]; }, mvx, mvy, best);
 }
 
-#ifdef SVC_HBMA_WAVES8  // A/B switch: force 64 VGPRs (8 waves per SIMD) at the price of a 24-28 B/lane spill
-#define SVC_HBMA_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
-#else
-#define SVC_HBMA_OCC
-#endif
-
-template <int L, int RT, bool REGION>
-__global__ __launch_bounds__(256) SVC_HBMA_OCC void hbma_fused16_kernel(FusedArgs a) {
-  uint32_t item, pair, blk;
-  if (REGION) {
-    // Region-major order.  Workgroups are dealt round-robin over the 8 XCDs, so XCD x gets blockIdx 8k + x: it is
-    // given the x-th eighth of the frame (a band of block rows) of EVERY pair, pairs in order.  The pyramid of frame
-    // p + 1 is the anchor of pair p and the tracked frame of pair p + 1: the two workgroups that read a band of it are
-    // neighbours in one XCD's dispatch sequence, so the second read is served by that XCD's L2 instead of crossing the
-    // fabric again.  Speed only: any placement gives the same result.
-    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-    pair = k / a.wgs_per_region;
-    blk = (xcd * a.wgs_per_region + (k - pair * a.wgs_per_region)) * 256u + threadIdx.x;
-    if (pair >= a.n_pairs || blk >= a.blocks) return;
-    item = pair * a.blocks + blk;
-  } else {
-    item = blockIdx.x * 256u + threadIdx.x;
-    if (item >= a.n_items) return;
-    pair = item / a.blocks;
-    blk = item - pair * a.blocks;
-  }
+template <int L, int RT>
+__global__ __launch_bounds__(256) void hbma_fused16_kernel(FusedArgs a) {
+  // Region-major order.  Workgroups are dealt round-robin over the 8 XCDs, so XCD x gets blockIdx 8k + x: it is
+  // given the x-th eighth of the frame (a band of block rows) of EVERY pair, pairs in order.  The pyramid of frame
+  // p + 1 is the anchor of pair p and the tracked frame of pair p + 1: the two workgroups that read a band of it are
+  // neighbours in one XCD's dispatch sequence, so the second read is served by that XCD's L2 instead of crossing the
+  // fabric again.  Speed only: any placement gives the same result.  (The pair-major order of round 1 was measured
+  // against it and dropped: profiles/r02_ab_hbma_order.txt.)
+  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+  const uint32_t pair = k / a.wgs_per_region;
+  const uint32_t blk = (xcd * a.wgs_per_region + (k - pair * a.wgs_per_region)) * 256u + threadIdx.x;
+  if (pair >= a.n_pairs || blk >= a.blocks) return;
+  const uint32_t item = pair * a.blocks + blk;
   const int by = (int)(blk / a.mfw), bx = (int)(blk - (uint32_t)by * a.mfw);
 
   const uint8_t* trk = a.tracked + (size_t)pair * a.pair_stride;
@@ -290,7 +287,9 @@ __global__ __launch_bounds__(256) SVC_HBMA_OCC void hbma_fused16_kernel(FusedArg
   int mvx = 0, mvy = 0;
   uint32_t best = 0;
   if (L == 4) {
-    search_top_b2<RT, 6>(trk + o3, anc + o3, w >> 3, h >> 3, bx, by, mvx, mvy, best);
+    TopB2<RT> top;
+    load_top_b2<RT>(trk + o3, anc + o3, w >> 3, h >> 3, bx, by, top);
+    search_top_b2<RT, 6>(top, bx, by, mvx, mvy, best);
     mvx *= 2; mvy *= 2;  // motion.cpp:458-460
     search_level<4, RT, false, 4>(trk + o2, anc + o2, w >> 2, h >> 2, bx, by, mvx, mvy, best);
   } else {
@@ -305,6 +304,187 @@ __global__ __launch_bounds__(256) SVC_HBMA_OCC void hbma_fused16_kernel(FusedArg
   a.mad[item] = (float)best * (1.0f / 256.0f);  // exact: best < 2^24, power-of-two scale
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled form for the 4-level search (the reference's default build, libs/motion.cpp:691-749).
+//
+// Why.  With R_top = 1 the per-lane form above issues two vector loads per tracked row for 12 QSADs, and the 4-level
+// search on fine texture returns an incoherent field (tools: a strip of 60 neighbouring blocks spans mv.y over +-8 at
+// C5 and C3b alike), so every lane of a wave instruction walks its own row: measured on gfx950 (tools/ubench_tcp.hip)
+// such an instruction holds the vector L1 for ~35 cycles whatever its width (x1, x2, x4 alike: ~0.55 cycles per lane
+// address), against 16 cycles per KiB for whole rows.  The vector L1, not HBM, then paces the kernel (84 % busy).
+//
+// What.  A workgroup owns a tile of TBX x TBY MV blocks.  Where a block's window can lie at level l is bounded without
+// knowing any vector: |mv_in| <= M_l = 2 (M_{l+1} + R_top), M_top = 0 (libs/motion.cpp:458-463), so the union of the
+// tile's windows at levels 2, 1 and 0 is three rectangles whose position depends on blockIdx alone.  All three are
+// brought into LDS as whole 16-byte chunks of whole rows by LDS-DMA (global_load_lds_dwordx4: no registers, one KiB
+// per wave instruction, every load of the workgroup in flight at once), the anchor rows of every level go to registers
+// (a wave's anchor row is one contiguous run), the 2x2 top level is searched from global memory while the tiles land,
+// then one barrier, then levels 2, 1, 0 read their windows from LDS at per-lane addresses: the vector L1 sees only
+// whole-row traffic.  Arithmetic, candidate order and tie rules are search_level's, so results are bit-identical.
+// One workgroup per CU (117 KB of LDS): occupancy is not what hides latency here, the depth of the DMA queue is.
+template <int B, int M, int RT, int TBX, int TBY>
+struct TileGeom {
+  static_assert(M + RT <= 16, "the tile starts 16 bytes left of its first anchor column");
+  static constexpr int ND = B / 4 + 2;                                       // dwords read per tracked row
+  static constexpr int X_LEFT = 16;                                          // bytes left of the first anchor column
+  static constexpr int Y_TOP = M + RT;                                       // rows above the first anchor row
+  static constexpr int A0_MAX = ((TBX - 1) * B + M - RT) & ~3;               // last dword-aligned window origin
+  static constexpr int W = (A0_MAX + 4 * ND + X_LEFT + 15) & ~15;            // bytes per tile row (= LDS pitch)
+  static constexpr int CPR = W / 16;                                         // 16-byte chunks per row
+  static constexpr int ROWS = Y_TOP + (TBY - 1) * B + (M - RT) + B + 2 * RT;
+  static constexpr int CHUNKS = CPR * ROWS;
+  // LDS bytes: whole workgroup-wide DMA rounds (NWAVES x 1 KiB each), so that the fill is branch-free
+  static constexpr int bytes(int nwaves) { return ((CHUNKS + 64 * nwaves - 1) / (64 * nwaves)) * 1024 * nwaves; }
+};
+
+// The tile of one level, global -> LDS.  Chunk i of the tile (row-major) is fetched by lane i % 64 of the wave
+// instruction that covers chunks [i & ~63, +64): LDS-DMA writes a wave's 64 x 16 bytes contiguously from the wave-uniform
+// base in M0.  Chunks that lie outside the plane are never read (a window is always inside it, make_window): their
+// source address is clamped into the plane.  Row widths are multiples of 16 at every level (the frame is a multiple of
+// 16 << (L-1)), so a chunk is either inside a row or outside.
+template <class G, int NWAVES>
+__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ plane, int fw, int fh, int x0, int y0,
+                                           uint8_t* lds_tile, uint32_t wave, uint32_t lane) {
+  // Straight-line on purpose (a tile's LDS is sized in whole rounds; lanes past the last chunk fetch it again): with
+  // no branch between the loads the compiler's vmcnt bookkeeping stays exact and the top-level search, whose loads
+  // were issued first, does not wait for the tiles.
+#pragma unroll
+  for (int base = 0; base < G::CHUNKS; base += 64 * NWAVES) {
+    const uint32_t wbase = (uint32_t)base + wave * 64u;
+    const uint32_t i = min(wbase + lane, (uint32_t)(G::CHUNKS - 1));
+    const uint32_t row = i / (uint32_t)G::CPR, c = i - row * (uint32_t)G::CPR;
+    const int gy = min(max(y0 + (int)row, 0), fh - 1);
+    const int gx = min(max(x0 + 16 * (int)c, 0), fw - 16);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(plane + ((uint32_t)gy * (uint32_t)fw + (uint32_t)gx)),
+        (__attribute__((address_space(3))) void*)(lds_tile + wbase * 16u), 16, 0, 0);
+  }
+}
+
+// search_level with the tracked window read from the level's LDS tile and the anchor block already in registers.
+template <int B, int RT, int SHIFT, class G>
+__device__ __forceinline__ void search_level_lds(const uint8_t* lds_tile, int x0, int y0, const uint32_t (&a)[B][B / 4],
+                                                 int fw, int fh, int bx, int by, int& mvx, int& mvy, uint32_t& best) {
+  constexpr int NW = B / 4, ND = NW + 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  const int ax = bx * B, ay = by * B;
+  const Window w = make_window<B, RT>(ax + mvx, ay + mvy, fw, fh);
+  const int a0 = w.wx & ~3;
+  const uint32_t sh = (uint32_t)(w.wx & 3);
+  const uint8_t* p = lds_tile + ((w.wy - y0) * G::W + (a0 - x0));
+
+  uint64_t acc4[NDY];
+  uint32_t acc1[NDY];
+#pragma unroll
+  for (int d = 0; d < NDY; ++d) { acc4[d] = 0; acc1[d] = 0; }
+  // one wave per SIMD: the whole window is requested before the first SAD so that the LDS latency is paid once
+  uint32_t m[NT][ND];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int k = 0; k < ND; ++k) m[t][k] = *reinterpret_cast<const uint32_t*>(p + (t * G::W + 4 * k));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    uint32_t v[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) v[k] = __builtin_amdgcn_alignbyte(m[t][k + 1], m[t][k], sh);
+#pragma unroll
+    for (int d = 0; d < NDY; ++d) {
+      const int r = t - d;
+      if (r >= 0 && r < B) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          const uint32_t av = a[r >= 0 && r < B ? r : 0][k];
+          acc4[d] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k], v[k + 1]), av, acc4[d]);
+          if (RT == 2) acc1[d] = __builtin_amdgcn_sad_u8(v[k + 1], av, acc1[d]);
+        }
+      }
+    }
+  }
+  select<RT, false, SHIFT>(
+      w, ax, ay,
+      [&](int d, int j) {
+        return j < 4 ? (uint32_t)(acc4[d] >> (16 * (j & 3))) & 0xFFFFu : acc1[d];
+      },
+      mvx, mvy, best);
+}
+
+template <int B>
+__device__ __forceinline__ void load_anchor_block(const uint8_t* __restrict__ anc, int fw, int bx, int by,
+                                                  uint32_t (&a)[B][B / 4]) {
+  const uint32_t ao = (uint32_t)(by * B * fw + bx * B);
+#pragma unroll
+  for (int t = 0; t < B; ++t) load_anchor_row<B / 4>(anc + (ao + (uint32_t)(t * fw)), a[t]);
+}
+
+template <int RT, int TBX, int TBY>
+__global__ __launch_bounds__(TBX* TBY) void hbma_tile16_kernel(FusedArgs a) {
+  constexpr int NWAVES = TBX * TBY / 64;
+  using G0 = TileGeom<16, 2 * (2 * (2 * RT + RT) + RT), RT, TBX, TBY>;  // M = 14 RT
+  using G1 = TileGeom<8, 2 * (2 * RT + RT), RT, TBX, TBY>;             // M = 6 RT
+  using G2 = TileGeom<4, 2 * RT, RT, TBX, TBY>;                        // M = 2 RT
+  __shared__ __attribute__((aligned(16))) uint8_t lds[G0::bytes(NWAVES) + G1::bytes(NWAVES) + G2::bytes(NWAVES)];
+  uint8_t* const t0 = lds;
+  uint8_t* const t1 = lds + G0::bytes(NWAVES);
+  uint8_t* const t2 = lds + G0::bytes(NWAVES) + G1::bytes(NWAVES);
+
+  // Region-major order as in hbma_fused16_kernel: XCD x is given the x-th eighth of the tiles of EVERY pair.
+  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+  const uint32_t pair = k / a.wgs_per_region;
+  const uint32_t tile = xcd * a.wgs_per_region + (k - pair * a.wgs_per_region);
+  const uint32_t tiles_x = (a.mfw + TBX - 1) / TBX, mfh = a.blocks / a.mfw;
+  const uint32_t tm = tile / tiles_x, tk = tile - tm * tiles_x;
+  if (pair >= a.n_pairs || tm * TBY >= mfh) return;  // uniform over the workgroup
+
+  const uint32_t tid = threadIdx.x, wave = tid / 64u, lane = tid & 63u;
+  const uint32_t lx = tid % TBX, ly = tid / TBX;
+  const uint32_t bxu = tk * TBX + lx, byu = tm * TBY + ly;
+  const bool live = bxu < a.mfw && byu < mfh;
+  // a lane beyond the frame searches the last block of its row / column again (in-tile addresses) and stores nothing
+  const int bx = (int)min(bxu, a.mfw - 1), by = (int)min(byu, mfh - 1);
+
+  const uint8_t* trk = a.tracked + (size_t)pair * a.pair_stride;
+  const uint8_t* anc = a.anchor + (size_t)pair * a.pair_stride;
+  const int w = (int)a.w, h = (int)a.h;
+  const size_t o1 = (size_t)w * h, o2 = o1 + (o1 >> 2), o3 = o2 + (o1 >> 4);
+
+  // the top level's 2x2 blocks and windows, then the anchor blocks of every level: registers (a wave's anchor row is
+  // one contiguous run).  The top level is loaded first, so that its search waits for nothing issued behind it.
+  TopB2<RT> top;
+  load_top_b2<RT>(trk + o3, anc + o3, w >> 3, h >> 3, bx, by, top);
+  uint32_t a0r[16][4], a1r[8][2], a2r[4][1];
+  load_anchor_block<4>(anc + o2, w >> 2, bx, by, a2r);
+  load_anchor_block<8>(anc + o1, w >> 1, bx, by, a1r);
+  load_anchor_block<16>(anc, w, bx, by, a0r);
+
+  // tracked tiles, coarse to fine: completion order is issue order
+  const int tx = (int)(tk * TBX), ty = (int)(tm * TBY);
+  const int x2 = tx * 4 - G2::X_LEFT, y2 = ty * 4 - G2::Y_TOP;
+  const int x1 = tx * 8 - G1::X_LEFT, y1 = ty * 8 - G1::Y_TOP;
+  const int x0 = tx * 16 - G0::X_LEFT, y0 = ty * 16 - G0::Y_TOP;
+  stage_tile<G2, NWAVES>(trk + o2, w >> 2, h >> 2, x2, y2, t2, wave, lane);
+  stage_tile<G1, NWAVES>(trk + o1, w >> 1, h >> 1, x1, y1, t1, wave, lane);
+  stage_tile<G0, NWAVES>(trk, w, h, x0, y0, t0, wave, lane);
+
+  int mvx = 0, mvy = 0;
+  uint32_t best = 0;
+  search_top_b2<RT, 6>(top, bx, by, mvx, mvy, best);
+
+  __syncthreads();  // every wave's DMA has landed (the compiler drains vmcnt in front of the barrier)
+
+  mvx *= 2; mvy *= 2;  // motion.cpp:458-460
+  search_level_lds<4, RT, 4, G2>(t2, x2, y2, a2r, w >> 2, h >> 2, bx, by, mvx, mvy, best);
+  mvx *= 2; mvy *= 2;
+  search_level_lds<8, RT, 2, G1>(t1, x1, y1, a1r, w >> 1, h >> 1, bx, by, mvx, mvy, best);
+  mvx *= 2; mvy *= 2;
+  search_level_lds<16, RT, 0, G0>(t0, x0, y0, a0r, w, h, bx, by, mvx, mvy, best);
+
+  if (live) {
+    const uint32_t item = pair * a.blocks + byu * a.mfw + bxu;
+    reinterpret_cast<float2*>(a.mv)[item] = make_float2((float)mvx, (float)mvy);
+    a.mad[item] = (float)best * (1.0f / 256.0f);
+  }
+}
+
 bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw,
                      uint32_t bh) {
   if (bw != 16 || bh != 16 || (levels != 3 && levels != 4)) return false;
@@ -317,9 +497,28 @@ bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, ui
   return tw >= tb + 8 && tw >= 12 && tw % 4 == 0 && th >= tb + 2 * rt && (w % 16 == 0) && (h % 16 == 0);
 }
 
+// The LDS-tiled kernel serves the 4-level search with R_top = 1 on planes whose rows are whole 16-byte chunks at the
+// three levels it stages (so the frame width is a multiple of 64; any height).
+bool tile_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh) {
+  return fused_supported(levels, w, h, range, bw, bh) && levels == 4 && (range >> 3) == 1 && w % 64 == 0;
+}
+
+constexpr int kTileBX = 32, kTileBY = 8;
+
+static int launch_hbma_tile(FusedArgs a, uint32_t n_pairs, hipStream_t stream) {
+  const uint32_t mfh = a.blocks / a.mfw;
+  const uint32_t tiles = div_up(a.mfw, kTileBX) * div_up(mfh, kTileBY);
+  a.wgs_per_region = div_up(tiles, 8);
+  const uint64_t wgs = (uint64_t)8 * a.wgs_per_region * n_pairs;
+  if (wgs > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu workgroups exceed one launch", (unsigned long long)wgs);
+  hipLaunchKernelGGL((hbma_tile16_kernel<1, kTileBX, kTileBY>), dim3((uint32_t)wgs), dim3(kTileBX * kTileBY), 0, stream, a);
+  return check_launch("hbma_tile16_kernel");
+}
+
+// kernel: 0 = the shape's default, 1 = lane-per-block (no LDS), 2 = LDS-tiled (UNSUPPORTED where tile_supported is false)
 int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
                       uint32_t n_pairs, uint32_t levels, uint32_t w, uint32_t h, uint32_t range,
-                      float* d_mv, float* d_mad, hipStream_t stream) {
+                      float* d_mv, float* d_mad, int kernel, hipStream_t stream) {
   FusedArgs a;
   a.tracked = d_tracked;
   a.anchor = d_anchor;
@@ -334,23 +533,21 @@ int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_
   a.mv = d_mv;
   a.mad = d_mad;
   a.n_pairs = n_pairs;
-  const char* order = std::getenv("SVC_HBMA_ORDER");  // A/B switch: "pair" = the round-1 pair-major order
-  a.wgs_per_region = (order && order[0] == 'p') ? 0u : div_up(div_up(a.blocks, 256), 8);
-  const uint64_t wgs = a.wgs_per_region ? (uint64_t)8 * a.wgs_per_region * n_pairs : div_up(a.n_items, 256);
+  const bool can_tile = tile_supported(levels, w, h, range, 16, 16) && ((uintptr_t)d_tracked % 16 == 0) && ((uintptr_t)d_anchor % 16 == 0) &&
+                        pair_stride % 16 == 0;
+  if (kernel == 2 && !can_tile)
+    return fail(SVC_ERR_UNSUPPORTED, "hbma: the LDS-tiled kernel needs 4 levels, r_top 1, a frame width that is a multiple of 64 and 16-byte aligned pyramids");
+  if (kernel == 2 || (kernel == 0 && can_tile)) return launch_hbma_tile(a, n_pairs, stream);
+  a.wgs_per_region = div_up(div_up(a.blocks, 256), 8);
+  const uint64_t wgs = (uint64_t)8 * a.wgs_per_region * n_pairs;
   if (wgs > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu workgroups exceed one launch", (unsigned long long)wgs);
   const dim3 grid((uint32_t)wgs), block(256);
   const uint32_t rt = range >> (levels - 1);
-#define SVC_FUSED_LAUNCH(LV, R)                                                                        \
-  do {                                                                                                 \
-    if (a.wgs_per_region) hipLaunchKernelGGL((hbma_fused16_kernel<LV, R, true>), grid, block, 0, stream, a); \
-    else hipLaunchKernelGGL((hbma_fused16_kernel<LV, R, false>), grid, block, 0, stream, a);           \
-  } while (0)
-  if (levels == 3 && rt == 2) SVC_FUSED_LAUNCH(3, 2);
-  else if (levels == 3 && rt == 1) SVC_FUSED_LAUNCH(3, 1);
-  else if (levels == 4 && rt == 1) SVC_FUSED_LAUNCH(4, 1);
-  else if (levels == 4 && rt == 2) SVC_FUSED_LAUNCH(4, 2);
+  if (levels == 3 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<3, 2>), grid, block, 0, stream, a);
+  else if (levels == 3 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<3, 1>), grid, block, 0, stream, a);
+  else if (levels == 4 && rt == 1) hipLaunchKernelGGL((hbma_fused16_kernel<4, 1>), grid, block, 0, stream, a);
+  else if (levels == 4 && rt == 2) hipLaunchKernelGGL((hbma_fused16_kernel<4, 2>), grid, block, 0, stream, a);
   else return fail(SVC_ERR_UNSUPPORTED, "hbma fused: levels=%u r_top=%u not instantiated", levels, rt);
-#undef SVC_FUSED_LAUNCH
   return check_launch("hbma_fused16_kernel");
 }
 

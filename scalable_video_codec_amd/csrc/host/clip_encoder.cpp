@@ -6,7 +6,6 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -170,7 +169,7 @@ struct ClipEncoder::Impl {
     const uint64_t t0 = sh.needs_halo ? 0 : 1;  // slot of the first tracked pyramid
     Run(Stage::kHbma, st, timing, [&] {
       Abi(svc_hip_hbma_pairs(pyr[b].p + t0 * pyr_stride, pyr[b].p + (t0 + 1) * pyr_stride, pyr_stride, sh.pairs, c.levels, pw, ph,
-                             c.search_range, c.mv_block, c.mv_block, mv[q].p, mad[q].p, SVC_HBMA_AUTO, st), "svc_hip_hbma_pairs");
+                             c.search_range, c.mv_block, c.mv_block, mv[q].p, mad[q].p, c.hbma_flags, st), "svc_hip_hbma_pairs");
     });
   }
 
@@ -327,12 +326,11 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   if ((c.dct_block_w == 0) != (c.dct_block_h == 0))
     throw std::runtime_error("svc::ClipEncoder: transform block needs both sides");
   m.sh = PlanShard(c.clip_frames, c.world, c.rank);
-  {
-    const char* e = std::getenv("SVC_LAUNCH_BESIDE");  // A/B switch: "0" keeps the stand-alone shapes
-    m.lat_flags = (c.schedule == Schedule::kPipelined && !(e && e[0] == '0')) ? SVC_LAUNCH_BESIDE : 0u;
-    const char* f = std::getenv("SVC_LAUNCH_NO_FORK");  // A/B switch: "0" lets the segmentation fork its side stream
-    if (c.schedule == Schedule::kPipelined && !(f && f[0] == '0')) m.lat_flags |= SVC_LAUNCH_NO_FORK;
+  if (c.schedule == Schedule::kPipelined) {
+    if (!c.standalone_shapes) m.lat_flags |= SVC_LAUNCH_BESIDE;
+    if (!c.segment_fork) m.lat_flags |= SVC_LAUNCH_NO_FORK;
   }
+  if (c.lat_depth > (uint32_t)Impl::kMaxDepth) throw std::runtime_error("svc::ClipEncoder: lat_depth must be 0..3");
   m.fork_early = c.world > 1 || (uint64_t)m.sh.pairs * ((uint64_t)((c.width + c.mv_block - 1) / c.mv_block) * ((c.height + c.mv_block - 1) / c.mv_block)) < 1600000ull;
   const uint32_t f = 1u << (c.levels - 1);
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
@@ -357,13 +355,10 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   // drains (profiles/r02_timeline_C5.txt), so its chain of four launches spans more than one iteration.  Two is never
   // worse and is what the tiny and the 4K shards need (ms per step at depth 1 / 2 / 3, profiles/r02_ab_lat_depth.txt:
   // C5 2.83 / 2.44 / 2.70, C5 8-frame shard 1.07 / 0.65 / 0.81, C3 2.57 / 2.56 / 2.56, C3 38 frames 0.371 / 0.370 /
-  // 0.373, C3 19 frames 0.236 / 0.208 / 0.207).  SVC_LAT_DEPTH overrides (A/B runs).
+  // 0.373, C3 19 frames 0.236 / 0.208 / 0.207).  ClipEncoderConfig::lat_depth overrides (A/B runs).
   const bool pipelined = c.schedule == Schedule::kPipelined;
   m.depth = 1;
-  if (pipelined && !c.graph) {
-    m.depth = 2;
-    if (const char* e = std::getenv("SVC_LAT_DEPTH")) m.depth = std::min(std::max(std::atoi(e), 1), (int)Impl::kMaxDepth);
-  }
+  if (pipelined && !c.graph) m.depth = c.lat_depth ? (int)c.lat_depth : 2;
   m.nsets = !pipelined ? 1 : c.graph ? 4 : m.depth + 2;  // hipGraph replay: the set must also fix the pyramid parity
   Hip(hipStreamCreateWithFlags(&m.sM, hipStreamNonBlocking), "hipStreamCreate");
   Hip(hipStreamCreateWithFlags(&m.sC, hipStreamNonBlocking), "hipStreamCreate");
@@ -493,6 +488,7 @@ void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
 }  // namespace svc
 
 // ---- C handle API (include/svc_clip.h) ---------------------------------------------------------
+static_assert(sizeof(svc_clip_config) == 136 && sizeof(svc_clip_info) == 72, "the ctypes binding (clip.py) mirrors this layout");
 struct svc_clip {
   std::unique_ptr<svc::ClipEncoder> enc;
   svc::ClipEncoderConfig cfg;
@@ -542,6 +538,9 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.rank = k->rank; c.world = k->world;
     c.schedule = k->schedule == SVC_CLIP_SERIAL ? svc::Schedule::kSerial : svc::Schedule::kPipelined;
     c.graph = k->graph != 0;
+    c.hbma_flags = k->hbma_flags; c.lat_depth = k->lat_depth;
+    c.standalone_shapes = (k->tuning & SVC_CLIP_TUNE_STANDALONE_SHAPES) != 0;
+    c.segment_fork = (k->tuning & SVC_CLIP_TUNE_SEGMENT_FORK) != 0;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
     h->enc.reset(new svc::ClipEncoder(c));

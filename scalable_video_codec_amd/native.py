@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(PKG, "libsvc_hip.so")
 MOTION_LIB_PATH = os.path.join(PKG, "libsvc_motion.so")
 
 SVC_OK, SVC_ERR_INVALID_ARG, SVC_ERR_UNSUPPORTED, SVC_ERR_HIP, SVC_ERR_NO_DEVICE = range(5)
-HBMA_AUTO, HBMA_FORCE_WAVE_PER_BLOCK, HBMA_FORCE_FUSED = 0, 1, 2
+HBMA_AUTO, HBMA_FORCE_WAVE_PER_BLOCK, HBMA_FORCE_FUSED, HBMA_FORCE_TILED, HBMA_FORCE_LANE = 0, 1, 2, 4, 8
 
 
 class SvcError(RuntimeError):

@@ -121,20 +121,45 @@ def test_hbma_pairs_batched_clip(native, oracle, levels):
         _assert_same(mvw[p].cpu().numpy(), madw[p].cpu().numpy(), exp_mv, exp_mad, f"wave pair {p}")
 
 
-@pytest.mark.parametrize("levels,search", [(3, 8), (3, 4), (4, 8), (4, 16)])
-def test_hbma_fused_pair_major_instantiation(native, levels, search, monkeypatch):
-    """SVC_HBMA_ORDER=pair (the A/B switch of tools/ab_hbma_order.sh) launches a separate instantiation of the fused kernel
-    -- workgroups may straddle pairs, per-lane plane bases -- that the default order never runs: same results, including a
-    block count that is not a multiple of 256 and pairs that end inside a workgroup."""
-    n = 4
-    _, pyrs, (pw, ph) = util.clip_frames(352, 208, n, 0x5EED + levels, levels)
+@pytest.mark.parametrize("w,h,n", [(512, 128, 3), (640, 400, 3), (1024, 256, 2), (128, 128, 2), (1152, 640, 2), (192, 144, 2), (576, 1088, 2)])
+@pytest.mark.parametrize("kind", ["clip", "noise"])
+def test_hbma_tiled_kernel(native, oracle, w, h, n, kind):
+    """The LDS-tiled form of the 4-level search (SVC_HBMA_FORCE_TILED; the default kernel for 4 levels, R_top = 1 on frames
+    whose width is a multiple of 64): frames of one tile, of partial tiles in both directions (640 = 1.25 tiles of 32
+    blocks, 400 / 16 = 25 block rows = 3.1 tiles of 8), of several tiles, and smaller than a tile; coherent clips and uncorrelated
+    noise (every window clamp, vectors up to the +-15 the tile margins are sized for).  Against the oracle, the
+    lane-per-block kernel and the per-level kernel, libs/motion.cpp:691-749."""
+    levels, r = 4, 8
+    if kind == "clip":
+        _, pyrs, (pw, ph) = util.clip_frames(w, h, n, 0x711E + w, levels)
+        pyrs = [util.np_pyr(p) for p in pyrs]
+    else:
+        rng = np.random.default_rng(w * 7 + h)
+        pw, ph = w, h
+        pyrs = [util.random_planes(rng, w, h, levels) for _ in range(n)]
+    assert (pw, ph) == (w, h)
     stride = native.pyramid_stride(pw, ph, levels)
     buf = util.pack_clip(pyrs, stride, "cuda")
-    mv, mad = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, search)
-    monkeypatch.setenv("SVC_HBMA_ORDER", "pair")
-    mvp, madp = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, search)
+    out = {}
+    for name, f in (("tiled", native.HBMA_FORCE_TILED), ("lane", native.HBMA_FORCE_LANE), ("auto", native.HBMA_AUTO),
+                    ("wave", native.HBMA_FORCE_WAVE_PER_BLOCK)):
+        out[name] = native.hbma_pairs(buf, buf[stride:], stride, n - 1, levels, pw, ph, r, flags=f)
     torch.cuda.synchronize()
-    assert torch.equal(mv, mvp) and torch.equal(mad, madp)
+    for p in range(n - 1):
+        exp_mv, exp_mad = oracle.hbma(pyrs[p], pyrs[p + 1], r, 16, 16)
+        for name, (mv, mad) in out.items():
+            _assert_same(mv[p].cpu().numpy(), mad[p].cpu().numpy(), exp_mv, exp_mad, f"{name} {w}x{h} {kind} pair {p}")
+
+
+def test_hbma_tiled_kernel_says_unsupported(native):
+    """Shapes the tiled form does not cover are UNSUPPORTED when it is forced (3 levels; a frame width that is not a multiple
+    of 64; R_top = 2), and run through the lane-per-block form otherwise."""
+    for levels, w, h, r in ((3, 256, 128, 8), (4, 352, 256, 8), (4, 256, 128, 16)):
+        t = util.random_planes(np.random.default_rng(1), w, h, levels)
+        with pytest.raises(native.SvcError) as e:
+            native.hbma_host(t, t, r, 16, 16, flags=native.HBMA_FORCE_TILED)
+        assert e.value.status == native.SVC_ERR_UNSUPPORTED
+        native.hbma_host(t, t, r, 16, 16, flags=native.HBMA_FORCE_LANE)
 
 
 def test_invalid_args(native):
