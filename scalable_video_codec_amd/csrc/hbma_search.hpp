@@ -1,0 +1,263 @@
+// hbma_search.hpp -- device code shared by the all-level motion search kernels (hbma_fused.hip: lane per block;
+// hbma_tiled.hip: LDS-tiled): the SAD engine, the reference's window clamps and the candidate selection rules.
+//
+// SAD engine.  v_qsad_pk_u16_u8 returns, for one 4-byte anchor word, the four SADs
+// against the tracked bytes at offsets 0..3 of an 8-byte window, accumulated as
+// 4 x u16 (a 16x16 block's SAD <= 65280 fits).  Measured on gfx950 (tools/
+// ubench_valu.hip): QSAD issues in 16 cycles per wave, v_sad_u8 / v_alignbyte_b32 /
+// v_min3 in 4, i.e. 4 cycles per 4-byte SAD either way: each tracked row is
+// funnel-shifted ONCE to the window origin (shared by every vertical offset), then one
+// QSAD covers dx = 0..3 and one v_sad_u8 the fifth column.  Candidates outside the
+// reference's clamped window (libs/motion.cpp:375-385) are masked at selection time.
+//
+// Arithmetic.  All block areas are powers of two, so MAD = sad / area is an exact
+// dyadic rational; the MAD carried across levels (libs/motion.cpp:401 compares a
+// level-l MAD with the level-(l+1) minimum) is kept as the integer sad << 2l
+// (units of 1/256) and converted once at the end: bit-identical to the float path.
+#pragma once
+
+#include "svc_common.hpp"
+
+namespace svc {
+
+// what the lane-per-block kernel covers (hbma_fused.hip) / the LDS-tiled one (hbma_tiled.hip)
+bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
+bool tiled_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
+// SVC_HBMA_AUTO takes the LDS-tiled kernel wherever it applies (measured: profiles/r03_ab_hbma_tiled.txt)
+constexpr bool kTiledIsDefault = true;
+
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct FusedArgs {
+  const uint8_t* tracked;
+  const uint8_t* anchor;
+  uint64_t pair_stride;
+  uint32_t n_items;  // pairs * blocks
+  uint32_t n_pairs;
+  uint32_t wgs_per_region;  // workgroups of one frame pair per XCD region (see the kernels)
+  uint32_t blocks;
+  uint32_t mfw;
+  uint32_t w, h;     // base-level frame size
+  float* mv;
+  float* mad;
+};
+
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) {
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Loads N consecutive dwords of a tracked row.  CLAMP (top level only, the last
+// plane of a packed pyramid): every dword's column is clamped into the row, so
+// nothing past the pyramid is ever touched; a clamped dword only feeds masked
+// candidates.
+// Addresses are `plane + 32-bit offset`: the plane pointer is uniform over the wavefront in the region-major kernel (the
+// pair comes from blockIdx alone), so the loads take the scalar-base + 32-bit-VGPR-offset form and no 64-bit address is
+// ever built in vector registers.
+template <int N, bool CLAMP>
+__device__ __forceinline__ void load_row(const uint8_t* plane, uint32_t row_off, int a0, int fw, uint32_t (&m)[N]) {
+  if (CLAMP) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      m[k] = *reinterpret_cast<const uint32_t*>(plane + (row_off + (uint32_t)min(a0 + 4 * k, fw - 4)));
+  } else {
+    const uint8_t* p = plane + (row_off + (uint32_t)a0);
+    if (N == 6) {
+      u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+      u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(p + 16);
+      m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w; m[4] = u.x; m[5] = u.y;
+    } else if (N == 4) {
+      u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+      m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) m[k] = *reinterpret_cast<const uint32_t*>(p + 4 * k);
+    }
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void load_anchor_row(const uint8_t* p, uint32_t (&a)[NW]) {
+  if (NW == 4) {
+    u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+  } else if (NW == 2) {
+    u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(p);
+    a[0] = v.x; a[1] = v.y;
+  } else {
+    a[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+}
+
+struct Window {
+  int wx, wy;              // origin of the (2RT+1) x (2RT+1) candidate grid (always in the plane)
+  int jlo, jhi, dlo, dhi;  // the reference's clamped window inside that grid
+};
+
+template <int B, int RT>
+__device__ __forceinline__ Window make_window(int cx, int cy, int fw, int fh) {
+  Window w;
+  const int x0 = max(0, cx - RT), x1 = min(fw - B + 1, cx + RT + 1);  // motion.cpp:381-385
+  const int y0 = max(0, cy - RT), y1 = min(fh - B + 1, cy + RT + 1);  // :375-379
+  w.wx = min(max(cx - RT, 0), fw - (B + 2 * RT));
+  w.wy = min(max(cy - RT, 0), fh - (B + 2 * RT));
+  w.jlo = x0 - w.wx; w.jhi = x1 - w.wx;
+  w.dlo = y0 - w.wy; w.dhi = y1 - w.wy;
+  return w;
+}
+
+// Picks the winner of the (2RT+1)^2 grid of SADs in the reference's raster order with one
+// unsigned min over packed keys  (scaled_sad << 5) | code :
+//   refinement (motion.cpp:401, strict `<` against the carried minimum): code = raster
+//     index, so equal SADs resolve to the FIRST candidate; the winner replaces the carried
+//     value only if its scaled SAD is strictly smaller;
+//   top level (motion.cpp:324-337, `<=`): code = 31 - index, so equal SADs resolve to the
+//     LAST candidate; and if the valid SADs are non-increasing in raster order every
+//     candidate "updated" and the MV is zeroed (the minimum is kept).
+// Candidates outside the reference's clamped window get the all-ones key.
+template <int RT, bool TOP, int SHIFT, typename GetSad>
+__device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad sad_at, int& mvx,
+                                       int& mvy, uint32_t& best) {
+  constexpr int N = 2 * RT + 1;
+  static_assert(N * N <= 32, "raster index must fit the 5-bit code");
+  uint32_t kmin = 0xFFFFFFFFu;
+  uint32_t prev = 0xFFFFFFFFu;  // FLT_MAX of motion.cpp:290
+  bool mono = true;
+#pragma unroll
+  for (int d = 0; d < N; ++d) {
+    const bool row_ok = d >= w.dlo && d < w.dhi;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const bool valid = row_ok && j >= w.jlo && j < w.jhi;
+      const uint32_t s = sad_at(d, j);
+      const int idx = d * N + j;
+      const uint32_t key = (s << (SHIFT + 5)) | (uint32_t)(TOP ? 31 - idx : idx);
+      kmin = min(kmin, valid ? key : 0xFFFFFFFFu);
+      if (TOP) {
+        mono = mono && (!valid || s <= prev);
+        prev = valid ? s : prev;
+      }
+    }
+  }
+  const uint32_t smin = kmin >> 5;  // scaled SAD of the winner
+  const int idx = TOP ? 31 - (int)(kmin & 31u) : (int)(kmin & 31u);
+  const int bd = idx / N, bj = idx - bd * N;
+  if (TOP) {
+    best = smin;
+    mvx = mono ? 0 : w.wx + bj - ax;
+    mvy = mono ? 0 : w.wy + bd - ay;
+  } else if (smin < best) {
+    best = smin;
+    mvx = w.wx + bj - ax;
+    mvy = w.wy + bd - ay;
+  }
+}
+
+// One level with block size B >= 4.  Per tracked row: NW + 2 aligned dwords are loaded
+// and funnel-shifted once (v_alignbyte_b32) so that word k starts at window byte 4k; then
+// for every anchor row that meets it, per anchor word: one v_qsad_pk_u16_u8 (candidates
+// dx = 0..3) and, for RT = 2, one v_sad_u8 (dx = 4).
+template <int B, int RT, bool TOP, int SHIFT>
+__device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
+                                             const uint8_t* __restrict__ anc, int fw, int fh,
+                                             int bx, int by, int& mvx, int& mvy, uint32_t& best) {
+  constexpr int NW = B / 4, ND = NW + 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  const int ax = bx * B, ay = by * B;
+  const Window w = make_window<B, RT>(ax + mvx, ay + mvy, fw, fh);
+  const int a0 = w.wx & ~3;
+  const uint32_t sh = (uint32_t)(w.wx & 3);
+
+  uint64_t acc4[NDY];
+  uint32_t acc1[NDY];
+#pragma unroll
+  for (int d = 0; d < NDY; ++d) { acc4[d] = 0; acc1[d] = 0; }
+  uint32_t a[B][NW];
+  const uint32_t to = (uint32_t)(w.wy * fw), ao = (uint32_t)(ay * fw + ax);  // a plane is far below 2^32 bytes
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    uint32_t m[ND], v[NW + 1];
+    load_row<ND, TOP>(trk, to + (uint32_t)(t * fw), a0, fw, m);
+    if (t < B) load_anchor_row<NW>(anc + (ao + (uint32_t)(t * fw)), a[t < B ? t : 0]);
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
+#pragma unroll
+    for (int d = 0; d < NDY; ++d) {
+      const int r = t - d;  // anchor row that meets tracked row t at vertical offset d
+      if (r >= 0 && r < B) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          const uint32_t av = a[r >= 0 && r < B ? r : 0][k];
+          acc4[d] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k], v[k + 1]), av, acc4[d]);
+          if (RT == 2) acc1[d] = __builtin_amdgcn_sad_u8(v[k + 1], av, acc1[d]);
+        }
+      }
+    }
+  }
+  select<RT, TOP, SHIFT>(
+      w, ax, ay,
+      [&](int d, int j) {
+        return j < 4 ? (uint32_t)(acc4[d] >> (16 * (j & 3))) & 0xFFFFu : acc1[d];
+      },
+      mvx, mvy, best);
+}
+
+// Top level of a 4-level pyramid: 2x2 blocks (reference motion.cpp:719-720).  Two
+// bytes per anchor row do not fill a QSAD word, so this level uses v_sad_u8 on
+// 16-bit slices; it is 1/64 of the pixels of level 0.  Loading and searching are
+// separate steps so that a caller can put other loads between them.
+template <int RT>
+struct TopB2 {
+  static constexpr int NT = 2 + 2 * RT;
+  Window w;
+  uint32_t m[NT][3];
+  uint32_t a[2];
+};
+
+template <int RT>
+__device__ __forceinline__ void load_top_b2(const uint8_t* __restrict__ trk, const uint8_t* __restrict__ anc, int fw,
+                                            int fh, int bx, int by, TopB2<RT>& s) {
+  constexpr int B = 2, NT = TopB2<RT>::NT;
+  const int ax = bx * B, ay = by * B;
+  s.w = make_window<B, RT>(ax, ay, fw, fh);
+  const int a0 = s.w.wx & ~3;
+#pragma unroll
+  for (int r = 0; r < B; ++r)
+    s.a[r] = *reinterpret_cast<const uint16_t*>(anc + (uint32_t)((ay + r) * fw + ax));
+  const uint32_t to = (uint32_t)(s.w.wy * fw);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) load_row<3, true>(trk, to + (uint32_t)(t * fw), a0, fw, s.m[t]);
+}
+
+template <int RT, int SHIFT>
+__device__ __forceinline__ void search_top_b2(const TopB2<RT>& s, int bx, int by, int& mvx, int& mvy, uint32_t& best) {
+  constexpr int B = 2, NDY = 2 * RT + 1, NT = TopB2<RT>::NT;
+  const uint32_t sh = (uint32_t)(s.w.wx & 3);
+  uint32_t sad[NDY][NDY];
+#pragma unroll
+  for (int d = 0; d < NDY; ++d)
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) sad[d][j] = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    // window bytes 0 .. 2RT+1 (<= 6) as two dwords starting at the window origin
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(s.m[t][1], s.m[t][0], sh);
+    const uint32_t v1 = __builtin_amdgcn_alignbyte(s.m[t][2], s.m[t][1], sh);
+    uint32_t tj[NDY];
+#pragma unroll
+    for (int j = 0; j < NDY; ++j)
+      tj[j] = (j < 4 ? __builtin_amdgcn_alignbyte(v1, v0, j) : v1 >> (8 * (j - 4))) & 0xFFFFu;
+#pragma unroll
+    for (int d = 0; d < NDY; ++d) {
+      const int r = t - d;
+      if (r >= 0 && r < B) {
+#pragma unroll
+        for (int j = 0; j < NDY; ++j)
+          sad[d][j] = __builtin_amdgcn_sad_u8(tj[j], s.a[r >= 0 && r < B ? r : 0], sad[d][j]);
+      }
+    }
+  }
+  select<RT, true, SHIFT>(s.w, bx * B, by * B, [&](int d, int j) { return sad[d][j]; }, mvx, mvy, best);
+}
+
+}  // namespace svc
