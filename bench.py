@@ -326,8 +326,8 @@ def main() -> None:
     # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The
     # environment variables of the round-2 scripts under tools/ are honoured HERE as defaults, not inside the library.
     ap.add_argument("--hbma-kernel", choices=("auto", "tiled", "lane", "wave"), default=os.environ.get("SVC_HBMA_KERNEL", "auto"),
-                    help="motion search kernel: auto (LDS-tiled for 4 levels / r_top 1, lane-per-block for the other fused shapes), "
-                         "tiled, lane (lane-per-block, no LDS), wave (per-level general kernel)")
+                    help="motion search kernel: auto (lane-per-block for the fused shapes, else the per-level kernel), tiled (4 levels / r_top 1: "
+                         "levels 2 and 1 from LDS tiles), lane (lane-per-block, no LDS), wave (per-level general kernel)")
     ap.add_argument("--lat-depth", type=int, default=int(os.environ.get("SVC_LAT_DEPTH", "0")),
                     help="pipelined: iterations RANSAC + segmentation get to finish (1..3; 0 = default 2)")
     ap.add_argument("--standalone-shapes", action="store_true", default=os.environ.get("SVC_LAUNCH_BESIDE", "1") == "0",
@@ -458,9 +458,9 @@ def main() -> None:
             hbma_ms = kt["hbma"] / nl["hbma"]
             hbma_gbps = hbma_bytes / (hbma_ms * 1e-3) / 1e9
             fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2) and args.hbma_kernel != "wave"
-            tiled = fused and cfg.levels == 4 and cfg.r_top == 1 and pw % 64 == 0 and args.hbma_kernel in ("auto", "tiled")
+            tiled = fused and cfg.levels == 4 and cfg.r_top == 1 and pw % 64 == 0 and args.hbma_kernel == "tiled"
             out["roofline"] = {
-                "kernel": "hbma_tile16_kernel (MAD search, all pyramid levels, windows staged in LDS)" if tiled else
+                "kernel": "hbma_tiled16_kernel (MAD search, all pyramid levels, windows of levels 2 and 1 staged in LDS)" if tiled else
                           "hbma_fused16_kernel (MAD search, all pyramid levels, lane per block)" if fused else
                           "hbma_wave_level_kernel (LDS-staged wave-per-block search)",
                 "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

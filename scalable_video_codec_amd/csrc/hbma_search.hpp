@@ -23,8 +23,9 @@ namespace svc {
 // what the lane-per-block kernel covers (hbma_fused.hip) / the LDS-tiled one (hbma_tiled.hip)
 bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
 bool tiled_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
-// SVC_HBMA_AUTO takes the LDS-tiled kernel wherever it applies (measured: profiles/r03_ab_hbma_tiled.txt)
-constexpr bool kTiledIsDefault = true;
+// SVC_HBMA_AUTO keeps the lane-per-block kernel for every fused shape: the LDS-tiled kernel measures level with it
+// (C5 0.279 vs 0.281 ms, C3b 0.328 vs 0.323: profiles/r03_ab_hbma_tiled.txt) and is there on request (SVC_HBMA_FORCE_TILED)
+constexpr bool kTiledIsDefault = false;
 
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));

@@ -124,10 +124,10 @@ def test_hbma_pairs_batched_clip(native, oracle, levels):
 @pytest.mark.parametrize("w,h,n", [(512, 128, 3), (640, 400, 3), (1024, 256, 2), (128, 128, 2), (1152, 640, 2), (192, 144, 2), (576, 1088, 2)])
 @pytest.mark.parametrize("kind", ["clip", "noise"])
 def test_hbma_tiled_kernel(native, oracle, w, h, n, kind):
-    """The LDS-tiled form of the 4-level search (SVC_HBMA_FORCE_TILED; the default kernel for 4 levels, R_top = 1 on frames
-    whose width is a multiple of 64): frames of one tile, of partial tiles in both directions (640 = 1.25 tiles of 32
+    """The LDS-tiled form of the 4-level search (SVC_HBMA_FORCE_TILED: levels 2 and 1 from LDS tiles, 4 levels, R_top = 1,
+    frame width a multiple of 64): frames of one tile, of partial tiles in both directions (640 = 1.25 tiles of 32
     blocks, 400 / 16 = 25 block rows = 3.1 tiles of 8), of several tiles, and smaller than a tile; coherent clips and uncorrelated
-    noise (every window clamp, vectors up to the +-15 the tile margins are sized for).  Against the oracle, the
+    noise (every window clamp, vectors up to the +-6 / +-2 the tile margins are sized for).  Against the oracle, the
     lane-per-block kernel and the per-level kernel, libs/motion.cpp:691-749."""
     levels, r = 4, 8
     if kind == "clip":
