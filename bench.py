@@ -208,6 +208,8 @@ def _torch_halo_transport(rank: int, world: int, staged: bool):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()  # nccl: orders the stream behind the transfer, does not block the host
             if staged and rank > 0:
+                if os.environ.get("SVC_BENCH_CORRUPT_HALO") == "1":  # test hook (gloo rehearsal only): the self-check must catch it
+                    recv_h[12345] ^= 0x40
                 recv.copy_(recv_h)
                 stream.synchronize()
     return fn
@@ -239,6 +241,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
         if (rank == 0 and mode == "strong" and world == 1 and not args.no_cpu_baseline) else None
     del src
     halo = None
+    halo_check = None
     if world > 1:
         if comm is not None:
             enc.set_comm(comm)
@@ -265,8 +268,18 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
                             device=dev if backend == "nccl" else "cpu")
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        if rank > 0 and _checksum(pyr[:stride]) != int(every[rank - 1].item()):
-            raise SystemExit(f"rank {rank}: the halo received is not rank {rank - 1}'s last pyramid")
+        got = _checksum(pyr[:stride]) if rank > 0 else 0
+        bad = torch.tensor([1 if (rank > 0 and got != int(every[rank - 1].item())) else 0], dtype=torch.int64, device=mine.device)
+        verdicts = [torch.zeros_like(bad) for _ in range(world)]
+        dist.all_gather(verdicts, bad)  # collective: every rank learns every rank's verdict and they leave together
+        failed = [q for q in range(world) if int(verdicts[q].item())]
+        if failed:
+            if rank in failed:
+                print(f"bench.py: rank {rank}: the halo received (checksum {got}) is not rank {rank - 1}'s last pyramid "
+                      f"(checksum {int(every[rank - 1].item())})", file=sys.stderr, flush=True)
+            raise SystemExit(f"halo self-check failed on rank(s) {failed} (transport: {halo})")
+        halo_check = {"verdict": "ok", "ranks_checked": world - 1,
+                      "what": "position-weighted checksum of the pyramid in halo slot 0 == the predecessor's last pyramid, all-gathered"}
         del pyr
     barrier()
     enc.reset_timers()
@@ -284,10 +297,17 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     encoded = torch.tensor([float(info.pairs)], dtype=torch.float64, device=red_dev)
+    st = enc.stage_times_ms()
+    per_rank = None
     if world > 1:
+        # every rank's own clock and halo time: a straggler or a slow link shows up by rank in the line
+        halo_ms = st["halo_exchange"][0] / st["halo_exchange"][1] if "halo_exchange" in st else -1.0
+        mine_row = torch.tensor([elapsed / args.steps * 1e3, halo_ms, float(info.frames), float(info.pairs)], dtype=torch.float64, device=red_dev)
+        rows = [torch.zeros_like(mine_row) for _ in range(world)]
+        dist.all_gather(rows, mine_row)
+        per_rank = [[float(v) for v in r_.tolist()] for r_ in rows]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(encoded, op=dist.ReduceOp.SUM)
-    st = enc.stage_times_ms()
     timed_steps = len(range(0, args.steps, stride))
     res = {
         "elapsed": float(t.item()), "encoded_per_step": float(encoded.item()), "info": info, "halo": halo,
@@ -299,7 +319,19 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
         "launches_timed": {k: v[1] for k, v in st.items()},
         "timed_steps": timed_steps,
         "sample_frames": sample_frames, "clip_frames": clip_frames,
+        "per_rank": per_rank, "halo_check": halo_check,
     }
+    if args.sustain_seconds > 0 and world == 1 and mode == "strong":
+        # untimed for `value`: back-to-back steps for a few seconds, so that a sampler outside this process sees the
+        # GPU busy and the line carries a figure that is not a 50 ms burst
+        n_sus, t_sus = 0, time.perf_counter()
+        while time.perf_counter() - t_sus < args.sustain_seconds:
+            for _ in range(50):
+                enc.step()
+            enc.sync()
+            n_sus += 50
+        res["sustained"] = {"ms_per_step": (time.perf_counter() - t_sus) / n_sus * 1e3, "steps": n_sus,
+                            "seconds": time.perf_counter() - t_sus}
     enc.close()
     torch.cuda.empty_cache()
     return res
@@ -334,6 +366,8 @@ def main() -> None:
                     help="pipelined: keep the stand-alone launch shapes of RANSAC / segmentation")
     ap.add_argument("--segment-fork", action="store_true", default=os.environ.get("SVC_LAUNCH_NO_FORK", "1") == "0",
                     help="pipelined: let the segmentation fork its heavy attempts to a side stream")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0,
+                    help="N = 1: after the timed steps, run back-to-back steps for this long and report sustained_ms_per_step (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     args = ap.parse_args()
@@ -368,14 +402,25 @@ def main() -> None:
         # learns whether EVERY rank got its communicator; if not, all of them use the torch.distributed transport
         # (also RCCL) -- the decision must be collective or the ranks would wait on different transports.
         ok = torch.ones(1, dtype=torch.int32, device=dev)
-        try:
-            box = [clipmod.comm_unique_id() if rank == 0 else None]
-        except Exception as e:  # noqa: BLE001
-            box, comm_note = [None], f"svc_hip_comm_unique_id failed: {e}"
-        dist.broadcast_object_list(box, src=0, device=dev)
+        # ncclCommInitRank is a blocking collective: the ranks enter it all together or not at all, so whether librccl
+        # binds (a per-process matter: dlopen, symbols) is agreed on FIRST
+        if not clipmod.comm_available():
+            ok.zero_()
+            comm_note = f"librccl does not bind on rank {rank}: {native.load().svc_hip_last_error().decode()}"
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        box = [None]
+        if int(ok.item()):
+            try:
+                box = [clipmod.comm_unique_id() if rank == 0 else None]
+            except Exception as e:  # noqa: BLE001
+                box, comm_note = [None], f"svc_hip_comm_unique_id failed: {e}"
+            dist.broadcast_object_list(box, src=0, device=dev)
         if box[0] is not None:
             try:
                 comm = clipmod.comm_create(box[0], rank, world)
+                n_ranks, my_rank, _ = clipmod.comm_info(comm)
+                if (n_ranks, my_rank) != (world, rank):
+                    raise RuntimeError(f"the communicator reports rank {my_rank} of {n_ranks}, expected {rank} of {world}")
             except Exception as e:  # noqa: BLE001
                 ok.zero_()
                 comm_note = f"svc_hip_comm_create failed on rank {rank}: {e}"
@@ -442,6 +487,20 @@ def main() -> None:
         if world > 1:
             out["halo_exchange_ms"] = kt.get("halo_exchange")
             out["rank0_kernel_ms_per_step"] = main_kt
+            pr = r["per_rank"]
+            out["multi_gpu"] = {
+                "transport": r["halo"],
+                "rccl_ranks": clipmod.comm_info(comm)[0] if comm is not None else None,  # ncclCommCount of the C ABI's communicator
+                "transport_note": comm_note,
+                "halo_check": r["halo_check"],
+                "ms_per_step_by_rank": [x[0] for x in pr],
+                "ms_per_step_min": min(x[0] for x in pr), "ms_per_step_max": max(x[0] for x in pr),
+                "halo_exchange_ms_by_rank": [x[1] if x[1] >= 0 else None for x in pr],
+                "frames_by_rank": [int(x[2]) for x in pr], "encoded_by_rank": [int(x[3]) for x in pr],
+                "note": "each rank's own wall clock over the timed steps / steps; `ms_per_step` of the line is the max over ranks "
+                        "between barriers.  halo_exchange_ms: event-to-event on the communication stream (includes waiting for the "
+                        "neighbour's pyramid kernel)",
+            }
         if "weak" in results and main_mode != "weak":
             w = results["weak"]
             out["weak"] = {"value": w["encoded_per_step"] * args.steps / w["elapsed"], "unit": "frames/s",
@@ -495,6 +554,10 @@ def main() -> None:
                                     "frac": step_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
                                     "note": "luma+pyramid, motion search and transform of one step / ms_per_step; "
                                             "RANSAC + segmentation move < 1 % of these bytes"}
+        if r.get("sustained"):
+            out["sustained_ms_per_step"] = r["sustained"]["ms_per_step"]
+            out["sustained"] = {**r["sustained"], "value": r["encoded_per_step"] / (r["sustained"]["ms_per_step"] * 1e-3), "unit": "frames/s",
+                                "note": "untimed for `value`: back-to-back steps after the timed region"}
         if world == 1 and not args.no_hbm_probe:
             # context only: what plain streaming kernels get from this box's HBM (not a ceiling: the DCT kernel beats the 1:4 probe)
             out["hbm_streaming_measured"] = {"unit": "GB/s", **hbm_streaming_rates(dev),

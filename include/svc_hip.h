@@ -71,7 +71,7 @@ typedef struct svc_segment_params {
 #define SVC_HBMA_FORCE_LANE 8u           /* fused kernel, lane-per-block form without LDS (every fused shape) */
 
 const char* svc_hip_last_error(void);
-int svc_hip_abi_version(void); /* 2 (round 2: additions only -- *_ex launch flags, global motion, comm / halo shift) */
+int svc_hip_abi_version(void); /* 3 (round 3: additions only -- SVC_HBMA_FORCE_TILED / _LANE, svc_hip_comm_available / _info) */
 int svc_hip_device_count(int* count);
 
 /* Measurement aid, not part of the hot path: one launch of a plain streaming kernel (dwordx4 per lane,
@@ -347,6 +347,13 @@ int svc_hip_global_avg_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_
 #define SVC_COMM_ID_BYTES 128u /* sizeof(ncclUniqueId) */
 #define SVC_SHIFT_CYCLIC 1u    /* the last rank also sends to rank 0 (frame-per-GPU round robin) */
 
+/* SVC_OK when librccl could be bound in this process (no communicator is created: safe to call on any subset of
+ * the ranks, unlike svc_hip_comm_create, which is a collective). */
+int svc_hip_comm_available(void);
+/* What the communicator says about itself: ncclCommCount / ncclCommUserRank / ncclCommCuDevice (any pointer may be
+ * null).  A multi-rank run reports these so that "the halo really went through an N-rank RCCL communicator" is a
+ * measured statement. */
+int svc_hip_comm_info(void* comm, uint32_t* ranks, uint32_t* rank, int32_t* device);
 /* ncclGetUniqueId: call on one rank, hand the bytes to all of them out of band. */
 int svc_hip_comm_unique_id(uint8_t id[SVC_COMM_ID_BYTES]);
 /* ncclCommInitRank on the calling thread's current device; *comm is an ncclComm_t. */

@@ -99,6 +99,18 @@ def plan_shard(clip_frames: int, world: int, rank: int) -> Tuple[int, int, int, 
 
 # ---- RCCL communicator of the C ABI (include/svc_hip.h, csrc/comm.hip) --------------------------
 
+def comm_available() -> bool:
+    """librccl binds in this process (no communicator is created: not a collective)."""
+    return native.load().svc_hip_comm_available() == 0
+
+
+def comm_info(comm: int) -> Tuple[int, int, int]:
+    """(ranks, my rank, device) as the communicator itself reports them (ncclCommCount / UserRank / CuDevice)."""
+    n, r, d = _u32(), _u32(), C.c_int32()
+    native._check(native.load().svc_hip_comm_info(_vp(comm), C.byref(n), C.byref(r), C.byref(d)))
+    return n.value, r.value, d.value
+
+
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * COMM_ID_BYTES)()
     native._check(native.load().svc_hip_comm_unique_id(buf))

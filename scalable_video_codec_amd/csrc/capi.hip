@@ -97,7 +97,7 @@ using namespace svc;
 extern "C" {
 
 const char* svc_hip_last_error(void) { return g_err; }
-int svc_hip_abi_version(void) { return 2; }  // 2: + *_ex launch flags, global-motion entries, comm / halo shift
+int svc_hip_abi_version(void) { return 3; }  // 3: + SVC_HBMA_FORCE_TILED / _LANE, svc_hip_comm_available / _info
 
 int svc_hip_device_count(int* count) {
   SVC_REQUIRE(count, "device_count: null output");

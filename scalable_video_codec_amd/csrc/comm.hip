@@ -21,6 +21,9 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +55,9 @@ Rccl* rccl() {
     const bool ok = bind(r.lib, "ncclGetUniqueId", &r.GetUniqueId, r.why, sizeof r.why) &&
                     bind(r.lib, "ncclCommInitRank", &r.CommInitRank, r.why, sizeof r.why) &&
                     bind(r.lib, "ncclCommDestroy", &r.CommDestroy, r.why, sizeof r.why) &&
+                    bind(r.lib, "ncclCommCount", &r.CommCount, r.why, sizeof r.why) &&
+                    bind(r.lib, "ncclCommUserRank", &r.CommUserRank, r.why, sizeof r.why) &&
+                    bind(r.lib, "ncclCommCuDevice", &r.CommCuDevice, r.why, sizeof r.why) &&
                     bind(r.lib, "ncclGroupStart", &r.GroupStart, r.why, sizeof r.why) &&
                     bind(r.lib, "ncclGroupEnd", &r.GroupEnd, r.why, sizeof r.why) &&
                     bind(r.lib, "ncclSend", &r.Send, r.why, sizeof r.why) &&
@@ -78,6 +84,22 @@ int no_rccl() { return fail(SVC_ERR_UNSUPPORTED, "RCCL is not available: %s", g_
 using namespace svc;
 
 extern "C" {
+
+int svc_hip_comm_available(void) {
+  return rccl() ? SVC_OK : no_rccl();
+}
+
+int svc_hip_comm_info(void* comm, uint32_t* ranks, uint32_t* rank, int32_t* device) {
+  SVC_REQUIRE(comm, "comm_info: null communicator");
+  Rccl* r = rccl();
+  if (!r) return no_rccl();
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  int v = 0;
+  if (ranks) { SVC_NCCL_TRY(r, r->CommCount(c, &v)); *ranks = (uint32_t)v; }
+  if (rank) { SVC_NCCL_TRY(r, r->CommUserRank(c, &v)); *rank = (uint32_t)v; }
+  if (device) { SVC_NCCL_TRY(r, r->CommCuDevice(c, &v)); *device = v; }
+  return SVC_OK;
+}
 
 int svc_hip_comm_unique_id(uint8_t id[SVC_COMM_ID_BYTES]) {
   static_assert(sizeof(ncclUniqueId) == SVC_COMM_ID_BYTES, "ncclUniqueId size");

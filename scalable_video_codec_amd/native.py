@@ -88,6 +88,8 @@ SIGNATURES = {
     "svc_hip_global_ebma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_global_hbma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     "svc_hip_global_avg_host": (C.c_int, [_vp, _u32, _vp]),
+    "svc_hip_comm_available": (C.c_int, []),
+    "svc_hip_comm_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_int32)]),
     "svc_hip_comm_unique_id": (C.c_int, [_vp]),
     "svc_hip_comm_create": (C.c_int, [_vp, _u32, _u32, C.POINTER(_vp)]),
     "svc_hip_comm_destroy": (C.c_int, [_vp]),

@@ -41,6 +41,25 @@ def test_bench_line_contract():
     assert set(d["kernel_ms_per_step"]) == {"luma_pyramid", "hbma", "dct_quant"}  # the main stream, back to back
     assert set(d["overlapped_ms_per_step"]) == {"ransac", "segment", "note"}        # beside it (pipelined schedule)
     assert sum(d["kernel_ms_per_step"].values()) <= d["ms_per_step"] * 1.02
+    # the sustained loop behind the timed region (>= 3 s of back-to-back steps, untimed for `value`)
+    assert d["sustained"]["seconds"] >= 3.0 and d["sustained_ms_per_step"] > 0 and d["sustained"]["steps"] >= 50
+
+
+def test_single_rank_under_the_launcher_is_the_plain_run():
+    """The scaling driver launches N = 1 through torch.distributed.run like every other N: same code path, same line
+    (world size 1: no process group, no halo, `scaling` weak) -- so SCALE's N = 1 agrees with BENCH by construction."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "12", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--sustain-seconds", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    launched = json.loads(lines[0])
+    plain = _run("--gpus", "1", "--frames", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--sustain-seconds", "0")
+    assert launched["n_gpus"] == plain["n_gpus"] == 1 and launched["scaling"] == plain["scaling"] == "weak"
+    assert launched["config"] == plain["config"] and "multi_gpu" not in launched and "sustained" not in launched
+    assert set(launched) == set(plain) and set(launched["kernel_ms_per_step"]) == set(plain["kernel_ms_per_step"])
 
 
 def test_bench_other_config_and_flags():
@@ -71,3 +90,22 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert d["config"]["frames_per_gpu"] == [5, 4] and d["config"]["encoded_frames_per_step"] == 8
     assert d["weak"]["clip_frames"] == 18 and d["weak"]["encoded_frames_per_step"] == 17 and d["weak"]["value"] > 0
     assert d["halo_exchange_ms"] is not None
+    # the self-diagnosis of a multi-rank run: which transport carried the halo, what the communicator says about
+    # itself (none here: gloo rehearsal), the halo checksum verdict, every rank's own clock and halo time
+    m = d["multi_gpu"]
+    assert "gloo" in m["transport"] and m["rccl_ranks"] is None
+    assert m["halo_check"]["verdict"] == "ok" and m["halo_check"]["ranks_checked"] == 1
+    assert len(m["ms_per_step_by_rank"]) == 2 and m["ms_per_step_min"] <= m["ms_per_step_max"] <= d["ms_per_step"] * 1.05
+    assert m["frames_by_rank"] == [5, 4] and m["encoded_by_rank"] == [4, 4]
+    assert len(m["halo_exchange_ms_by_rank"]) == 2 and all(v is not None and v > 0 for v in m["halo_exchange_ms_by_rank"])
+
+
+def test_bench_halo_check_failure_is_collective():
+    """A halo that does not arrive intact must end EVERY rank non-zero (a one-sided exit would leave the others in the next
+    barrier until the launcher times out), naming the failing rank."""
+    env = dict(os.environ, SVC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SVC_BENCH_CORRUPT_HALO="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "9", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "halo self-check failed on rank(s) [1]" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -116,6 +116,50 @@ def test_pipeline_state_machine_fuzz(native, graph):
     enc.close()
 
 
+@pytest.mark.parametrize("graph,lat_depth", [(False, 0), (False, 1), (False, 3), (True, 0)])
+@pytest.mark.parametrize("steps_after", [1, 2, 3, 4, 5, 6])
+def test_buffer_sets_never_serve_stale_steps(native, graph, lat_depth, steps_after):
+    """The pipelined schedule keeps the small per-step buffers in depth + 2 sets and the pyramids in two; re-encoding the
+    same clip leaves every set with identical bytes after a few steps, so a missing join (the transform of step d reading
+    region ids before RANSAC + segmentation of d have run, the motion search of step h overwriting a field its reader has
+    not finished with) would hand back stale bytes that EQUAL the right ones.  Here the clip changes between bursts:
+    after a burst on clip A every set holds A's data; then 1 .. nsets + 1 steps of clip B must give B's outputs exactly
+    (a stale set would surface A's motion field, region ids or coefficients)."""
+    dev = torch.device("cuda")
+    n = 9
+    cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
+    fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    assert not torch.equal(fa, fb)
+    want = {}
+    for name, f in (("a", fa), ("b", fb)):
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL)
+        s.load_frames(f)
+        s.step()
+        s.sync()
+        want[name] = (s.outputs(), s.read("coeffs"))
+        s.close()
+    assert not torch.equal(want["a"][0]["mv"], want["b"][0]["mv"]) and not torch.equal(want["a"][0]["block_types"], want["b"][0]["block_types"])
+    enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, graph=graph, lat_depth=lat_depth)
+    enc.load_frames(fa)
+    for _ in range(7):
+        enc.step()
+    enc.load_frames(fb)  # drains the pipeline; every buffer set now holds clip A
+    for _ in range(steps_after):
+        enc.step()
+    out = enc.outputs()  # syncs
+    for k in want["b"][0]:
+        assert torch.equal(out[k], want["b"][0][k]), k
+    assert torch.equal(enc.read("coeffs"), want["b"][1])
+    enc.load_frames(fa)  # and back, mid-stream (no drain before the switch other than load_frames' own)
+    enc.step()
+    enc.step()
+    out = enc.outputs()
+    for k in want["a"][0]:
+        assert torch.equal(out[k], want["a"][0][k]), k
+    assert torch.equal(enc.read("coeffs"), want["a"][1])
+    enc.close()
+
+
 def test_wire_and_no_segmentation(native):
     dev = torch.device("cuda")
     n = 6
