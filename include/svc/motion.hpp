@@ -87,6 +87,13 @@ void EstimateGlobalMotionHierarchical(const uchar* const* tracked_pyramid,
 // Makes this thread's RANSAC draws reproducible.
 void SvcSeedRansac(uint seed);
 
+// Compatibility switch for the two whole-frame searches above (per thread, default off).  On: they answer what the
+// UNMODIFIED reference answers -- EstimateGlobalMotionExhaustiveSearch {0, 0} and FLT_MAX for every search_range > 0
+// (its loops never run, libs/motion.cpp:72, :81), EstimateGlobalMotionHierarchical {0, 0} -- so that a caller who swaps
+// this library in for the reference's `motion` target can have bit-identical outputs for these two (dead) functions
+// too.  Off: the search the code evidently means.
+void SvcReferenceLiteralGlobalSearch(bool on);
+
 // The reference keeps these two file-static (Dct, libs/encoder.cpp:323-339; the
 // quant lines of DecodeBlock, libs/decoder.cpp:130-144), so there is no signature
 // to keep; parameter meaning follows the originals.  `bgr` is the padded frame as

@@ -149,20 +149,9 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float byte_at(const uint32_t* w, int b) {
-  return (float)((w[b >> 2] >> (8 * (b & 3))) & 0xFFu);  // v_cvt_f32_ubyteN
-}
-
-#ifdef SVC_DCT_SLAB32  // experiment: row-pass results parked as 32-bit fixed point (2^-21), half the LDS
-constexpr int kRowPitch = 80;                   // 16 i32 + 16 B pad
-constexpr int kSlab8 = 8 * kRowPitch;           // 640 B
-constexpr int kSlab16 = 16 * kRowPitch + 64;    // 1344 B
-constexpr double kFix = 2097152.0, kUnfix = 1.0 / 2097152.0;
-#else
 constexpr int kRowPitch = 144;                  // 16 f64 + 16 B pad
 constexpr int kSlab8 = 8 * kRowPitch;           // 1152 B  (= 128 mod 256)
 constexpr int kSlab16 = 16 * kRowPitch + 128;   // 2432 B  (= 128 mod 256)
-#endif
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -227,18 +216,6 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-#ifdef SVC_DCT_ROW_F32  // A/B switch: the round-1 form (butterflies in f32: two conversions per multiply operand)
-    float x[16];
-    double r[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) x[p] = byte_at(wds, 3 * p + c);
-    if (N == 8) {
-      dct1d<8, float>(x, r);
-      dct1d<8, float>(x + 8, r + 8);
-    } else {
-      dct1d<16, float>(x, r);
-    }
-#else
     int x[16];
     double r[16];
 #pragma unroll
@@ -249,18 +226,9 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
     } else {
       dct1d<16, int>(x, r);
     }
-#endif
-#ifdef SVC_DCT_SLAB32
-    int4* row = reinterpret_cast<int4*>(slab + j * kRowPitch);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      row[i] = make_int4(__double2int_rn(r[4 * i] * kFix), __double2int_rn(r[4 * i + 1] * kFix),
-                         __double2int_rn(r[4 * i + 2] * kFix), __double2int_rn(r[4 * i + 3] * kFix));
-#else
     double2* row = reinterpret_cast<double2*>(slab + j * kRowPitch);
 #pragma unroll
     for (int i = 0; i < 8; ++i) row[i] = make_double2(r[2 * i], r[2 * i + 1]);
-#endif
     wave_lds_sync();
 
     float* plane = out_frame + (size_t)c * a.w * a.h;
@@ -269,15 +237,9 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
       double ca[8], cb[8], ya[8], yb[8];
 #pragma unroll
       for (int y = 0; y < 8; ++y) {
-#ifdef SVC_DCT_SLAB32
-        int2 t = *reinterpret_cast<const int2*>(slab + y * kRowPitch + j * 8);
-        ca[y] = (double)t.x * kUnfix;
-        cb[y] = (double)t.y * kUnfix;
-#else
         double2 t = *reinterpret_cast<const double2*>(slab + y * kRowPitch + j * 16);
         ca[y] = t.x;
         cb[y] = t.y;
-#endif
       }
       dct1d<8, double>(ca, ya);
       dct1d<8, double>(cb, yb);
@@ -309,11 +271,7 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
       double cc[16], yy[16];
 #pragma unroll
       for (int y = 0; y < 16; ++y)
-#ifdef SVC_DCT_SLAB32
-        cc[y] = (double)*reinterpret_cast<const int*>(slab + y * kRowPitch + j * 4) * kUnfix;
-#else
         cc[y] = *reinterpret_cast<const double*>(slab + y * kRowPitch + j * 8);
-#endif
       dct1d<16, double>(cc, yy);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + j;
       if (WIRE) wave_lds_sync();

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <random>
 #include <vector>
 
@@ -33,6 +34,12 @@ RansacRng& Rng() {
 }
 
 }  // namespace
+
+namespace {
+thread_local bool g_literal_global_search = false;
+}
+
+void SvcReferenceLiteralGlobalSearch(bool on) { g_literal_global_search = on; }
 
 void SvcSeedRansac(uint seed) {
   static_cast<void>(Rng());
@@ -106,6 +113,12 @@ Vec2f EstimateGlobalMotionAvg(const Vec2f* motion_field, uint sz) {
 
 void EstimateGlobalMotionExhaustiveSearch(const uchar* tracked_frame, const uchar* anchor_frame, uint frame_w,
                                           uint frame_h, uint search_range, Vec2f* global_motion, float* min_mad) {
+  if (g_literal_global_search && search_range > 0) {
+    // what the reference's loops leave behind when they do not run (`int dy <= uint search_range`, motion.cpp:66-67, :72)
+    *global_motion = Vec2f{0.0f, 0.0f};
+    *min_mad = std::numeric_limits<float>::max();
+    return;
+  }
   int rc = svc_hip_global_ebma_host(tracked_frame, anchor_frame, frame_w, frame_h, search_range,
                                     reinterpret_cast<float*>(global_motion), min_mad);
   if (rc) Die("EstimateGlobalMotionExhaustiveSearch", rc);
@@ -114,6 +127,11 @@ void EstimateGlobalMotionExhaustiveSearch(const uchar* tracked_frame, const ucha
 void EstimateGlobalMotionHierarchical(const uchar* const* tracked_pyramid, const uchar* const* anchor_pyramid,
                                       uint num_levels, uint base_frame_w, uint base_frame_h, uint base_search_range,
                                       Vec2f* global_motion) {
+  if (g_literal_global_search) {
+    // every level's search either does not run (range > 0) or sees the single candidate (0, 0): motion.cpp:118-141
+    *global_motion = Vec2f{0.0f, 0.0f};
+    return;
+  }
   int rc = svc_hip_global_hbma_host(tracked_pyramid, anchor_pyramid, num_levels, base_frame_w, base_frame_h,
                                     base_search_range, reinterpret_cast<float*>(global_motion));
   if (rc) Die("EstimateGlobalMotionHierarchical", rc);

@@ -12,13 +12,6 @@
 // Both are HBM-bound byte work: 3 B in / 1 B out, then 1 B in / 0.25 B out.
 #include "svc_common.hpp"
 
-#ifndef SVC_PYR_TW  // tile of the plane-to-plane pyramid pass (A/B knobs)
-#define SVC_PYR_TW 512
-#endif
-#ifndef SVC_PYR_TH
-#define SVC_PYR_TH 32
-#endif
-
 namespace svc {
 
 struct LumaArgs {
@@ -153,7 +146,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTWBgr = 128, kTHBgr = 32, kTWPlane = SVC_PYR_TW, kTHPlane = SVC_PYR_TH, kOff = 16;  // LDS column c <-> x = x0 - kOff + c
+constexpr int kTWBgr = 128, kTHBgr = 32, kTWPlane = 512, kTHPlane = 32 /* 128 x 64 ... 512 x 32 measured: profiles/r02_ab_pyr_tile.txt */, kOff = 16;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
   const uint8_t* bgr;      // FROM_BGR: interleaved frames

@@ -42,13 +42,16 @@ def load_pmc_traffic() -> Dict[str, float]:
 
 
 def plan_shards(total_frames: int, world: int) -> List[Tuple[int, int, bool]]:
-    """Cuts a clip of `total_frames` into `world` consecutive chunks -- svc::PlanShard, the C++ driver's own plan
-    (include/svc/clip_encoder.hpp).  Returns, per rank, (first_frame, n_frames, needs_halo): every rank but the
-    first needs the pyramid of frame first_frame - 1 from its predecessor.  Encoded frames: total_frames - 1."""
-    from . import clip
+    """Cuts a clip of `total_frames` into `world` consecutive chunks, the first `total_frames % world` ranks one frame
+    longer -- the plan of svc::PlanShard (include/svc/clip_encoder.hpp), restated here in plain Python so that the CPU
+    (gloo) tests need no built library; tests/test_host_logic.py holds the two to each other.  Returns, per rank,
+    (first_frame, n_frames, needs_halo): every rank but the first needs the pyramid of frame first_frame - 1 from its
+    predecessor.  Encoded frames: total_frames - 1."""
+    base, extra = divmod(total_frames, world)
     out = []
     for r in range(world):
-        first, n, _pairs, _first_encoded = clip.plan_shard(total_frames, world, r)
+        n = base + (1 if r < extra else 0)
+        first = r * base + min(r, extra)
         out.append((first, n, first > 0 and n > 0))
     return out
 

@@ -17,7 +17,10 @@ def pytest_sessionstart(session):
     test that loads them (hipcc cross-compiles gfx950 without a GPU; a minute the first time)."""
     from scalable_video_codec_amd import build as b
     if not (os.path.exists(b.LIB_HIP) and os.path.exists(b.LIB_MOTION)):
-        b.build_all(verbose=True)
+        try:
+            b.build_all(verbose=True)
+        except RuntimeError as e:  # no hipcc on this box: the oracle / golden / host-logic tests still run,
+            print(f"[conftest] native libraries not built: {e}", file=sys.stderr)  # the `native` fixture skips
 
 
 @pytest.fixture(scope="session")
@@ -43,8 +46,11 @@ def reference():
 def native():
     """The product library; GPU tests must go through it (no fallback)."""
     import torch
+    from scalable_video_codec_amd import build as b
     from scalable_video_codec_amd import native as n
-    n.load()
+    if not os.path.exists(b.LIB_HIP) and not torch.cuda.is_available():
+        pytest.skip("libsvc_hip.so is not built (no hipcc) and no GPU is visible")
+    n.load()  # on a GPU box a missing library is an error, not a skip: the product path has no fallback
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return n

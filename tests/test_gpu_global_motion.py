@@ -115,3 +115,37 @@ def test_cpp_symbols_of_the_reference_header(native, oracle):
     app = (C.c_void_p * 2)(*[x.ctypes.data for x in ap])
     hfn(tpp, app, 2, 64, 48, 4, gm.ctypes.data)
     assert gm.tobytes() == oracle.global_hbma(tp, ap, 4).tobytes()
+
+
+def test_reference_literal_switch_reproduces_the_reference(native):
+    """SvcReferenceLiteralGlobalSearch(true): the two whole-frame searches answer what the unmodified reference answers
+    (its `int dy <= uint search_range` loops never run, libs/motion.cpp:72, :81) -- the committed reference outputs of
+    tests/golden/global_motion.npz -- and nothing else changes; off again, the search as meant."""
+    lib = C.CDLL(native.MOTION_LIB_PATH)
+    sw = lib._Z31SvcReferenceLiteralGlobalSearchb
+    sw.restype, sw.argtypes = None, [C.c_bool]
+    _, t, a, literal = G.global_motion_cases()
+    h, w = t.shape
+    g = lib._Z36EstimateGlobalMotionExhaustiveSearchPKhS0_jjjP5Vec2fPf
+    g.restype, g.argtypes = None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+    hfn = lib._Z32EstimateGlobalMotionHierarchicalPKPKhS2_jjjjP5Vec2f
+    hfn.restype, hfn.argtypes = None, [C.c_void_p, C.c_void_p] + [C.c_uint] * 4 + [C.c_void_p]
+    gm, mad = np.full(2, 9.0, np.float32), np.full(1, 9.0, np.float32)
+    sw(True)
+    try:
+        for r, want in sorted(literal.items()):
+            g(t.ctypes.data, a.ctypes.data, w, h, r, gm.ctypes.data, mad.ctypes.data)
+            assert np.array([gm[0], gm[1], mad[0]], np.float32).tobytes() == want.tobytes(), r
+            if r > 0:
+                assert gm.tolist() == [0.0, 0.0] and mad[0] == np.finfo(np.float32).max
+        tp = [np.ascontiguousarray(t[:: 1 << l, :: 1 << l]) for l in range(2)]
+        ap = [np.ascontiguousarray(a[:: 1 << l, :: 1 << l]) for l in range(2)]
+        tpp = (C.c_void_p * 2)(*[x.ctypes.data for x in tp])
+        app = (C.c_void_p * 2)(*[x.ctypes.data for x in ap])
+        gm[:] = 9.0
+        hfn(tpp, app, 2, w, h, 4, gm.ctypes.data)
+        assert gm.tolist() == [0.0, 0.0]
+    finally:
+        sw(False)
+    g(t.ctypes.data, a.ctypes.data, w, h, 4, gm.ctypes.data, mad.ctypes.data)
+    assert mad[0] < np.finfo(np.float32).max  # the search runs again

@@ -1,6 +1,9 @@
 """Host-side logic: configs, padding, the synthetic generator, the pre-step definitions,
 frame sharding.  CPU only."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from scalable_video_codec_amd import configs, pipeline, synth
@@ -74,6 +77,20 @@ def test_plan_shards_covers_the_clip_once():
         # encoded frames = frames with a predecessor somewhere in the clip
         encoded = sum(n - 1 + (1 if halo else 0) for _, n, halo in plan if n > 0)
         assert encoded == total - 1
+
+
+def test_plan_shards_is_the_c_driver_plan():
+    """The plain-Python plan (what the gloo tests use) == svc_clip_plan_shard of the built C++ layer, wherever that exists."""
+    from scalable_video_codec_amd import build as b
+    if not os.path.exists(b.LIB_MOTION):
+        pytest.skip("libsvc_motion.so is not built")
+    from scalable_video_codec_amd import clip
+    for total, world in ((300, 1), (300, 8), (64, 8), (10, 3), (5, 8), (8, 8), (7, 8), (2400, 7)):
+        plan = pipeline.plan_shards(total, world)
+        for r in range(world):
+            first, n, pairs, first_encoded = clip.plan_shard(total, world, r)
+            assert plan[r] == (first, n, first > 0 and n > 0)
+            assert pairs == (0 if n == 0 else n - (0 if plan[r][2] else 1)) and first_encoded == (first if plan[r][2] else first + 1)
 
 
 def test_ransac_samples_are_distinct_and_in_range():
