@@ -23,7 +23,7 @@ OBJ = os.path.join(PKG, "_obj")
 LIB_HIP = os.path.join(PKG, "libsvc_hip.so")
 LIB_MOTION = os.path.join(PKG, "libsvc_motion.so")
 
-HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "hbma_tiled.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip", "global_motion.hip"]
+HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "hbma_fused8.hip", "hbma_fused32.hip", "hbma_tiled.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip", "global_motion.hip"]
 HOST_SOURCES = [os.path.join("host", "motion_hip.cpp")]
 
 # -ffp-contract=off: the reference's float expressions (RANSAC inlier test, quant) are
@@ -59,7 +59,7 @@ def _run(cmd: List[str]) -> None:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "dct_tables.inc"),
+    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "hbma_fused_kernel.hpp"), os.path.join(CSRC, "dct_tables.inc"),
                os.path.join(INCLUDE, "svc_hip.h")]
     jobs, objs = [], []
     for s in HIP_SOURCES:
@@ -70,7 +70,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         if verbose:
             print(f"[build] compiling {len(jobs)} HIP translation unit(s) for gfx950", flush=True)
-        with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
     if jobs or not os.path.exists(LIB_HIP):
         _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP, *objs])

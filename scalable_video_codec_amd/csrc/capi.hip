@@ -16,7 +16,7 @@ char* last_error_buf() { return g_err; }
 
 bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
 int launch_hbma_fused(const uint8_t*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                      uint32_t, float*, float*, int kernel, hipStream_t);
+                      uint32_t, uint32_t mv_block, float*, float*, int kernel, hipStream_t);
 int launch_hbma_wave(const uint8_t*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t,
                      uint32_t, uint32_t, uint32_t, float*, float*, hipStream_t);
 
@@ -45,11 +45,11 @@ int launch_hbma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair
   const int kernel = (flags & SVC_HBMA_FORCE_TILED) ? 2 : (flags & SVC_HBMA_FORCE_LANE) ? 1 : 0;
   if (flags & (SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE)) {
     if (!can_fuse)
-      return fail(SVC_ERR_UNSUPPORTED, "hbma: fused kernel needs 16x16 blocks, 3-4 levels, r_top in {1,2}, 4-byte aligned planes");
-    return launch_hbma_fused(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, d_mv, d_mad, kernel, stream);
+      return fail(SVC_ERR_UNSUPPORTED, "hbma: fused kernel needs square blocks of 8 / 16 / 32, 2 .. log2(block) levels, r_top in 1 .. 4, 4-byte aligned planes");
+    return launch_hbma_fused(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, bw, d_mv, d_mad, kernel, stream);
   }
   if (can_fuse && !(flags & SVC_HBMA_FORCE_WAVE_PER_BLOCK))
-    return launch_hbma_fused(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, d_mv, d_mad, 0, stream);
+    return launch_hbma_fused(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, bw, d_mv, d_mad, 0, stream);
   return launch_hbma_wave(d_tracked, d_anchor, pair_stride, n_pairs, levels, w, h, range, bw, bh, d_mv, d_mad, stream);
 }
 

@@ -79,9 +79,12 @@ __device__ __forceinline__ void load_row(const uint8_t* plane, uint32_t row_off,
 
 template <int NW>
 __device__ __forceinline__ void load_anchor_row(const uint8_t* p, uint32_t (&a)[NW]) {
-  if (NW == 4) {
-    u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
-    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+  if (NW % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < NW / 4; ++q) {
+      u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p + 16 * q);
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
   } else if (NW == 2) {
     u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(p);
     a[0] = v.x; a[1] = v.y;
@@ -108,19 +111,22 @@ __device__ __forceinline__ Window make_window(int cx, int cy, int fw, int fh) {
 }
 
 // Picks the winner of the (2RT+1)^2 grid of SADs in the reference's raster order with one
-// unsigned min over packed keys  (scaled_sad << 5) | code :
+// unsigned min over packed keys  (scaled_sad << CB) | code  (CB = 5 bits up to 25 candidates, 7 up to 81):
 //   refinement (motion.cpp:401, strict `<` against the carried minimum): code = raster
 //     index, so equal SADs resolve to the FIRST candidate; the winner replaces the carried
 //     value only if its scaled SAD is strictly smaller;
-//   top level (motion.cpp:324-337, `<=`): code = 31 - index, so equal SADs resolve to the
+//   top level (motion.cpp:324-337, `<=`): code = 2^CB - 1 - index, so equal SADs resolve to the
 //     LAST candidate; and if the valid SADs are non-increasing in raster order every
 //     candidate "updated" and the MV is zeroed (the minimum is kept).
-// Candidates outside the reference's clamped window get the all-ones key.
+// Candidates outside the reference's clamped window get the all-ones key.  A scaled SAD is at most
+// 255 * (MV block area) <= 2^18 (32 x 32 blocks), so the key fits 32 bits.
 template <int RT, bool TOP, int SHIFT, typename GetSad>
 __device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad sad_at, int& mvx,
                                        int& mvy, uint32_t& best) {
   constexpr int N = 2 * RT + 1;
-  static_assert(N * N <= 32, "raster index must fit the 5-bit code");
+  constexpr int CB = N * N <= 32 ? 5 : 7;
+  constexpr uint32_t CM = (1u << CB) - 1u;
+  static_assert(N * N <= 128, "raster index must fit the 7-bit code");
   uint32_t kmin = 0xFFFFFFFFu;
   uint32_t prev = 0xFFFFFFFFu;  // FLT_MAX of motion.cpp:290
   bool mono = true;
@@ -132,7 +138,7 @@ __device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad s
       const bool valid = row_ok && j >= w.jlo && j < w.jhi;
       const uint32_t s = sad_at(d, j);
       const int idx = d * N + j;
-      const uint32_t key = (s << (SHIFT + 5)) | (uint32_t)(TOP ? 31 - idx : idx);
+      const uint32_t key = (s << (SHIFT + CB)) | (uint32_t)(TOP ? (int)CM - idx : idx);
       kmin = min(kmin, valid ? key : 0xFFFFFFFFu);
       if (TOP) {
         mono = mono && (!valid || s <= prev);
@@ -140,8 +146,8 @@ __device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad s
       }
     }
   }
-  const uint32_t smin = kmin >> 5;  // scaled SAD of the winner
-  const int idx = TOP ? 31 - (int)(kmin & 31u) : (int)(kmin & 31u);
+  const uint32_t smin = kmin >> CB;  // scaled SAD of the winner
+  const int idx = TOP ? (int)CM - (int)(kmin & CM) : (int)(kmin & CM);
   const int bd = idx / N, bj = idx - bd * N;
   if (TOP) {
     best = smin;
@@ -154,34 +160,56 @@ __device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad s
   }
 }
 
-// One level with block size B >= 4.  Per tracked row: NW + 2 aligned dwords are loaded
+// How the 2 RT + 1 horizontal candidates of a level map onto the SAD instructions: NQ v_qsad_pk_u16_u8 per anchor word
+// (four candidates each) and, when one candidate is left over (RT = 2, 4), one v_sad_u8.
+template <int RT>
+struct SadPlan {
+  static constexpr int N = 2 * RT + 1;
+  static constexpr bool kTail = (N % 4) == 1;          // RT 2, 4: the last column by v_sad_u8
+  static constexpr int NQ = kTail ? N / 4 : (N + 3) / 4;  // RT 1: 1, RT 2: 1 (+ tail), RT 3: 2, RT 4: 2 (+ tail)
+};
+
+// One level with block size B >= 4.  Per tracked row: NW + NQ + 1 aligned dwords are loaded
 // and funnel-shifted once (v_alignbyte_b32) so that word k starts at window byte 4k; then
-// for every anchor row that meets it, per anchor word: one v_qsad_pk_u16_u8 (candidates
-// dx = 0..3) and, for RT = 2, one v_sad_u8 (dx = 4).
+// for every anchor row that meets it, per anchor word: NQ v_qsad_pk_u16_u8 (candidates
+// dx = 4q .. 4q + 3) and, for RT = 2 / 4, one v_sad_u8 (the last column).  The packed 16-bit
+// sums of a QSAD hold 256 byte differences: a 32-pixel-wide block spills them to 32 bits
+// every 8 anchor rows.
 template <int B, int RT, bool TOP, int SHIFT>
 __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
                                              const uint8_t* __restrict__ anc, int fw, int fh,
                                              int bx, int by, int& mvx, int& mvy, uint32_t& best) {
-  constexpr int NW = B / 4, ND = NW + 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  using P = SadPlan<RT>;
+  constexpr int NW = B / 4, NQ = P::NQ, NV = NW + NQ, ND = NV + 1, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  constexpr bool WIDE = B * B > 256;  // a block's SAD can exceed 16 bits
+  constexpr int FLUSH = 256 / B;      // anchor rows per 16-bit accumulation run
   const int ax = bx * B, ay = by * B;
   const Window w = make_window<B, RT>(ax + mvx, ay + mvy, fw, fh);
   const int a0 = w.wx & ~3;
   const uint32_t sh = (uint32_t)(w.wx & 3);
 
-  uint64_t acc4[NDY];
+  uint64_t acc4[NDY][NQ];
   uint32_t acc1[NDY];
+  uint32_t wide[WIDE ? NDY : 1][WIDE ? 4 * NQ : 1];
 #pragma unroll
-  for (int d = 0; d < NDY; ++d) { acc4[d] = 0; acc1[d] = 0; }
+  for (int d = 0; d < NDY; ++d) {
+    acc1[d] = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc4[d][q] = 0;
+    if (WIDE)
+#pragma unroll
+      for (int j = 0; j < 4 * NQ; ++j) wide[d][j] = 0;
+  }
   uint32_t a[B][NW];
   const uint32_t to = (uint32_t)(w.wy * fw), ao = (uint32_t)(ay * fw + ax);  // a plane is far below 2^32 bytes
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    uint32_t m[ND], v[NW + 1];
+    uint32_t m[ND], v[NV];
     load_row<ND, TOP>(trk, to + (uint32_t)(t * fw), a0, fw, m);
     if (t < B) load_anchor_row<NW>(anc + (ao + (uint32_t)(t * fw)), a[t < B ? t : 0]);
 #pragma unroll
-    for (int k = 0; k <= NW; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
+    for (int k = 0; k < NV; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
 #pragma unroll
     for (int d = 0; d < NDY; ++d) {
       const int r = t - d;  // anchor row that meets tracked row t at vertical offset d
@@ -189,8 +217,18 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
           const uint32_t av = a[r >= 0 && r < B ? r : 0][k];
-          acc4[d] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k], v[k + 1]), av, acc4[d]);
-          if (RT == 2) acc1[d] = __builtin_amdgcn_sad_u8(v[k + 1], av, acc1[d]);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            acc4[d][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k + q], v[k + q + 1]), av, acc4[d][q]);
+          if (P::kTail) acc1[d] = __builtin_amdgcn_sad_u8(v[k + NQ], av, acc1[d]);
+        }
+        if (WIDE && (r + 1) % FLUSH == 0) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wide[d][4 * q + f] += (uint32_t)(acc4[d][q] >> (16 * f)) & 0xFFFFu;
+            acc4[d][q] = 0;
+          }
         }
       }
     }
@@ -198,20 +236,22 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
   select<RT, TOP, SHIFT>(
       w, ax, ay,
       [&](int d, int j) {
-        return j < 4 ? (uint32_t)(acc4[d] >> (16 * (j & 3))) & 0xFFFFu : acc1[d];
+        if (j >= 4 * NQ) return acc1[d];
+        return WIDE ? wide[WIDE ? d : 0][WIDE ? j : 0] : (uint32_t)(acc4[d][j >> 2] >> (16 * (j & 3))) & 0xFFFFu;
       },
       mvx, mvy, best);
 }
 
-// Top level of a 4-level pyramid: 2x2 blocks (reference motion.cpp:719-720).  Two
-// bytes per anchor row do not fill a QSAD word, so this level uses v_sad_u8 on
+// A top level of 2x2 blocks (reference motion.cpp:719-720: the 4-level search of 16x16 blocks; likewise 3 levels
+// of 8x8, 5 of 32x32).  Two bytes per anchor row do not fill a QSAD word, so this level uses v_sad_u8 on
 // 16-bit slices; it is 1/64 of the pixels of level 0.  Loading and searching are
 // separate steps so that a caller can put other loads between them.
 template <int RT>
 struct TopB2 {
   static constexpr int NT = 2 + 2 * RT;
+  static constexpr int ND = RT <= 2 ? 3 : 4;  // dwords that hold the 2 RT + 2 window bytes at any alignment
   Window w;
-  uint32_t m[NT][3];
+  uint32_t m[NT][ND];
   uint32_t a[2];
 };
 
@@ -227,12 +267,12 @@ __device__ __forceinline__ void load_top_b2(const uint8_t* __restrict__ trk, con
     s.a[r] = *reinterpret_cast<const uint16_t*>(anc + (uint32_t)((ay + r) * fw + ax));
   const uint32_t to = (uint32_t)(s.w.wy * fw);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) load_row<3, true>(trk, to + (uint32_t)(t * fw), a0, fw, s.m[t]);
+  for (int t = 0; t < NT; ++t) load_row<TopB2<RT>::ND, true>(trk, to + (uint32_t)(t * fw), a0, fw, s.m[t]);
 }
 
 template <int RT, int SHIFT>
 __device__ __forceinline__ void search_top_b2(const TopB2<RT>& s, int bx, int by, int& mvx, int& mvy, uint32_t& best) {
-  constexpr int B = 2, NDY = 2 * RT + 1, NT = TopB2<RT>::NT;
+  constexpr int B = 2, NDY = 2 * RT + 1, NT = TopB2<RT>::NT, NV = TopB2<RT>::ND - 1;
   const uint32_t sh = (uint32_t)(s.w.wx & 3);
   uint32_t sad[NDY][NDY];
 #pragma unroll
@@ -241,13 +281,16 @@ __device__ __forceinline__ void search_top_b2(const TopB2<RT>& s, int bx, int by
     for (int j = 0; j < NDY; ++j) sad[d][j] = 0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    // window bytes 0 .. 2RT+1 (<= 6) as two dwords starting at the window origin
-    const uint32_t v0 = __builtin_amdgcn_alignbyte(s.m[t][1], s.m[t][0], sh);
-    const uint32_t v1 = __builtin_amdgcn_alignbyte(s.m[t][2], s.m[t][1], sh);
+    // window bytes 0 .. 2RT+1 as dwords starting at the window origin
+    uint32_t v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = __builtin_amdgcn_alignbyte(s.m[t][k + 1], s.m[t][k], sh);
     uint32_t tj[NDY];
 #pragma unroll
-    for (int j = 0; j < NDY; ++j)
-      tj[j] = (j < 4 ? __builtin_amdgcn_alignbyte(v1, v0, j) : v1 >> (8 * (j - 4))) & 0xFFFFu;
+    for (int j = 0; j < NDY; ++j) {  // the 16-bit slice at window byte j
+      const int q = j >> 2, o = j & 3;
+      tj[j] = (o < 3 ? v[q] >> (8 * o) : __builtin_amdgcn_alignbyte(v[q + 1 < NV ? q + 1 : q], v[q], 3)) & 0xFFFFu;
+    }
 #pragma unroll
     for (int d = 0; d < NDY; ++d) {
       const int r = t - d;

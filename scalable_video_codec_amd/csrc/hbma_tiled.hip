@@ -196,7 +196,7 @@ __global__ __launch_bounds__(TBX* TBY) void hbma_tiled16_kernel(FusedArgs a, uin
 // The LDS-tiled kernel serves the 4-level search with R_top = 1 on planes whose rows are whole 16-byte chunks at the
 // three levels it stages (so the frame width is a multiple of 64; any height).
 bool tiled_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh) {
-  return fused_supported(levels, w, h, range, bw, bh) && levels == 4 && (range >> 3) == 1 && w % 64 == 0;
+  return fused_supported(levels, w, h, range, bw, bh) && bw == 16 && levels == 4 && (range >> 3) == 1 && w % 64 == 0;
 }
 
 template <int TBX, int TBY>

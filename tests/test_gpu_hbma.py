@@ -44,6 +44,60 @@ def test_hbma_fused_vs_oracle_noise(native, oracle, levels, rng_range):
     _assert_same(mv, mad, exp_mv, exp_mad, f"wave L={levels} R={rng_range}")
 
 
+FUSED_SHAPES = [(mb, L, rt) for mb in (8, 16, 32) for L in range(2, 6) if (mb >> (L - 1)) >= 2
+                for rt in range(1, (2 if mb == 32 else 4) + 1)]
+
+
+@pytest.mark.parametrize("mb,levels,rt", FUSED_SHAPES)
+def test_hbma_fused_every_instantiation(native, oracle, mb, levels, rt):
+    """Every (MV block, levels, R_top) the lane-per-block kernel is instantiated for -- 8x8 / 16x16 / 32x32 blocks, 2 ..
+    log2(block) levels, R_top 1 .. 4 (apps/encoder.cpp:75-104: mv-block-w/h, pyr-lvl-count, mv-search-range) -- against
+    the oracle (libs/motion.cpp:412-465): uncorrelated noise (every clamp, 32x32 SADs beyond 16 bits, 49 / 81
+    candidates), a shifted copy (the planted vector must come back) and a frame of the minimum admitted size."""
+    f = 1 << (levels - 1)
+    r = rt * f + (f // 2 if f > 1 else 0)  # R_top = r >> (levels - 1) = rt with a remainder that must be ignored
+    rng = np.random.default_rng(mb * 100 + levels * 10 + rt)
+    for nbx, nby, kind in ((8, 5, "noise"), (6, 4, "shifted"), (None, None, "min")):  # even counts: the top plane's rows stay dword multiples
+        if kind == "min":  # the smallest frame fused_supported admits for this shape
+            tb = mb >> (levels - 1)
+            tw = max(tb + 8, 12)
+            tw = (tw + 3) // 4 * 4
+            w = tw * f
+            w = (w + mb - 1) // mb * mb
+            h = max((tb + 2 * rt) * f, mb)
+            h = (h + mb - 1) // mb * mb
+        else:
+            tb = mb >> (levels - 1)
+            nby = max(nby, -(-(tb + 2 * rt) * f // mb))  # the top plane must hold a candidate grid
+            w, h = mb * nbx, mb * nby
+        base_t = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        if kind == "shifted":
+            dy, dx = int(rng.integers(-rt * f + 1, rt * f)), int(rng.integers(-rt * f + 1, rt * f))
+            base_a = np.roll(base_t, (dy, dx), (0, 1))
+        else:
+            base_a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        t = [np.ascontiguousarray(base_t[:: 1 << l, :: 1 << l]) for l in range(levels)]
+        a = [np.ascontiguousarray(base_a[:: 1 << l, :: 1 << l]) for l in range(levels)]
+        exp_mv, exp_mad = oracle.hbma(t, a, r, mb, mb)
+        mv, mad = native.hbma_host(t, a, r, mb, mb, flags=native.HBMA_FORCE_FUSED)
+        _assert_same(mv, mad, exp_mv, exp_mad, f"fused {mb}x{mb} L={levels} R={r} {kind} {w}x{h}")
+        mv, mad = native.hbma_host(t, a, r, mb, mb, flags=native.HBMA_FORCE_WAVE_PER_BLOCK)
+        _assert_same(mv, mad, exp_mv, exp_mad, f"wave {mb}x{mb} L={levels} R={r} {kind} {w}x{h}")
+
+
+def test_hbma_fused_says_unsupported(native):
+    """Shapes outside the instantiations are UNSUPPORTED when the fused kernel is forced and take the per-level kernel
+    otherwise: non-square blocks, one level, R_top 5, 32x32 at R_top 3, a top level of 1x1 blocks."""
+    for levels, w, h, r, bw, bh in ((2, 256, 128, 4, 16, 8), (1, 128, 128, 2, 16, 16), (2, 256, 128, 10, 16, 16),
+                                    (3, 512, 256, 12, 32, 32), (4, 256, 128, 8, 8, 8)):
+        t = util.random_planes(np.random.default_rng(1), w, h, levels)
+        with pytest.raises(native.SvcError) as e:
+            native.hbma_host(t, t, r, bw, bh, flags=native.HBMA_FORCE_FUSED)
+        assert e.value.status in (native.SVC_ERR_UNSUPPORTED, native.SVC_ERR_INVALID_ARG), (levels, bw, bh)
+        if bw >> (levels - 1) >= 1 and bh >> (levels - 1) >= 1:
+            native.hbma_host(t, t, r, bw, bh)
+
+
 @pytest.mark.parametrize("bw,bh,r,levels", [(8, 8, 4, 1), (16, 8, 8, 2), (4, 4, 2, 1), (32, 16, 8, 3), (6, 10, 3, 1)])
 def test_hbma_wave_generic_shapes(native, oracle, bw, bh, r, levels):
     """Block shapes outside the fused kernel, including a non-multiple-of-4 width (byte path)."""

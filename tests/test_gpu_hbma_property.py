@@ -57,17 +57,20 @@ def test_hbma_random_shapes(native, oracle, case):
 
 
 @settings(max_examples=fuzz_examples(40), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=not FUZZ_RANDOM)
-@given(levels=st.sampled_from([3, 4]), rt=st.sampled_from([1, 2]), nbx=st.integers(2, 9), nby=st.integers(1, 6),
+@given(mb=st.sampled_from([8, 16, 32]), levels=st.integers(2, 5), rt=st.integers(1, 4), nbx=st.integers(2, 9), nby=st.integers(1, 6),
        seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["noise", "shifted", "flat", "periodic"]))
-def test_fused_kernel_random_frames(native, oracle, levels, rt, nbx, nby, seed, kind):
-    """The fused 16x16 kernel on small odd-shaped fields: every block near a border."""
-    w, h = 16 * nbx, 16 * nby
+def test_fused_kernel_random_frames(native, oracle, mb, levels, rt, nbx, nby, seed, kind):
+    """The fused lane-per-block kernel (8x8 / 16x16 / 32x32 blocks, 2 .. 5 levels, R_top 1 .. 4) on small odd-shaped
+    fields: every block near a border."""
+    if (mb >> (levels - 1)) < 1:
+        levels = mb.bit_length() - 1
+    w, h = mb * nbx, mb * nby
     r = rt << (levels - 1)
     t, a = _planes(kind, np.random.default_rng(seed), w, h, levels)
-    exp_mv, exp_mad = oracle.hbma(t, a, r, 16, 16)
+    exp_mv, exp_mad = oracle.hbma(t, a, r, mb, mb)
     try:
-        mv, mad = native.hbma_host(t, a, r, 16, 16, flags=native.HBMA_FORCE_FUSED)
-    except native.SvcError as e:  # too small for the fused kernel's candidate grid: must say so, not guess
+        mv, mad = native.hbma_host(t, a, r, mb, mb, flags=native.HBMA_FORCE_FUSED)
+    except native.SvcError as e:  # outside the instantiations / too small for the candidate grid: must say so, not guess
         assert e.status == native.SVC_ERR_UNSUPPORTED
-        mv, mad = native.hbma_host(t, a, r, 16, 16)
-    assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (levels, rt, w, h, kind)
+        mv, mad = native.hbma_host(t, a, r, mb, mb)
+    assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (mb, levels, rt, w, h, kind)
