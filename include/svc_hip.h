@@ -140,6 +140,11 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
  * few hardware queues, and an internal stream that lands on the queue of the caller's MAIN stream holds that stream's
  * next kernel back for the length of an attempt kernel. */
 #define SVC_LAUNCH_NO_FORK 2u
+/* Segmentation, fields above 8 192 blocks: a heavy frame's k-means attempts as launch sequences over several workgroups
+ * (default: only when frames x attempts would leave more than half of the CUs idle).  _WIDE forces that form, _NO_WIDE the
+ * one-workgroup form; results are identical. */
+#define SVC_LAUNCH_WIDE 4u
+#define SVC_LAUNCH_NO_WIDE 8u
 int svc_hip_ransac_frames_ex(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
                              svc_ransac_params params, const uint32_t* d_samples,
                              uint32_t iter_count, float* d_gm_xy, float* d_rmse,

@@ -330,6 +330,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
     if (!c.standalone_shapes) m.lat_flags |= SVC_LAUNCH_BESIDE;
     if (!c.segment_fork) m.lat_flags |= SVC_LAUNCH_NO_FORK;
   }
+  if (c.narrow_attempts) m.lat_flags |= SVC_LAUNCH_NO_WIDE;
   if (c.lat_depth > (uint32_t)Impl::kMaxDepth) throw std::runtime_error("svc::ClipEncoder: lat_depth must be 0..3");
   m.fork_early = c.world > 1 || (uint64_t)m.sh.pairs * ((uint64_t)((c.width + c.mv_block - 1) / c.mv_block) * ((c.height + c.mv_block - 1) / c.mv_block)) < 1600000ull;
   const uint32_t f = 1u << (c.levels - 1);
@@ -541,6 +542,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.hbma_flags = k->hbma_flags; c.lat_depth = k->lat_depth;
     c.standalone_shapes = (k->tuning & SVC_CLIP_TUNE_STANDALONE_SHAPES) != 0;
     c.segment_fork = (k->tuning & SVC_CLIP_TUNE_SEGMENT_FORK) != 0;
+    c.narrow_attempts = (k->tuning & SVC_CLIP_TUNE_NARROW_ATTEMPTS) != 0;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
     h->enc.reset(new svc::ClipEncoder(c));

@@ -22,6 +22,8 @@
 //   B  one workgroup per frame: best attempt, connected components (horizontal runs by ballot,
 //      then a lock-free union-find over the few links the runs do not imply), numbering.
 // Lists, labels and whatever does not fit LDS sit in the caller-provided workspace (L2-resident).
+#include <algorithm>
+
 #include "svc_common.hpp"
 
 namespace svc {
@@ -40,9 +42,11 @@ struct SegArgs {
   uint32_t bits_bytes;   // ... of which the bit fields at its start
   uint32_t packable;     // host check: field <= 512 x 512 blocks and x_px, y_px < 2^14 (32-bit distances)
   uint32_t take_all;     // the 256-lane attempt kernel also takes the heavy frames (no 1024-lane launch)
+  uint32_t wide_g;       // > 0: heavy frames' attempts run as launch sequences over wide_g workgroups each (the 1024-lane
+                         // attempt kernel then leaves them alone)
+  uint32_t wide_step;    // which launch of the sequence this is
 };
 
-constexpr uint32_t kMaxK = 64;
 // Lanes per frame are a template parameter T: 256 when the per-block arrays fit in LDS (measured at
 // 1080p: 64 lanes 0.86 ms, 256 lanes 0.39 ms per 64 frames -- the field-sized sweeps need the
 // lanes), 1024 when they live in global memory (4K), where sweep throughput is what counts.
@@ -221,7 +225,24 @@ __device__ __forceinline__ void bit_morph(const uint32_t* src, uint32_t* tmp, ui
 //   dmin     [A][n] u32 k-means++ running minima when they do not fit registers or LDS
 //   cl [n] u8, parent [n] u32: connected-components arrays when they do not fit LDS
 //   roots    [n] u32    component roots in raster order
+//   dmin2    [A][n] u32 second set of running minima: the multi-launch form reads step j - 1's while it writes step j's
+//   wide     [A] WideState   the multi-launch form of an attempt (segment_wide_*_kernel): centres, partial sums per
+//                            workgroup, the "attempt is over" flag
 constexpr uint32_t kMaxAttempts = 16;
+constexpr uint32_t kMaxK = 64;
+constexpr uint32_t kWideMaxG = 32;  // workgroups one attempt can be spread over
+
+// State of one attempt that runs as a sequence of launches (see segment_wide_seed_kernel).  Everything a launch reads was
+// written by an EARLIER launch of the same stream; within a launch every workgroup recomputes what it needs from it.
+struct WideState {
+  int cint[kMaxK][3];                               // k-means++ centres as drawn
+  double c[2][kMaxK][3];                            // Lloyd centres, double-buffered by iteration parity
+  unsigned long long seed_sum[kMaxK][kWideMaxG];    // seeding step j: sum of the running minima per workgroup
+  long long part[2][kWideMaxG][kMaxK][4];           // Lloyd: count, sum mv.x, sum column, sum row per workgroup and cluster
+  unsigned long long compact[2][kWideMaxG];         // Lloyd: fixed-point compactness per workgroup
+  uint32_t done;                                    // the attempt is over: ws.compact()[att] is final, later launches leave
+  uint32_t pad[3];
+};
 
 struct Workspace {
   uint8_t* base;
@@ -235,7 +256,9 @@ struct Workspace {
   __host__ __device__ uint64_t off_cl() const { return off_dmin() + a16(4ull * attempts * n); }
   __host__ __device__ uint64_t off_parent() const { return off_cl() + a16(n); }
   __host__ __device__ uint64_t off_roots() const { return off_parent() + a16(4ull * n); }
-  __host__ __device__ uint64_t bytes() const { return (off_roots() + 4ull * n + 255) & ~255ull; }
+  __host__ __device__ uint64_t off_dmin2() const { return (off_roots() + 4ull * n + 255) & ~255ull; }
+  __host__ __device__ uint64_t off_wide() const { return (off_dmin2() + 4ull * attempts * n + 255) & ~255ull; }
+  __host__ __device__ uint64_t bytes() const { return (off_wide() + (uint64_t)attempts * sizeof(WideState) + 255) & ~255ull; }
   __device__ uint32_t* nf() const { return reinterpret_cast<uint32_t*>(base); }
   __device__ uint32_t* packed() const { return reinterpret_cast<uint32_t*>(base + 4); }
   __device__ unsigned long long* compact() const { return reinterpret_cast<unsigned long long*>(base + 8); }
@@ -247,6 +270,8 @@ struct Workspace {
   __device__ uint8_t* cl() const { return base + off_cl(); }
   __device__ uint32_t* parent() const { return reinterpret_cast<uint32_t*>(base + off_parent()); }
   __device__ uint32_t* roots() const { return reinterpret_cast<uint32_t*>(base + off_roots()); }
+  __device__ uint32_t* dmin2(uint32_t a) const { return reinterpret_cast<uint32_t*>(base + off_dmin2() + 4ull * a * n); }
+  __device__ WideState* wide(uint32_t a) const { return reinterpret_cast<WideState*>(base + off_wide()) + a; }
 };
 
 #ifdef SVC_SEG_TIMING  // diagnostic build only (tools/diag_segment_phases.py): shader-clock stamps of the phases
@@ -861,6 +886,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const uint32_t nf = *ws.nf();
   if (nf == 0 || (!a.take_all && (nf > kLightMax) != (T == kTA))) return;
+  if (T == kTA && a.wide_g && *ws.packed() != 0) return;  // the launch sequence of segment_wide_*_kernel has this frame
   const uint32_t te = T == kTA ? kTA : nf <= 256 ? 64u : 256u;  // one wave: no barrier ever waits
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
   uint8_t* lab = ws.lab(att);
@@ -895,6 +921,247 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   }
   if (tid == 0) ws.compact()[att] = compact;
   SEG_STAMP(31);
+}
+
+// ---- an attempt as a SEQUENCE OF LAUNCHES over G workgroups (few frames, large fields) ---------------------------
+// One (frame, attempt) of the kernel above is bound to one CU by its ~40 workgroup barriers: 0.57 ms for a 4K scene cut
+// (29 600 foreground blocks), which is what an 8-frame shard of a 4K clip then waits for while 230 CUs idle.  When
+// frames x attempts is small the host instead runs the attempt as k + max_iter + 1 launches of G workgroups per (frame,
+// attempt): every grid-wide reduction of the algorithm (the k-means++ draw, the centre update) sits on a kernel boundary,
+// so there is no spin-wait and no residency assumption.  A launch reads only what EARLIER launches wrote (WideState);
+// inside a launch every workgroup recomputes the shared quantities (draw, centres, convergence) redundantly from the
+// per-workgroup partial sums, which are exact integers -- so the result is the single-kernel path's, and
+// oracle/svc_segment.c's, bit for bit.  Workgroup g owns the g-th contiguous chunk of the foreground list.
+constexpr uint32_t kTW = 256;  // lanes of a wide workgroup
+
+__device__ __forceinline__ void wide_chunk(uint32_t nf, uint32_t G, uint32_t g, uint32_t& w0, uint32_t& w1) {
+  const uint32_t chunk = (((nf + G - 1) / G) + 63u) & ~63u;
+  w0 = min(nf, g * chunk);
+  w1 = min(nf, w0 + chunk);
+}
+
+// Launch j = a.wide_step of the seeding (j = 0 .. k - 1): fixes centre j, then folds it into the running minima of this
+// workgroup's chunk and publishes their sum for launch j + 1's draw (libs/encoder.cpp:557-578 via cv::kmeans' k-means++,
+// as oracle/svc_segment.c states it).
+__global__ __launch_bounds__(kTW) void segment_wide_seed_kernel(SegArgs a) {
+  __shared__ uint64_t s_red[kTW / 64];
+  __shared__ uint64_t s_sums[kWideMaxG];
+  __shared__ uint32_t s_pick;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t g = blockIdx.x, G = a.wide_g, frame = blockIdx.y, att = blockIdx.z, n = a.n, j = a.wide_step;
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
+  const uint32_t nf = *ws.nf();
+  if (nf <= kLightMax || *ws.packed() == 0) return;  // light / unpackable frames stay on the single-kernel paths
+  const uint32_t k = min(a.k, nf);
+  if (j >= k) return;
+  WideState& W = *ws.wide(att);
+  const uint32_t* pk = ws.pk();
+  // step j reads the minima of step j - 1 (another workgroup may still be scanning this workgroup's chunk for the draw)
+  // and writes its own into the other set
+  const uint32_t* dprev = (j & 1u) ? ws.dmin(att) : ws.dmin2(att);
+  uint32_t* dmin = (j & 1u) ? ws.dmin2(att) : ws.dmin(att);
+  const uint64_t aseed = (a.seed + frame) ^ ((uint64_t)att << 32);
+  const uint32_t bw = a.mv_bw, bh = a.mv_bh;
+  uint32_t w0, w1;
+  wide_chunk(nf, G, g, w0, w1);
+
+  uint32_t cv;  // centre j as a packed point
+  if (j == 0) {
+    cv = pk[(uint32_t)(seg_hash(aseed) % nf)];
+    if (g == 0 && tid == 0) W.done = 0;
+  } else {
+    // the draw of step j over the minima that launch j - 1 left: total, owner workgroup, offset inside its chunk
+    if (tid < G) s_sums[tid] = W.seed_sum[j - 1][tid];  // G loads in flight together, then LDS
+    __syncthreads();
+    uint64_t total = 0;
+    for (uint32_t q = 0; q < G; ++q) total += s_sums[q];
+    if (total == 0) {
+      cv = pk[j < nf ? j : 0];
+    } else {
+      uint64_t r = seg_hash(aseed ^ j) % total;
+      uint32_t owner = 0;
+      for (; owner + 1 < G && r >= s_sums[owner]; ++owner) r -= s_sums[owner];
+      uint32_t o0, o1;
+      wide_chunk(nf, G, owner, o0, o1);
+      // "the first point whose inclusive prefix exceeds r", in list order: every lane sums a contiguous run of the
+      // owner's chunk, one block scan over the 256 run sums finds the run that holds the crossing, its lane walks it
+      const uint32_t run = (o1 - o0 + kTW - 1) / kTW;
+      const uint32_t b = min(o1, o0 + tid * run), e = min(o1, b + run);
+      uint64_t seg = 0;
+      for (uint32_t i = b; i < e; ++i) seg += dprev[i];
+      uint64_t blk_total;
+      const uint64_t excl = block_excl_scan(seg, s_red, tid, kTW / 64, &blk_total);
+      if (r >= excl && r - excl < seg) {  // exactly one lane (blk_total = the owner's published sum > r)
+        uint64_t acc = excl;
+        for (uint32_t i = b; i < e; ++i) {
+          acc += dprev[i];
+          if (acc > r) { s_pick = i; break; }
+        }
+      }
+      __syncthreads();
+      cv = pk[s_pick];
+      __syncthreads();  // s_pick is read before anyone could get to overwrite it (single use: kept for symmetry)
+    }
+  }
+  if (g == 0 && tid == 0) {
+    const Pt p = unpack_pt(cv, bw, bh);
+    W.cint[j][0] = p.f[0]; W.cint[j][1] = p.f[1]; W.cint[j][2] = p.f[2];
+  }
+  if (j + 1 >= k) return;  // the last centre: nothing draws after it
+  const Pt cp = unpack_pt(cv, bw, bh);
+  const int c[3] = {cp.f[0], cp.f[1], cp.f[2]};
+  uint64_t lsum = 0;
+  for (uint32_t i = w0 + tid; i < w1; i += kTW) {
+    const uint32_t d = dist2_u32(unpack_pt(pk[i], bw, bh), c);
+    const uint32_t m = j == 0 ? d : min(dprev[i], d);
+    dmin[i] = m;
+    lsum += m;
+  }
+  lsum = wave_sum_u64(lsum);
+  if (lane == 0) s_red[wave] = lsum;
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t t = 0;
+    for (uint32_t q = 0; q < kTW / 64; ++q) t += s_red[q];
+    W.seed_sum[j][g] = t;
+  }
+}
+
+// Launch it = a.wide_step of the Lloyd iterations (it = 0 .. max_iter): closes iteration it - 1 (compactness, centre
+// update, convergence: lloyd_end_iter's arithmetic in lloyd_end_iter's order), then assigns this workgroup's chunk to
+// the new centres and publishes its per-cluster sums.  Launch max_iter only closes.
+__global__ __launch_bounds__(kTW) void segment_wide_lloyd_kernel(SegArgs a) {
+  __shared__ double s_c[kMaxK][3];
+  __shared__ double s_shift[kMaxK];
+  __shared__ unsigned long long s_acc[kMaxK][2];
+  __shared__ unsigned long long s_sum[kMaxK][4];
+  __shared__ unsigned long long s_lc;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t g = blockIdx.x, G = a.wide_g, frame = blockIdx.y, att = blockIdx.z, n = a.n, it = a.wide_step;
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
+  const uint32_t nf = *ws.nf();
+  if (nf <= kLightMax || *ws.packed() == 0) return;
+  const uint32_t k = min(a.k, nf);
+  WideState& W = *ws.wide(att);
+  if (W.done) return;  // written by an earlier launch
+  const uint32_t bw = a.mv_bw, bh = a.mv_bh;
+  const uint32_t par = it & 1u, prev = par ^ 1u;
+
+  if (it == 0) {
+    if (tid < k) { s_c[tid][0] = (double)W.cint[tid][0]; s_c[tid][1] = (double)W.cint[tid][1]; s_c[tid][2] = (double)W.cint[tid][2]; }
+    __syncthreads();
+  } else {
+    // iteration it - 1 is complete in W.part[prev] / W.compact[prev]: summed over the G workgroups with every load in flight
+    // at once (one lane per (workgroup, cluster) record), not G round trips in a row
+    if (tid < k) { s_sum[tid][0] = 0; s_sum[tid][1] = 0; s_sum[tid][2] = 0; s_sum[tid][3] = 0; }
+    if (tid == 0) s_lc = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < G * k; t += kTW) {
+      const uint32_t q = t / k, j = t - q * k;
+      const long long* r = W.part[prev][q][j];
+      const long long r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+      atomicAdd(&s_sum[j][0], (unsigned long long)r0); atomicAdd(&s_sum[j][1], (unsigned long long)r1);
+      atomicAdd(&s_sum[j][2], (unsigned long long)r2); atomicAdd(&s_sum[j][3], (unsigned long long)r3);
+    }
+    if (tid < G) atomicAdd(&s_lc, W.compact[prev][tid]);
+    __syncthreads();
+    const unsigned long long compact = s_lc;
+    const bool last = it >= a.max_iter;  // lloyd_end_iter: `if (it + 1 >= max_iter) return true` before any update
+    if (!last && tid < k) {
+      const long long cnt = (long long)s_sum[tid][0], smv = (long long)s_sum[tid][1], sbx = (long long)s_sum[tid][2],
+                      sby = (long long)s_sum[tid][3];
+      double s = 0.0;
+      double c0 = W.c[prev][tid][0], c1 = W.c[prev][tid][1], c2 = W.c[prev][tid][2];
+      if (cnt) {
+        const long long sums[3] = {smv, sbx * (long long)bw, sby * (long long)bh};
+        double cc[3] = {c0, c1, c2};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double nc = (double)sums[d] / (double)cnt;
+          const double t = nc - cc[d];
+          s = s + t * t;
+          cc[d] = nc;
+        }
+        c0 = cc[0]; c1 = cc[1]; c2 = cc[2];
+      }
+      s_c[tid][0] = c0; s_c[tid][1] = c1; s_c[tid][2] = c2;
+      s_shift[tid] = s;
+    }
+    __syncthreads();
+    bool over = last;
+    if (!last) {
+      double shift = 0.0;
+      for (uint32_t q = 0; q < k; ++q) shift = s_shift[q] > shift ? s_shift[q] : shift;
+      over = shift <= a.eps2;
+    }
+    if (over) {  // the labels of iteration it - 1 stand; every workgroup sees the same verdict
+      if (g == 0 && tid == 0) { ws.compact()[att] = compact; W.done = 1; }
+      return;
+    }
+  }
+  if (g == 0 && tid < k) { W.c[par][tid][0] = s_c[tid][0]; W.c[par][tid][1] = s_c[tid][1]; W.c[par][tid][2] = s_c[tid][2]; }
+  if (tid < k) { s_acc[tid][0] = 0; s_acc[tid][1] = 0; }
+  if (tid == 0) s_lc = 0;
+  __syncthreads();
+
+  // assign: nearest centre (strict <: the lowest index keeps a tie), f64 in lloyd_quad's operation order
+  const uint32_t* pk = ws.pk();
+  uint8_t* lab = ws.lab(att);
+  uint32_t w0, w1;
+  wide_chunk(nf, G, g, w0, w1);
+  unsigned long long lc = 0;
+  for (uint32_t i0 = w0; i0 < w1; i0 += 4 * kTW) {  // four points per lane at a time: four independent f64 chains
+    uint32_t v[4], bj[4];
+    bool act[4];
+    double px[4], py[4], pz[4], best[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * kTW + tid;
+      act[u] = i < w1;
+      v[u] = act[u] ? pk[i] : 0u;
+      const Pt p = unpack_pt(v[u], bw, bh);
+      px[u] = (double)p.f[0]; py[u] = (double)p.f[1]; pz[u] = (double)p.f[2];
+      const double dx = px[u] - s_c[0][0], dy = py[u] - s_c[0][1], dz = pz[u] - s_c[0][2];
+      double d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      best[u] = d;
+      bj[u] = 0;
+    }
+    for (uint32_t q = 1; q < k; ++q) {
+      const double c0 = s_c[q][0], c1 = s_c[q][1], c2 = s_c[q][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double ax = px[u] - c0, ay = py[u] - c1, az = pz[u] - c2;
+        double da = ax * ax;
+        da = da + ay * ay;
+        da = da + az * az;
+        bj[u] = da < best[u] ? q : bj[u];          // strict <: the lowest index keeps a tie
+        best[u] = __builtin_fmin(best[u], da);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!act[u]) continue;
+      lab[i0 + (uint32_t)u * kTW + tid] = (uint8_t)bj[u];
+      lc += (unsigned long long)(best[u] * 256.0);
+      // two fields per 64-bit LDS atomic, as lloyd_quad packs them: count | (mv.x + 8192) << 32 and column | row << 32; a
+      // chunk holds fewer than 2^17 points, so no field reaches 2^32
+      atomicAdd(&s_acc[bj[u]][0], 1ull | ((unsigned long long)(uint32_t)(((int)v[u] >> 18) + 8192) << 32));
+      atomicAdd(&s_acc[bj[u]][1], (unsigned long long)(v[u] & 511u) | ((unsigned long long)((v[u] >> 9) & 511u) << 32));
+    }
+  }
+  lc = wave_sum_u64(lc);
+  if (lane == 0) atomicAdd(&s_lc, lc);
+  __syncthreads();
+  if (tid < k) {
+    const long long cnt = (long long)(uint32_t)s_acc[tid][0];
+    W.part[par][g][tid][0] = cnt;
+    W.part[par][g][tid][1] = (long long)(s_acc[tid][0] >> 32) - 8192ll * cnt;  // sum of mv.x
+    W.part[par][g][tid][2] = (long long)(uint32_t)s_acc[tid][1];
+    W.part[par][g][tid][3] = (long long)(s_acc[tid][1] >> 32);
+  }
+  if (tid == 0) W.compact[par][g] = s_lc;
 }
 
 // Kernel B: one workgroup per frame.  Takes the attempt with the smallest compactness (ties ->
@@ -1149,8 +1416,34 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   const bool small = (flags & SVC_LAUNCH_BESIDE) != 0 && a.n <= kRegPts * kTA;
   a.take_all = small ? 1u : 0u;
   if (small) a.lds_bytes = a.bits_bytes + 16;  // the foreground list goes to the workspace
+  // Few frames of a large field (the shard of a multi-GPU 4K run): a heavy frame's attempts run as launch sequences over
+  // wide_g workgroups each instead of one workgroup (segment_wide_*_kernel) -- when they would otherwise leave most CUs idle.
+  a.wide_g = 0;
+  a.wide_step = 0;
+  if (!small && a.packable && a.n > kRegPts * kTA && !(flags & SVC_LAUNCH_NO_WIDE)) {
+    static const uint32_t cus = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+      return (uint32_t)v;
+    }();
+    const uint64_t work = (uint64_t)n_frames * p.attempt_count;
+    if ((flags & SVC_LAUNCH_WIDE) || 2 * work <= cus)
+      a.wide_g = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4 * (uint64_t)cus / std::max<uint64_t>(work, 1), 2), kWideMaxG);  // ~4 workgroups per CU
+  }
   hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);
   a.lds_bytes = 0;
+  auto launch_wide = [&](hipStream_t st) {
+    SegArgs w = a;
+    const dim3 grid_w(a.wide_g, n_frames, p.attempt_count);
+    for (uint32_t j = 0; j < a.k; ++j) {
+      w.wide_step = j;
+      hipLaunchKernelGGL(segment_wide_seed_kernel, grid_w, dim3(kTW), 0, st, w);
+    }
+    for (uint32_t it = 0; it <= a.max_iter; ++it) {
+      w.wide_step = it;
+      hipLaunchKernelGGL(segment_wide_lloyd_kernel, grid_w, dim3(kTW), 0, st, w);
+    }
+  };
   if (small) {
     hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
   } else if (a.n > kLightMax) {
@@ -1170,11 +1463,13 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
       SVC_HIP_TRY(hipEventRecord(side->fork, stream));
       SVC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
       hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, side->stream, heavy);
+      if (a.wide_g) launch_wide(side->stream);
       SVC_HIP_TRY(hipEventRecord(side->join, side->stream));
       hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
       SVC_HIP_TRY(hipStreamWaitEvent(stream, side->join, 0));
     } else {
       hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, stream, heavy);
+      if (a.wide_g) launch_wide(stream);
       hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
     }
   } else {

@@ -71,10 +71,13 @@ def test_segment_edge_cases(native, oracle):
 @pytest.mark.parametrize("mfw,mfh,density", [(120, 68, 0.45), (120, 68, 0.7), (120, 68, 0.93), (120, 68, 1.0),
                                              (240, 135, 0.6), (240, 135, 0.97), (33, 31, 0.8),
                                              (480, 270, 0.35), (480, 270, 0.12)])
-@pytest.mark.parametrize("flags", [0, 1, 2, 3], ids=["alone", "beside", "nofork", "beside-nofork"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 10], ids=["alone", "beside", "nofork", "beside-nofork", "wide", "wide-nofork",
+                                                              "nowide", "nowide-nofork"])
 def test_segment_heavy_frames(native, oracle, mfw, mfh, density, flags):
     """Scene-cut-like frames: much of the field is foreground (the 1024-lane launch; above 8 192 blocks the
-    points leave the registers for LDS and, at 8K, the workspace), next to a light and an empty frame."""
+    points leave the registers for LDS and, at 8K, the workspace), next to a light and an empty frame.  Above 8 192
+    blocks the attempts of a heavy frame also exist as launch sequences over several workgroups (SVC_LAUNCH_WIDE = 4
+    forces that form, SVC_LAUNCH_NO_WIDE = 8 the one-workgroup form; with three frames the default is the wide form)."""
     rng = np.random.default_rng(int(density * 100) + mfw)
     n = mfw * mfh
     yy, xx = np.mgrid[0:mfh, 0:mfw]
@@ -108,3 +111,33 @@ def test_segment_unpacked_points_path(native, oracle, mfw, mfh):
     got = native.segment_frames(torch.from_numpy(mask[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh,
                                 seed=21).cpu().numpy()[0]
     assert np.array_equal(got.astype(np.uint32), oracle.segment(mask, mv, mfw, mfh, seed=21))
+
+
+@pytest.mark.parametrize("kw", [dict(cluster_count=1), dict(cluster_count=3, attempt_count=1, max_iter_count=2), dict(epsilon=50.0),
+                                dict(cluster_count=40, attempt_count=5), dict(max_iter_count=1), dict(cluster_count=64, max_iter_count=30)])
+@pytest.mark.parametrize("frames", [1, 7])
+def test_segment_wide_attempts_parameters(native, oracle, kw, frames):
+    """The multi-launch form of an attempt (SVC_LAUNCH_WIDE) across the k-means parameters -- one centre (no draw at all),
+    one iteration (the closing launch only), an epsilon that stops after the first update, more centres than the default,
+    the iteration cap reached or not -- and across workgroup counts (1 frame: 32 workgroups per attempt; 7 frames x 5
+    attempts: 7): region ids == oracle/svc_segment.c == the one-workgroup form."""
+    mfw, mfh = 240, 135
+    n = mfw * mfh
+    rng = np.random.default_rng(frames * 13 + len(kw))
+    yy, xx = np.mgrid[0:mfh, 0:mfw]
+    masks, mvs = [], []
+    for f in range(frames):
+        d = (0.9, 0.5, 0.2, 0.97, 0.05, 0.65, 0.0)[f % 7]
+        mask = (~(rng.random((mfh, mfw)) < d)).astype(np.uint8).reshape(-1)
+        mv = np.stack([np.round(7 * np.sin(xx / 23.0 + f) + rng.integers(-3, 4, (mfh, mfw))), rng.integers(-9, 10, (mfh, mfw))],
+                      -1).astype(np.float32).reshape(n, 2)
+        masks.append(mask); mvs.append(mv)
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    tm, tv = torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda()
+    wide = native.segment_frames(tm, tv, mfw, mfh, seed=5, flags=4, **kw).cpu().numpy()
+    narrow = native.segment_frames(tm, tv, mfw, mfh, seed=5, flags=8, **kw).cpu().numpy()
+    assert np.array_equal(wide, narrow)
+    okw = {"attempts" if k == "attempt_count" else "max_iter" if k == "max_iter_count" else k: v for k, v in kw.items()}
+    for f in range(min(frames, 3)):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=5 + f, **okw)
+        assert np.array_equal(wide[f].astype(np.uint32), want), f"frame {f}: {(wide[f] != want).sum()} blocks differ"
