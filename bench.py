@@ -229,7 +229,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     hbma_flags = {"auto": native.HBMA_AUTO, "tiled": native.HBMA_FORCE_TILED, "lane": native.HBMA_FORCE_LANE,
                   "wave": native.HBMA_FORCE_WAVE_PER_BLOCK}[args.hbma_kernel]
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
-             (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0)
+             (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule, graph=args.graph,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
                        lat_depth=args.lat_depth, tuning=tuning)
@@ -369,6 +369,8 @@ def main() -> None:
                     help="pipelined: let the segmentation fork its heavy attempts to a side stream")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="N = 1: after the timed steps, run back-to-back steps for this long and report sustained_ms_per_step (0 = skip)")
+    ap.add_argument("--inline-rmse", action="store_true",
+                    help="pipelined: RANSAC keeps its in-order RMSE sum inside its kernel (A/B of the deferred form)")
     ap.add_argument("--narrow-attempts", action="store_true",
                     help="segmentation: one workgroup per (frame, k-means attempt) even on small shards of large fields (A/B of the multi-launch form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -71,6 +71,7 @@ struct ClipEncoderConfig {
   uint32_t lat_depth = 0;               // pipelined: iterations RANSAC + segmentation get, 1..3; 0 = 2 (1 with graph)
   bool standalone_shapes = false;       // pipelined: keep the latency-bound stages' stand-alone launch shapes
   bool segment_fork = false;            // pipelined: let the segmentation fork its heavy attempts to a side stream
+  bool inline_rmse = false;             // pipelined: keep RANSAC's in-order RMSE sum inside its kernel instead of beside the segmentation
   bool narrow_attempts = false;         // segmentation: one workgroup per (frame, attempt) whatever the shard size (SVC_LAUNCH_NO_WIDE)
 };
 

@@ -28,6 +28,7 @@ typedef struct svc_clip svc_clip;
 
 #define SVC_CLIP_TUNE_STANDALONE_SHAPES 1u /* pipelined: RANSAC / segmentation keep their stand-alone launch shapes */
 #define SVC_CLIP_TUNE_SEGMENT_FORK 2u      /* pipelined: the segmentation may fork its heavy attempts to a side stream */
+#define SVC_CLIP_TUNE_INLINE_RMSE 8u       /* pipelined: RANSAC keeps its in-order RMSE sum inside its kernel */
 #define SVC_CLIP_TUNE_NARROW_ATTEMPTS 4u   /* segmentation: never spread a heavy frame's k-means attempts over workgroups */
 
 typedef struct svc_clip_config {

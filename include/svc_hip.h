@@ -145,11 +145,25 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
  * one-workgroup form; results are identical. */
 #define SVC_LAUNCH_WIDE 4u
 #define SVC_LAUNCH_NO_WIDE 8u
+/* SVC_LAUNCH_DEFER_RMSE (svc_hip_ransac_frames_ex only): leave out the in-order f32 RMSE sum over the inliers -- the
+ * kernel's serial tail (one dependent add per MV block: 34 us at 1080p, 134 us at 4K), which nothing downstream of RANSAC
+ * needs.  d_gm_xy, d_inlier_mask and d_inlier_count are final when the launch ends; d_rmse is final only for frames whose
+ * inlier count is below subset_sz (libs/motion.cpp:240-242).  The caller completes it with svc_hip_ransac_rmse_frames() on
+ * any stream ordered behind this launch; the bytes are the undeferred call's. */
+#define SVC_LAUNCH_DEFER_RMSE 16u
 int svc_hip_ransac_frames_ex(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
                              svc_ransac_params params, const uint32_t* d_samples,
                              uint32_t iter_count, float* d_gm_xy, float* d_rmse,
                              uint8_t* d_inlier_mask, uint32_t* d_inlier_count, uint32_t flags,
                              void* stream);
+
+/* The RMSE of libs/motion.cpp:258-259 (Rmse, :165-180) from the outputs of a RANSAC launch: sqrt(mean over the inliers,
+ * summed in index order in f32, of |mv - gm|^2) for every frame with at least subset_sz inliers; other frames' d_rmse is
+ * left as it is.  Completes svc_hip_ransac_frames_ex(..., SVC_LAUNCH_DEFER_RMSE, ...); idempotent after a full call. */
+int svc_hip_ransac_rmse_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames,
+                               svc_ransac_params params, const float* d_gm_xy,
+                               const uint8_t* d_inlier_mask, const uint32_t* d_inlier_count,
+                               float* d_rmse, void* stream);
 
 /* In-repo part of the segmentation glue, libs/encoder.cpp:507-513 + :549-551:
  * foreground = not a RANSAC inlier; d_block_types [n_frames][blocks] gets 0

@@ -168,6 +168,18 @@ int svc_hip_ransac_frames_ex(const float* d_mv_xy, uint32_t blocks, uint32_t n_f
                        d_inlier_mask, d_inlier_count, flags, static_cast<hipStream_t>(stream));
 }
 
+int svc_hip_ransac_rmse_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_frames, svc_ransac_params params,
+                               const float* d_gm_xy, const uint8_t* d_inlier_mask, const uint32_t* d_inlier_count,
+                               float* d_rmse, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  SVC_REQUIRE(d_mv_xy && d_gm_xy && d_rmse && d_inlier_mask && d_inlier_count, "ransac rmse: null pointer");
+  SVC_REQUIRE(params.subset_sz > 0 && blocks >= params.subset_sz, "ransac rmse: motion field of %u smaller than subset %u", blocks,
+              params.subset_sz);
+  SVC_REQUIRE(aligned(d_mv_xy, 8), "ransac rmse: motion field must be 8-byte aligned");
+  return launch_ransac_rmse(d_mv_xy, blocks, n_frames, params, d_gm_xy, d_inlier_mask, d_inlier_count, d_rmse,
+                            static_cast<hipStream_t>(stream));
+}
+
 int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks, uint32_t n_frames,
                                 uint32_t* d_block_types, void* stream) {
   if (n_frames == 0) return SVC_OK;  // empty batch: nothing to enqueue

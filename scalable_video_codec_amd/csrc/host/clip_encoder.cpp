@@ -78,8 +78,9 @@ struct ClipEncoder::Impl {
   DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records;
   DevBuf<float> mv[kSets], mad[kSets], gm[kSets], rmse[kSets], coeffs;
   DevBuf<uint32_t> count[kSets], types[kSets], samples;
-  hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {};
-  bool halo_recorded[2] = {false, false}, join_pending[kSets] = {};
+  hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {}, e_rfork = nullptr, e_rmse[kSets] = {};
+  bool halo_recorded[2] = {false, false}, join_pending[kSets] = {}, rmse_pending[kSets] = {};
+  bool defer_rmse = false;  // pipelined, no graph, large fields: RANSAC leaves its in-order RMSE sum to a kernel on sC (nothing downstream needs it)
   uint64_t iter = 0, fork_iter[kSets] = {};
   void* comm = nullptr;
   HaloFn halo;
@@ -111,7 +112,8 @@ struct ClipEncoder::Impl {
     for (auto& v : timed)
       for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {e_pyr[0], e_pyr[1], e_halo[0], e_halo[1], e_fork, e_join[0], e_join[1], e_join[2], e_join[3], e_join[4]})
+    for (hipEvent_t e : {e_pyr[0], e_pyr[1], e_halo[0], e_halo[1], e_fork, e_rfork, e_join[0], e_join[1], e_join[2], e_join[3], e_join[4],
+                         e_rmse[0], e_rmse[1], e_rmse[2], e_rmse[3], e_rmse[4]})
       if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {sM, sL[0], sL[1], sL[2], sC})
       if (s) (void)hipStreamDestroy(s);
@@ -182,8 +184,21 @@ struct ClipEncoder::Impl {
     Run(Stage::kRansac, st, timing, [&] {
       Hip(hipMemsetAsync(gm[b].p, 0, gm[b].bytes(), st), "hipMemsetAsync");  // in/out, libs/motion.cpp:241-242
       Abi(svc_hip_ransac_frames_ex(mv[b].p, blocks, sh.pairs, c.ransac, samples.p, iters, gm[b].p, rmse[b].p, mask[b].p,
-                                   count[b].p, lat_flags, st), "svc_hip_ransac_frames");
+                                   count[b].p, lat_flags | (defer_rmse ? SVC_LAUNCH_DEFER_RMSE : 0u), st), "svc_hip_ransac_frames");
     });
+    if (defer_rmse) {
+      // the serial tail of RANSAC (one dependent f32 add per MV block) beside the segmentation: it reads what the launch
+      // above left (gm, mask, count: final) and is picked up with the step's join.  On the COMMUNICATION stream, not a
+      // stream of its own: HIP multiplexes streams onto four hardware queues, and a fifth stream shares the main stream's
+      // queue -- its 0.13 ms single-wave kernel then holds every main-stream kernel back (measured: C5 2.43 -> 2.95 ms
+      // per step).  The halo that shares this stream has a whole iteration to arrive.
+      Hip(hipEventRecord(e_rfork, st), "hipEventRecord");
+      Hip(hipStreamWaitEvent(sC, e_rfork, 0), "hipStreamWaitEvent");
+      Abi(svc_hip_ransac_rmse_frames(mv[b].p, blocks, sh.pairs, c.ransac, gm[b].p, mask[b].p, count[b].p, rmse[b].p, sC),
+          "svc_hip_ransac_rmse_frames");
+      Hip(hipEventRecord(e_rmse[b], sC), "hipEventRecord");
+      rmse_pending[b] = true;
+    }
     Run(Stage::kSegment, st, timing, [&] {
       if (c.segmentation)
         Abi(svc_hip_segment_frames_ex(mask[b].p, mv[b].p, mfw, mfh, sh.pairs, c.mv_block, c.mv_block, c.segment,
@@ -227,6 +242,10 @@ struct ClipEncoder::Impl {
     fork_iter[Set(l)] = iter;
   }
   void JoinLat(uint64_t l) {
+    if (rmse_pending[Set(l)]) {  // the set's motion field is rewritten by a later motion search on this stream
+      Hip(hipStreamWaitEvent(sM, e_rmse[Set(l)], 0), "hipStreamWaitEvent");
+      rmse_pending[Set(l)] = false;
+    }
     if (!join_pending[Set(l)]) return;
     Hip(hipStreamWaitEvent(sM, e_join[Set(l)], 0), "hipStreamWaitEvent");
     join_pending[Set(l)] = false;
@@ -361,8 +380,16 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   m.depth = 1;
   if (pipelined && !c.graph) m.depth = c.lat_depth ? (int)c.lat_depth : 2;
   m.nsets = !pipelined ? 1 : c.graph ? 4 : m.depth + 2;  // hipGraph replay: the set must also fix the pyramid parity
+  // not while capturing: a fork out of a stream that is itself a fork of the capture's origin breaks hipStreamEndCapture
+  // and only where the chain is long enough to matter: 0.13 ms at 4K against 0.03 ms at 1080p, where it measures neutral
+  // (profiles/r03_ab_defer_rmse.txt)
+  m.defer_rmse = pipelined && !c.graph && !c.inline_rmse && m.blocks > 8192;
   Hip(hipStreamCreateWithFlags(&m.sM, hipStreamNonBlocking), "hipStreamCreate");
   Hip(hipStreamCreateWithFlags(&m.sC, hipStreamNonBlocking), "hipStreamCreate");
+  if (m.defer_rmse) {
+    Hip(hipEventCreateWithFlags(&m.e_rfork, hipEventDisableTiming), "hipEventCreate");
+    for (int b = 0; b < m.nsets; ++b) Hip(hipEventCreateWithFlags(&m.e_rmse[b], hipEventDisableTiming), "hipEventCreate");
+  }
   for (int k = 0; k < m.depth; ++k) Hip(hipStreamCreateWithFlags(&m.sL[k], hipStreamNonBlocking), "hipStreamCreate");
   for (hipEvent_t* e : {&m.e_pyr[0], &m.e_pyr[1], &m.e_halo[0], &m.e_halo[1], &m.e_fork})
     Hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
@@ -543,6 +570,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.standalone_shapes = (k->tuning & SVC_CLIP_TUNE_STANDALONE_SHAPES) != 0;
     c.segment_fork = (k->tuning & SVC_CLIP_TUNE_SEGMENT_FORK) != 0;
     c.narrow_attempts = (k->tuning & SVC_CLIP_TUNE_NARROW_ATTEMPTS) != 0;
+    c.inline_rmse = (k->tuning & SVC_CLIP_TUNE_INLINE_RMSE) != 0;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
     h->enc.reset(new svc::ClipEncoder(c));

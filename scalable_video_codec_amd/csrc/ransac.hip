@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
 // on a per-frame condition.
 constexpr uint32_t kPassModels = 16;
 
-template <uint32_t T, uint32_t PER, uint32_t F>
+// DEFER: the in-order RMSE sum over the inliers (the kernel's serial tail, needed by nothing downstream) is left to
+// ransac_rmse_kernel on another stream; gm, mask and count are final when this kernel ends either way.
+template <uint32_t T, uint32_t PER, uint32_t F, bool DEFER>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_reg_kernel(RansacArgs a, uint32_t n_frames) {
   constexpr uint32_t G = T / F, GW = G / 64;  // lanes and waves per frame
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];  // F staging areas of kChunk float2
@@ -416,7 +418,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void 
   // ---- RMSE (motion.cpp:258-259, :165-180): terms in parallel, the sums in order -- lane f of the
   // first wave walks frame f's terms, all F chains in the same instructions
   float acc = 0.f;
-  for (uint32_t base = 0; base < a.blocks; base += 2 * kChunk) {
+  if (DEFER) __syncthreads();  // s_out is read below
+  for (uint32_t base = 0; !DEFER && base < a.blocks; base += 2 * kChunk) {
     const uint32_t n = min(2 * kChunk, a.blocks - base);
     float* terms = reinterpret_cast<float*>(s_stage);
 #pragma unroll
@@ -452,8 +455,42 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void 
     }
     a.gm[2 * f] = s_out[tid][0];  // published by the frame's own group
     a.gm[2 * f + 1] = s_out[tid][1];
-    a.rmse[f] = r;
+    if (!DEFER || fw) a.rmse[f] = r;
     a.count[f] = bn;
+  }
+}
+
+// The RMSE of frames whose model is the mean of their inliers (motion.cpp:258-259, :165-180), from what the RANSAC
+// kernel left: final gm, inlier mask, inlier count.  Terms in parallel into LDS, the f32 sum strictly in index order by
+// one lane per frame (non-inliers were staged as +0.0f, which leaves the sum unchanged) -- the same arithmetic as the tail
+// of ransac_reg_kernel, so the same bits.  Frames that kept the best subset's model (count < subset, :240-242) already
+// have their RMSE and are left alone.  F frames per workgroup: their chains run as lanes of one wave (see above).
+template <uint32_t F>
+__global__ __launch_bounds__(256) void ransac_rmse_kernel(RansacArgs a, uint32_t n_frames) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];  // F staging areas of 2 * kChunk floats
+  const uint32_t tid = threadIdx.x;
+  float acc = 0.f;
+  for (uint32_t base = 0; base < a.blocks; base += 2 * kChunk) {
+    const uint32_t n = min(2 * kChunk, a.blocks - base);
+    for (uint32_t g = 0; g < F; ++g) {
+      const uint32_t f = min(blockIdx.x * F + g, n_frames - 1);
+      const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)f * a.blocks + base;
+      const uint8_t* mask = a.mask + (size_t)f * a.blocks + base;
+      const float gx = a.gm[2 * f], gy = a.gm[2 * f + 1];
+      float* terms = reinterpret_cast<float*>(dyn_lds) + (size_t)g * 2 * kChunk;
+      for (uint32_t i = tid; i < n; i += 256) {
+        const float2 m = mv[i];
+        const float dx = m.x - gx, dy = m.y - gy;
+        terms[i] = mask[i] ? dx * dx + dy * dy : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < F) serial_sum1(reinterpret_cast<const float*>(dyn_lds) + (size_t)tid * 2 * kChunk, n, acc);
+    __syncthreads();
+  }
+  if (tid < F && blockIdx.x * F + tid < n_frames) {
+    const uint32_t f = blockIdx.x * F + tid, bn = a.count[f];
+    if (bn >= a.subset) a.rmse[f] = sqrtf(acc / (float)bn);
   }
 }
 
@@ -495,19 +532,49 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ran
   // kernel's waves; a 1 024-lane workgroup of this kernel (4 waves x 114-128 VGPRs on every SIMD) needs an empty CU and
   // would only start once the kernel it was meant to run beside has drained.  Alone it is slower (0.10 vs 0.08 ms for
   // 300 frames at 1080p: a quarter of the lanes for the parallel phases, the same serial RMSE chain).
+  // SVC_LAUNCH_DEFER_RMSE: the caller runs launch_ransac_rmse() itself (on another stream); only the register kernels
+  // have the form without the tail, the fallback for fields above 32 768 blocks computes the RMSE regardless
+  const bool defer = (flags & SVC_LAUNCH_DEFER_RMSE) != 0;
+#define SVC_RANSAC_LAUNCH(T, PER, F, GRID, LDS)                                                                   \
+  do {                                                                                                            \
+    if (defer) hipLaunchKernelGGL((ransac_reg_kernel<T, PER, F, true>), dim3(GRID), dim3(T), LDS, stream, a, n_frames);  \
+    else hipLaunchKernelGGL((ransac_reg_kernel<T, PER, F, false>), dim3(GRID), dim3(T), LDS, stream, a, n_frames);       \
+  } while (0)
   if ((flags & SVC_LAUNCH_BESIDE) && blocks > 8 * 256 && blocks <= 32 * 256)
-    hipLaunchKernelGGL((ransac_reg_kernel<256, 32, 1>), dim3(n_frames), dim3(256), kStage, stream, a, n_frames);
+    SVC_RANSAC_LAUNCH(256, 32, 1, n_frames, kStage);
   else if (blocks <= 8 * 256)
-    hipLaunchKernelGGL((ransac_reg_kernel<256, 8, 1>), dim3(n_frames), dim3(256), kStage, stream, a, n_frames);
+    SVC_RANSAC_LAUNCH(256, 8, 1, n_frames, kStage);
   else if (blocks <= 8 * 1024 && n_frames <= 256)  // one workgroup per CU as it is
-    hipLaunchKernelGGL((ransac_reg_kernel<1024, 8, 1>), dim3(n_frames), dim3(1024), kStage, stream, a, n_frames);
+    SVC_RANSAC_LAUNCH(1024, 8, 1, n_frames, kStage);
   else if (blocks <= 16 * 512)  // more frames than CUs: two frames per workgroup rather than two workgroups per CU
-    hipLaunchKernelGGL((ransac_reg_kernel<1024, 16, 2>), dim3((n_frames + 1) / 2), dim3(1024), 2 * kStage, stream, a, n_frames);
+    SVC_RANSAC_LAUNCH(1024, 16, 2, (n_frames + 1) / 2, 2 * kStage);
   else if (blocks <= 32 * 1024)
-    hipLaunchKernelGGL((ransac_reg_kernel<1024, 32, 1>), dim3(n_frames), dim3(1024), kStage, stream, a, n_frames);
+    SVC_RANSAC_LAUNCH(1024, 32, 1, n_frames, kStage);
   else
     hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), 0, stream, a);
+#undef SVC_RANSAC_LAUNCH
   return check_launch("ransac_kernel");
+}
+
+int launch_ransac_rmse(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ransac_params params, const float* d_gm,
+                       const uint8_t* d_mask, const uint32_t* d_count, float* d_rmse, hipStream_t stream) {
+  if (n_frames == 0) return SVC_OK;
+  RansacArgs a;
+  a.mv = d_mv;
+  a.samples = nullptr;
+  a.blocks = blocks;
+  a.iters = 0;
+  a.subset = params.subset_sz;
+  a.thresh = params.inlier_thresh;
+  a.gm = const_cast<float*>(d_gm);
+  a.rmse = d_rmse;
+  a.mask = const_cast<uint8_t*>(d_mask);
+  a.count = const_cast<uint32_t*>(d_count);
+  constexpr size_t kTerms = 2 * kChunk * sizeof(float);
+  // more frames than CUs: two chains per workgroup, as lanes of one wave, rather than two workgroups per CU
+  if (n_frames > 256) hipLaunchKernelGGL((ransac_rmse_kernel<2>), dim3((n_frames + 1) / 2), dim3(256), 2 * kTerms, stream, a, n_frames);
+  else hipLaunchKernelGGL((ransac_rmse_kernel<1>), dim3(n_frames), dim3(256), kTerms, stream, a, n_frames);
+  return check_launch("ransac_rmse_kernel");
 }
 
 }  // namespace svc

@@ -84,6 +84,8 @@ int launch_ransac(const float* d_mv, uint32_t blocks, uint32_t n_frames,
                   svc_ransac_params params, const uint32_t* d_samples, uint32_t iters,
                   float* d_gm, float* d_rmse, uint8_t* d_mask, uint32_t* d_count,
                   uint32_t flags, hipStream_t stream);
+int launch_ransac_rmse(const float* d_mv, uint32_t blocks, uint32_t n_frames, svc_ransac_params params, const float* d_gm,
+                       const uint8_t* d_mask, const uint32_t* d_count, float* d_rmse, hipStream_t stream);
 int launch_block_types(const uint8_t* d_mask, uint64_t n, uint32_t* d_types, hipStream_t stream);
 int launch_serialize(const float* d_planes, uint64_t plane_elems, uint32_t n_frames, const uint32_t* d_types,
                      uint32_t mv_blocks, uint32_t frame_w, uint32_t frame_h, uint32_t tbw, uint32_t tbh,

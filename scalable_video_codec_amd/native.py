@@ -60,6 +60,7 @@ SIGNATURES = {
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "svc_hip_ransac_frames_ex": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "svc_hip_ransac_rmse_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _vp, _vp, _vp, _vp]),
     "svc_hip_segment_frames_ex": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, SegmentParams, _u64, _vp, _u64, _vp, _u32, _vp]),
     "svc_hip_block_types_frames": (C.c_int, [_vp, _u32, _u32, _vp, _vp]),
     "svc_hip_probe_stream": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp]),
@@ -197,6 +198,19 @@ def ransac_frames(mv: torch.Tensor, samples: torch.Tensor, gm_in: Optional[torch
                                            iters, _dev(gm, torch.float32), _dev(rmse, torch.float32),
                                            _dev(mask, torch.uint8), _dev(count, torch.int32), flags, _stream()))
     return gm, rmse, mask, count
+
+
+def ransac_rmse_frames(mv: torch.Tensor, gm: torch.Tensor, mask: torch.Tensor, count: torch.Tensor, rmse: torch.Tensor,
+                       subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5) -> torch.Tensor:
+    """Completes a ransac_frames(..., flags=LAUNCH_DEFER_RMSE) call: the in-order RMSE over the inliers, in place."""
+    frames, blocks = mv.shape[0], mv.shape[1]
+    p = RansacParams(subset_sz, inlier_thresh, success_prob, inlier_ratio)
+    _check(load().svc_hip_ransac_rmse_frames(_dev(mv, torch.float32), blocks, frames, p, _dev(gm, torch.float32),
+                                             _dev(mask, torch.uint8), _dev(count, torch.int32), _dev(rmse, torch.float32), _stream()))
+    return rmse
+
+
+LAUNCH_BESIDE, LAUNCH_NO_FORK, LAUNCH_WIDE, LAUNCH_NO_WIDE, LAUNCH_DEFER_RMSE = 1, 2, 4, 8, 16
 
 
 def block_types_frames(mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

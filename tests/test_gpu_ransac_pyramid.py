@@ -98,6 +98,18 @@ def test_ransac_frames_every_launch_shape(native, oracle, frames, n, subset, fla
     gm, rmse, mask, count = native.ransac_frames(torch.from_numpy(mv).cuda(), torch.from_numpy(samples).cuda(),
                                                  gm_in=torch.from_numpy(gm_in).cuda(), flags=flags, **p)
     torch.cuda.synchronize()
+    # SVC_LAUNCH_DEFER_RMSE + svc_hip_ransac_rmse_frames (the in-order RMSE sum as a launch of its own, what the pipelined
+    # driver runs beside the segmentation): the same bytes, every frame -- those that keep the best subset's model
+    # (count < subset: their RMSE comes from the first launch and must be left alone) included
+    gm2, rmse2, mask2, count2 = native.ransac_frames(torch.from_numpy(mv).cuda(), torch.from_numpy(samples).cuda(),
+                                                     gm_in=torch.from_numpy(gm_in).cuda(), flags=flags | native.LAUNCH_DEFER_RMSE, **p)
+    native.ransac_rmse_frames(torch.from_numpy(mv).cuda(), gm2, mask2, count2, rmse2, **p)
+    torch.cuda.synchronize()
+    assert torch.equal(gm2, gm) and torch.equal(mask2, mask) and torch.equal(count2, count)
+    assert rmse2.cpu().numpy().tobytes() == rmse.cpu().numpy().tobytes()
+    native.ransac_rmse_frames(torch.from_numpy(mv).cuda(), gm, mask, count, rmse2, **p)  # idempotent after a full call
+    torch.cuda.synchronize()
+    assert rmse2.cpu().numpy().tobytes() == rmse.cpu().numpy().tobytes()
     gm, rmse, mask, count = gm.cpu().numpy(), rmse.cpu().numpy(), mask.cpu().numpy(), count.cpu().numpy()
     for f in check:
         gm_o, rmse_o, inl_o = oracle.ransac(mv[f], samples[f].astype(np.uint32), gm_in=tuple(gm_in[f]), **p)
