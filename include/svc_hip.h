@@ -279,7 +279,7 @@ int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32
 /* Dct (+ optional quant) that emits the serialised records DIRECTLY instead of coefficient
  * planes: one kernel = libs/encoder.cpp:638-650 (convertTo, Dct, SerializeEncodedFrame) with
  * no extra pass over HBM.  Same bytes as svc_hip_dct[_quant]_frames followed by
- * svc_hip_serialize_frames(frame_w, emit_frame_h, ...).  Square transform block (8 or 16);
+ * svc_hip_serialize_frames(frame_w, emit_frame_h, ...).  Square transform block (even side up to 64; 8 and 16 take the tuned kernel);
  * frame_w must already be the padded width (the fused path does not reproduce the reference's
  * unpadded-width row stride, libs/encoder.cpp:258 -- use svc_hip_serialize_frames for that);
  * emit_frame_h = the height SerializeEncodedFrame is given (the encoder passes the unpadded

@@ -326,6 +326,9 @@ struct DctGenArgs {
   const uint32_t* types;
   uint32_t mv_bw, mv_bh, mfw, mv_blocks;
   float fg_step, bg_step, fg_inv, bg_inv;
+  uint8_t* records;         // WIRE: serialised records (libs/encoder.cpp:222-269) instead of planes; square blocks only
+  uint64_t records_stride;  // bytes per frame
+  uint32_t emit_bands;      // tile rows SerializeEncodedFrame visits (ceil(emit_frame_h / bh))
 };
 
 // C[k][n] = s_k cos(pi (2n + 1) k / 2N), s_0 = sqrt(1/N), s_k = sqrt(2/N): the orthonormal DCT-II of
@@ -336,7 +339,10 @@ __device__ __forceinline__ double dct_basis(uint32_t k, uint32_t n, uint32_t N) 
   return __builtin_sqrt(s) * cospi((double)j / (double)(2 * N));
 }
 
-template <bool QUANT>
+// WIRE (square blocks): the coefficient of channel c at (v, u) of tile (band, tx) goes to dword 1 + c * bw * bh + v * bh + u
+// of the tile's record, the tile's type word to dword 0 -- the bytes of the plane form followed by serialize_kernel
+// (wire.hip), without the two extra passes over 25 MB per frame.
+template <bool QUANT, bool WIRE>
 __global__ __launch_bounds__(256) void dct_general_kernel(DctGenArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t gen_lds[];
   const uint32_t tid = threadIdx.x, bw = a.bw, bh = a.bh, sw = a.sw;
@@ -378,12 +384,21 @@ __global__ __launch_bounds__(256) void dct_general_kernel(DctGenArgs a) {
         double acc = 0.0;
         for (uint32_t m = 0; m < bh; ++m) acc = __builtin_fma(cr[m], yrow[m * sw + x], acc);
         float f = (float)acc;
-        if (QUANT) {
+        uint32_t t = 0;
+        if (QUANT || WIRE)
           // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249); background (0) takes bg_step
-          const uint32_t t = a.types[(size_t)frame * a.mv_blocks + (y0 / a.mv_bh) * a.mfw + (x0 + x) / a.mv_bw];
-          f = quant1_fast(f, t == 0 ? a.bg_step : a.fg_step, t == 0 ? a.bg_inv : a.fg_inv);
+          t = a.types[(size_t)frame * a.mv_blocks + (y0 / a.mv_bh) * a.mfw + (x0 + x) / a.mv_bw];
+        if (QUANT) f = quant1_fast(f, t == 0 ? a.bg_step : a.fg_step, t == 0 ? a.bg_inv : a.fg_inv);
+        if (WIRE) {
+          if (band < a.emit_bands) {
+            const uint32_t u = x % bw, tile = band * (a.w / bw) + (x0 + x) / bw, rec_dw = 1 + 3 * bw * bh;
+            uint32_t* rec = reinterpret_cast<uint32_t*>(a.records + (size_t)frame * a.records_stride) + (size_t)tile * rec_dw;
+            rec[1 + c * bw * bh + v * bh + u] = __float_as_uint(f);
+            if (c == 0 && v == 0 && u == 0) rec[0] = t;
+          }
+        } else {
+          plane[(size_t)(y0 + v) * a.w + x0 + x] = f;
         }
-        plane[(size_t)(y0 + v) * a.w + x0 + x] = f;
       }
       __syncthreads();
     }
@@ -394,7 +409,12 @@ constexpr uint32_t kDctGenMaxSide = 64;
 
 static int launch_dct_general(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h,
                               uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw, uint32_t mv_bh,
-                              uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes, hipStream_t stream) {
+                              uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes, hipStream_t stream,
+                              uint8_t* d_records = nullptr, uint64_t records_stride = 0, uint32_t emit_h = 0) {
+  const bool wire = d_records != nullptr;
+  if (wire && (bw != bh || w % bw != 0))
+    return fail(SVC_ERR_UNSUPPORTED, "dct_records: the fused record emitter takes square transform blocks that divide the frame "
+                                     "width; for %ux%u call svc_hip_dct[_quant]_frames, then svc_hip_serialize_frames", bw, bh);
   // cv::dct (libs/encoder.cpp:335) takes even sizes, and single rows / columns of even length
   if ((bw > 1 && bw % 2) || (bh > 1 && bh % 2) || (bw == 1 && bh == 1))
     return fail(SVC_ERR_INVALID_ARG, "dct: transform block %ux%u: cv::dct implements even sizes only", bw, bh);
@@ -415,18 +435,28 @@ static int launch_dct_general(const uint8_t* d_bgr, uint64_t frame_stride, uint3
   if (total > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "dct: %llu strips exceed one launch", (unsigned long long)total);
   a.total_strips = (uint32_t)total;
   a.planes = d_planes;
-  if (quant) {
+  a.records = d_records;
+  a.records_stride = records_stride;
+  a.emit_bands = wire ? div_up(emit_h, bh) : 0;
+  if (quant || wire) {
     a.types = d_types;
     a.mv_bw = mv_bw; a.mv_bh = mv_bh;
     a.mfw = w / mv_bw;
     a.mv_blocks = a.mfw * (h / mv_bh);
+  }
+  if (quant) {
     a.fg_step = (float)fg_step; a.bg_step = (float)bg_step;
     a.fg_inv = 1.0f / a.fg_step; a.bg_inv = 1.0f / a.bg_step;
   }
   const size_t lds = 8 * ((size_t)bw * (bw + 1) + (size_t)bh * (bh + 1) + (size_t)bh * a.sw) + 4 * (size_t)bh * a.sw;
   const uint32_t grid = (uint32_t)(total < 4096 ? total : 4096);
-  if (quant) hipLaunchKernelGGL((dct_general_kernel<true>), dim3(grid), dim3(256), lds, stream, a);
-  else hipLaunchKernelGGL((dct_general_kernel<false>), dim3(grid), dim3(256), lds, stream, a);
+  if (wire) {
+    if (quant) hipLaunchKernelGGL((dct_general_kernel<true, true>), dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((dct_general_kernel<false, true>), dim3(grid), dim3(256), lds, stream, a);
+  } else {
+    if (quant) hipLaunchKernelGGL((dct_general_kernel<true, false>), dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((dct_general_kernel<false, false>), dim3(grid), dim3(256), lds, stream, a);
+  }
   return check_launch("dct_general_kernel");
 }
 
@@ -436,13 +466,9 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
                hipStream_t stream, uint8_t* d_records, uint64_t records_stride, uint32_t emit_h) {
   const bool wire = d_records != nullptr;
   const bool fast = bw == bh && (bw == 8 || bw == 16) && w % 16 == 0;
-  if (!fast) {
-    if (wire)
-      return fail(SVC_ERR_UNSUPPORTED, "dct_records: the fused record emitter takes 8x8 / 16x16 blocks on frames a multiple of "
-                                       "16 wide; for %ux%u call svc_hip_dct[_quant]_frames, then svc_hip_serialize_frames", bw, bh);
+  if (!fast)
     return launch_dct_general(d_bgr, frame_stride, n_frames, w, h, bw, bh, d_types, mv_bw, mv_bh, fg_step, bg_step, quant,
-                              d_planes, stream);
-  }
+                              d_planes, stream, d_records, records_stride, emit_h);
   DctArgs a{};
   a.bgr = d_bgr;
   a.frame_stride = frame_stride;

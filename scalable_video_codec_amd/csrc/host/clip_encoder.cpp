@@ -93,7 +93,7 @@ struct ClipEncoder::Impl {
   bool fork_early = false;
   // pipelined schedule: RANSAC + segmentation run beside the main stream's kernels and ask for shapes that fit there
   uint32_t lat_flags = 0;
-  bool fused_records = false;  // wire output straight from the 8x8 / 16x16 transform kernel
+  bool fused_records = false;  // wire output straight from the transform kernel (square transform blocks)
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
@@ -405,7 +405,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
     m.mask[b].Alloc((size_t)P * m.blocks); m.count[b].Alloc(P); m.types[b].Alloc((size_t)P * m.blocks);
   }
   for (int k = 0; k < m.depth; ++k) m.seg_ws[k].Alloc(m.seg_ws_bytes);
-  m.fused_records = c.wire && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) && m.pw % 16 == 0;
+  m.fused_records = c.wire && c.dct_block_w == c.dct_block_h && c.dct_block_w <= 64 && c.dct_block_w % 2 == 0;
   if (transform) {
     if (c.wire) m.records.Alloc((size_t)P * m.record_bytes);
     if (!c.wire || !m.fused_records) m.coeffs.Alloc((size_t)P * 3 * m.plane_elems);

@@ -163,7 +163,9 @@ def test_dct_block_preconditions(native):
     with pytest.raises(native.SvcError) as e:
         native.dct_host(np.zeros((30, 32, 3), np.uint8), 8)
     assert e.value.status == native.SVC_ERR_INVALID_ARG
-    with pytest.raises(native.SvcError) as e:  # the fused record emitter is 8x8 / 16x16 only: two calls for the rest
-        native.dct_records_frames(torch.zeros((1, 32, 32, 3), dtype=torch.uint8, device="cuda"), 4,
-                                  torch.zeros((1, 4), dtype=torch.int32, device="cuda"))
+    with pytest.raises(native.SvcError) as e:  # the fused record emitter takes square transform blocks up to 64 x 64
+        native.dct_records_frames(torch.zeros((1, 256, 256, 3), dtype=torch.uint8, device="cuda"), 128,
+                                  torch.zeros((1, 4), dtype=torch.int32, device="cuda"), mv_block=128)
     assert e.value.status == native.SVC_ERR_UNSUPPORTED
+    native.dct_records_frames(torch.zeros((1, 32, 32, 3), dtype=torch.uint8, device="cuda"), 4,
+                              torch.zeros((1, 4), dtype=torch.int32, device="cuda"))  # 4 x 4: the general kernel emits records

@@ -89,20 +89,22 @@ def test_pipeline_stream_roundtrip(native, oracle):
             assert np.array_equal(blk, coeffs[f, :, ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8])
 
 
-@pytest.mark.parametrize("block", [8, 16])
+@pytest.mark.parametrize("block,w,mvb", [(8, 160, 16), (16, 160, 16), (2, 160, 16), (4, 160, 16), (32, 160, 32), (64, 192, 64), (8, 168, 8)])
 @pytest.mark.parametrize("quant", [False, True])
-def test_fused_dct_records_equal_dct_then_serialize(native, block, quant):
-    """One kernel (DCT [+quant] -> records) must emit exactly the bytes of the two-step path."""
+def test_fused_dct_records_equal_dct_then_serialize(native, block, w, mvb, quant):
+    """One kernel (DCT [+quant] -> records) must emit exactly the bytes of the two-step path: the tuned 8x8 / 16x16 kernels,
+    and the general kernel for every other square transform block (2 .. 64) and for 8x8 on a width that is not a multiple of
+    16 (libs/encoder.cpp:222-269 takes any block)."""
     rng = np.random.default_rng(block + quant)
-    n, h, w = 3, 96, 160
+    n, h = 3, 192 if block == 64 else 96
     bgr = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
-    mfw, mfh = w // 16, h // 16
+    mfw, mfh = w // mvb, h // mvb
     types = torch.from_numpy(rng.integers(0, 4, (n, mfw * mfh)).astype(np.int32)).cuda()
     fg, bg = (2, 640) if quant else (0, 0)
-    planes = native.dct_quant_frames(bgr, block, types, 16, fg, bg) if quant else native.dct_frames(bgr, block)
-    for emit_h in (h, h - 16):  # the decodable layout, and the encoder's "unpadded height" call
-        want = native.serialize_frames(planes, types, w, emit_h, block, block, mfw, mfh)
-        got = native.dct_records_frames(bgr, block, types, 16, fg, bg, emit_h=emit_h)
+    planes = native.dct_quant_frames(bgr, block, types, mvb, fg, bg) if quant else native.dct_frames(bgr, block)
+    for emit_h in (h, h - max(block, 16)):  # the decodable layout, and the encoder's "unpadded height" call
+        want = native.serialize_frames(planes, types, w, emit_h, block, block, mfw, mfh, mv_block=mvb)
+        got = native.dct_records_frames(bgr, block, types, mvb, fg, bg, emit_h=emit_h)
         torch.cuda.synchronize()
         assert got.shape == want.shape and torch.equal(got, want), (block, quant, emit_h)
 
