@@ -58,3 +58,35 @@ def global_motion_cases():
     avgs = [(z[f"avg{i}/mv"], z[f"avg{i}/out"]) for i in range(5)]
     literal = {int(k.split("/r")[1]): z[k] for k in z.files if k.startswith("ebma/r")}
     return avgs, z["ebma/t"], z["ebma/a"], literal
+
+
+# ---- tests/golden/hbma_shapes.npz (make_hbma_shapes_golden.py): every shape of the lane-per-block kernel ----------------
+SHAPE_CASES = [(mb, L, rt << (L - 1)) for mb in (8, 16, 32) for L in range(2, 6) if (mb >> (L - 1)) >= 2
+               for rt in range(1, (2 if mb == 32 else 4) + 1)]
+
+
+def shape_case(mb, levels, r):
+    """Seeded input pyramids of one shape case: 8 x 6 blocks (taller where the top plane must hold the candidate grid), the
+    anchor frame a shifted copy of the tracked one plus +-2 noise and an unrelated patch; 2x2-decimation pyramids."""
+    rng = np.random.default_rng(1000 * mb + 10 * levels + r)
+    f = 1 << (levels - 1)
+    tb, rt = mb >> (levels - 1), r >> (levels - 1)
+    nby = max(6, -(-(tb + 2 * rt) * f // mb))
+    w, h = mb * 8, mb * nby
+    base_t = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    dy, dx = int(rng.integers(-r + 1, r)), int(rng.integers(-r + 1, r))
+    base_a = np.roll(base_t, (dy, dx), (0, 1)).astype(np.int16) + rng.integers(-2, 3, (h, w))
+    base_a = base_a.clip(0, 255).astype(np.uint8)
+    base_a[h // 3: h // 3 + mb, w // 4: w // 4 + 2 * mb] = rng.integers(0, 256, (mb, 2 * mb), dtype=np.uint8)
+    t = [np.ascontiguousarray(base_t[:: 1 << l, :: 1 << l]) for l in range(levels)]
+    a = [np.ascontiguousarray(base_a[:: 1 << l, :: 1 << l]) for l in range(levels)]
+    return t, a
+
+
+def shape_cases():
+    z = load("hbma_shapes.npz")
+    for mb, levels, r in SHAPE_CASES:
+        key = f"b{mb}_l{levels}_r{r}"
+        t, a = shape_case(mb, levels, r)
+        assert sha(t + a) == bytes(z[f"{key}/sha"]).hex(), f"{key}: the seeded inputs no longer regenerate bit for bit"
+        yield key, mb, levels, r, t, a, z[f"{key}/mv"], z[f"{key}/mad"]

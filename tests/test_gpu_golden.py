@@ -32,6 +32,17 @@ def test_hbma_micro(native, case):
         assert np.array_equal(mv, mv_ref) and np.array_equal(mad, mad_ref), (name, flags)
 
 
+@pytest.mark.parametrize("case", list(G.shape_cases()), ids=lambda c: c[0])
+def test_hbma_every_fused_shape_against_the_reference(native, case):
+    """tests/golden/hbma_shapes.npz: the unmodified reference's EstimateMotionHierarchical (libs/motion.cpp:412-465) for every
+    (MV block, levels, search range) the lane-per-block kernel is instantiated for; the forced fused kernel, the dispatcher's
+    choice and the per-level kernel must all reproduce it."""
+    key, mb, levels, r, t, a, mv_ref, mad_ref = case
+    for flags in (native.HBMA_FORCE_FUSED, native.HBMA_AUTO, native.HBMA_FORCE_WAVE_PER_BLOCK):
+        mv, mad = native.hbma_host(t, a, r, mb, mb, flags=flags)
+        assert np.array_equal(mv, mv_ref) and np.array_equal(mad, mad_ref), (key, flags)
+
+
 @pytest.mark.parametrize("case", list(G.ransac_cases()), ids=lambda c: c[0])
 def test_ransac(native, case):
     name, mv, params, samples, gm_ref, rmse_ref, inl_ref = case

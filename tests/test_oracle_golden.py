@@ -36,6 +36,15 @@ def test_hbma_micro_semantics(oracle, case):
     assert np.array_equal(mv, mv_ref) and np.array_equal(mad, mad_ref), name
 
 
+@pytest.mark.parametrize("case", list(G.shape_cases()), ids=lambda c: c[0])
+def test_hbma_shapes_match_reference(oracle, case):
+    """Every (MV block, levels, search range) of tests/golden/hbma_shapes.npz (8x8 / 16x16 / 32x32 blocks, 2 .. 5 levels,
+    R_top 1 .. 4), made by the unmodified reference: the restatement reproduces it."""
+    key, mb, levels, r, t, a, mv_ref, mad_ref = case
+    mv, mad = oracle.hbma(t, a, r, mb, mb)
+    assert np.array_equal(mv, mv_ref) and np.array_equal(mad, mad_ref), key
+
+
 def test_micro_fixtures_hit_their_semantics():
     cases = {c[0]: c for c in G.micro_cases()}
     _, _, _, _, _, _, mv, mad = cases["flat"]
