@@ -525,7 +525,7 @@ def main() -> None:
             tiled = fused and cfg.levels == 4 and cfg.r_top == 1 and pw % 64 == 0 and args.hbma_kernel == "tiled"
             out["roofline"] = {
                 "kernel": "hbma_tiled16_kernel (MAD search, all pyramid levels, windows of levels 2 and 1 staged in LDS)" if tiled else
-                          "hbma_fused16_kernel (MAD search, all pyramid levels, lane per block)" if fused else
+                          "hbma_fused_kernel (MAD search, all pyramid levels, lane per block)" if fused else
                           "hbma_wave_level_kernel (LDS-staged wave-per-block search)",
                 "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": hbma_gbps / HBM_PEAK_GBPS,

@@ -162,7 +162,7 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // and instruction for N = 8, 256 B for N = 16).  No extra HBM traffic versus planar output.
 template <int N, bool QUANT, bool WIRE>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
-  constexpr int kSegPerWg = 256 / N;
+  constexpr int kSegPerWg = 256 / N;  // 512- and 1024-lane workgroups (longer runs per row) measured level or worse: profiles/r03_ab_dct_lanes.txt
   constexpr int kSlab = N == 8 ? kSlab8 : kSlab16;
   __shared__ __attribute__((aligned(16))) uint8_t lds[kSegPerWg * kSlab];
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(TBX* TBY) void hbma_tiled16_kernel(FusedArgs a, uin
   __shared__ __attribute__((aligned(16))) uint8_t lds[G1::BYTES + G2::BYTES];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
 
-  // Region-major order as in hbma_fused16_kernel: XCD x (blockIdx 8 k + x) is given the x-th eighth of the tiles of EVERY
+  // Region-major order as in hbma_fused_kernel: XCD x (blockIdx 8 k + x) is given the x-th eighth of the tiles of EVERY
   // pair, pairs in order, so that the second read of a pyramid (anchor of pair p, tracked frame of pair p + 1) and the
   // margins neighbouring tiles share are served by that XCD's L2.  Speed only.
   const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
