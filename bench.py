@@ -220,14 +220,18 @@ def _checksum(x: torch.Tensor) -> int:
     return int((x.to(torch.int64) * w).sum().item())
 
 
+def hbma_flags_of(args) -> int:
+    return {"auto": native.HBMA_AUTO, "tiled": native.HBMA_FORCE_TILED, "lane": native.HBMA_FORCE_LANE,
+            "wave": native.HBMA_FORCE_WAVE_PER_BLOCK}[args.hbma_kernel]
+
+
 def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, comm):
     """Builds this rank's shard for `mode` ("strong": cfg.frames cut over the ranks; "weak": cfg.frames per rank),
     runs W warm-up and exactly K timed steps between barriers, returns the measurements of this rank."""
     n_cfg = args.frames or cfg.frames
     clip_frames = n_cfg if mode == "strong" else n_cfg * world
     schedule = clipmod.SERIAL if args.schedule == "serial" else clipmod.PIPELINED
-    hbma_flags = {"auto": native.HBMA_AUTO, "tiled": native.HBMA_FORCE_TILED, "lane": native.HBMA_FORCE_LANE,
-                  "wave": native.HBMA_FORCE_WAVE_PER_BLOCK}[args.hbma_kernel]
+    hbma_flags = hbma_flags_of(args)
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
              (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule, graph=args.graph,
@@ -359,8 +363,8 @@ def main() -> None:
     # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The
     # environment variables of the round-2 scripts under tools/ are honoured HERE as defaults, not inside the library.
     ap.add_argument("--hbma-kernel", choices=("auto", "tiled", "lane", "wave"), default=os.environ.get("SVC_HBMA_KERNEL", "auto"),
-                    help="motion search kernel: auto (lane-per-block for the fused shapes, else the per-level kernel), tiled (4 levels / r_top 1: "
-                         "levels 2 and 1 from LDS tiles), lane (lane-per-block, no LDS), wave (per-level general kernel)")
+                    help="motion search kernel: auto (the library's choice: LDS-tiled for 4 levels / r_top 1, lane-per-block for the other fused shapes, "
+                         "else the per-level kernel), tiled (levels 2 and 1 from LDS tiles), lane (lane-per-block, no LDS), wave (per-level general kernel)")
     ap.add_argument("--lat-depth", type=int, default=int(os.environ.get("SVC_LAT_DEPTH", "0")),
                     help="pipelined: iterations RANSAC + segmentation get to finish (1..3; 0 = default 2)")
     ap.add_argument("--standalone-shapes", action="store_true", default=os.environ.get("SVC_LAUNCH_BESIDE", "1") == "0",
@@ -521,12 +525,12 @@ def main() -> None:
             hbma_bytes = cfg.hbma_bytes_per_frame() * info.pairs
             hbma_ms = kt["hbma"] / nl["hbma"]
             hbma_gbps = hbma_bytes / (hbma_ms * 1e-3) / 1e9
-            fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2) and args.hbma_kernel != "wave"
-            tiled = fused and cfg.levels == 4 and cfg.r_top == 1 and pw % 64 == 0 and args.hbma_kernel == "tiled"
+            # the library's own dispatch names the kernel this run launched (svc_hip_hbma_kernel_name)
+            kname = native.hbma_kernel_name(cfg.levels, pw, ph, cfg.search_range, cfg.mv_block, cfg.mv_block, hbma_flags_of(args))
             out["roofline"] = {
-                "kernel": "hbma_tiled16_kernel (MAD search, all pyramid levels, windows of levels 2 and 1 staged in LDS)" if tiled else
-                          "hbma_fused_kernel (MAD search, all pyramid levels, lane per block)" if fused else
-                          "hbma_wave_level_kernel (LDS-staged wave-per-block search)",
+                "kernel": {"hbma_tiled16_kernel": "hbma_tiled16_kernel (MAD search, all pyramid levels, windows of levels 2 and 1 staged in LDS)",
+                           "hbma_fused_kernel": "hbma_fused_kernel (MAD search, all pyramid levels, lane per block)",
+                           "hbma_wave_level_kernel": "hbma_wave_level_kernel (LDS-staged wave-per-block search)"}[kname],
                 "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": hbma_gbps / HBM_PEAK_GBPS,
                 "traffic": traffic("hbma_bytes_per_launch", info.pairs),

@@ -71,7 +71,7 @@ typedef struct svc_segment_params {
 #define SVC_HBMA_FORCE_LANE 8u           /* fused kernel, lane-per-block form without LDS (every fused shape) */
 
 const char* svc_hip_last_error(void);
-int svc_hip_abi_version(void); /* 3 (round 3: additions only -- SVC_HBMA_FORCE_TILED / _LANE, svc_hip_comm_available / _info) */
+int svc_hip_abi_version(void); /* 3 (round 3: additions only -- SVC_HBMA_FORCE_TILED / _LANE, svc_hip_comm_available / _info, svc_hip_hbma_kernel_name) */
 int svc_hip_device_count(int* count);
 
 /* Measurement aid, not part of the hot path: one launch of a plain streaming kernel (dwordx4 per lane,
@@ -101,6 +101,14 @@ int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor,
                        uint32_t search_range, uint32_t block_w, uint32_t block_h,
                        float* d_mv_xy, float* d_min_mad, uint32_t flags,
                        void* stream);
+
+/* Which kernel svc_hip_hbma_pairs launches for these parameters and flags when the pyramids are 16-byte
+ * aligned with a pair stride that is a multiple of 16 (any hipMalloc'ed clip of packed pyramids whose frame
+ * width is a multiple of 16): "hbma_tiled16_kernel", "hbma_fused_kernel" or "hbma_wave_level_kernel".  NULL
+ * with svc_hip_last_error() set where svc_hip_hbma_pairs would return an error.  No GPU work. */
+const char* svc_hip_hbma_kernel_name(uint32_t level_count, uint32_t frame_w, uint32_t frame_h,
+                                     uint32_t search_range, uint32_t block_w, uint32_t block_h,
+                                     uint32_t flags);
 
 /* replaces EstimateMotionExhaustiveSearch, libs/motion.hpp:106-110 / motion.cpp:268-340.
  * Planes are single-level here: pair p's planes sit at base + p * pair_stride_bytes. */

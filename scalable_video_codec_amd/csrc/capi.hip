@@ -15,6 +15,8 @@ static thread_local char g_err[kErrBufSize] = "";
 char* last_error_buf() { return g_err; }
 
 bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
+bool tiled_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
+bool tiled_is_default();
 int launch_hbma_fused(const uint8_t*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t,
                       uint32_t, uint32_t mv_block, float*, float*, int kernel, hipStream_t);
 int launch_hbma_wave(const uint8_t*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t,
@@ -127,6 +129,23 @@ int svc_hip_hbma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64
               "hbma: pair stride %llu smaller than one pyramid", (unsigned long long)pair_stride_bytes);
   return launch_hbma(d_tracked, d_anchor, pair_stride_bytes, n_pairs, level_count, frame_w, frame_h,
                      search_range, block_w, block_h, d_mv_xy, d_min_mad, flags, static_cast<hipStream_t>(stream));
+}
+
+const char* svc_hip_hbma_kernel_name(uint32_t level_count, uint32_t frame_w, uint32_t frame_h, uint32_t search_range,
+                                     uint32_t block_w, uint32_t block_h, uint32_t flags) {
+  // launch_hbma's and launch_hbma_fused's choice, for aligned pyramids
+  if (validate_hbma(level_count, frame_w, frame_h, search_range, block_w, block_h)) return nullptr;
+  const bool can_fuse = fused_supported(level_count, frame_w, frame_h, search_range, block_w, block_h);
+  const bool can_tile = tiled_supported(level_count, frame_w, frame_h, search_range, block_w, block_h);
+  const bool forced = flags & (SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE);
+  if ((forced && !can_fuse) || ((flags & SVC_HBMA_FORCE_TILED) && !can_tile)) {
+    fail(SVC_ERR_UNSUPPORTED, "hbma: the kernel the flags name does not cover this shape");
+    return nullptr;
+  }
+  if (!forced && (!can_fuse || (flags & SVC_HBMA_FORCE_WAVE_PER_BLOCK))) return "hbma_wave_level_kernel";
+  if (flags & SVC_HBMA_FORCE_TILED) return "hbma_tiled16_kernel";
+  if (flags & SVC_HBMA_FORCE_LANE) return "hbma_fused_kernel";
+  return can_tile && tiled_is_default() ? "hbma_tiled16_kernel" : "hbma_fused_kernel";
 }
 
 int svc_hip_ebma_pairs(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride_bytes,

@@ -36,6 +36,8 @@ bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, ui
 
 int launch_hbma_tiled(const FusedArgs& a, uint32_t n_pairs, hipStream_t stream);
 
+bool tiled_is_default() { return kTiledIsDefault; }
+
 // kernel: 0 = the shape's default, 1 = lane-per-block (no LDS), 2 = LDS-tiled (UNSUPPORTED where tiled_supported is false)
 int launch_hbma_fused(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair_stride,
                       uint32_t n_pairs, uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t mb,

@@ -23,9 +23,10 @@ namespace svc {
 // what the lane-per-block kernel covers (hbma_fused.hip) / the LDS-tiled one (hbma_tiled.hip)
 bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
 bool tiled_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh);
-// SVC_HBMA_AUTO keeps the lane-per-block kernel for every fused shape: the LDS-tiled kernel measures level with it
-// (C5 0.279 vs 0.281 ms, C3b 0.328 vs 0.323: profiles/r03_ab_hbma_tiled.txt) and is there on request (SVC_HBMA_FORCE_TILED)
-constexpr bool kTiledIsDefault = false;
+// SVC_HBMA_AUTO takes the LDS-tiled kernel where it applies (16 x 16 blocks, 4 levels, R_top 1: the reference's default
+// build): 2 - 4 % faster than the lane-per-block kernel on C5 and C3b once both use the packed refinement select and the
+// tile shape is fitted to the frame (profiles/r03_ab_hbma_tiled_final.txt)
+constexpr bool kTiledIsDefault = true;
 
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -160,6 +161,57 @@ __device__ __forceinline__ void select(const Window& w, int ax, int ay, GetSad s
   }
 }
 
+// The refinement select (strict `<` against the carried minimum, first candidate in raster order on ties) straight on the
+// packed QSAD sums, for blocks whose SAD fits 16 bits (B <= 16).  Inside a level the scale of the SADs does not matter,
+// so a candidate's key is (sad << 16) | raster index: ONE instruction per candidate -- v_lshl_or_b32 for the sum in the
+// low half of its word, v_and_or_b32 for the one in the high half -- instead of extract, shift and or; only the winner
+// is scaled (<< SHIFT) for the compare with the carried minimum.  Where every lane of the wave has its whole candidate
+// grid inside the reference's clamped window (every block away from the frame border whose vector stays inside: almost
+// all of them) the validity masks are skipped too; the other waves take the masked form.  Same order, same winner.
+// Used for R_top = 1 (9 candidates); see search_level for why not beyond.
+template <int RT, int SHIFT, int NQ>
+__device__ __forceinline__ void select_refine_packed(const Window& w, int ax, int ay, const uint64_t (&acc4)[2 * RT + 1][NQ],
+                                                     const uint32_t (&acc1)[2 * RT + 1], int& mvx, int& mvy, uint32_t& best) {
+  constexpr int N = 2 * RT + 1;
+  constexpr uint32_t CM = 0xFFFFu;
+  uint32_t key[N][N];
+#pragma unroll
+  for (int d = 0; d < N; ++d)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const uint32_t code = (uint32_t)(d * N + j);
+      if (j >= 4 * NQ) {
+        key[d][j] = (acc1[d] << 16) | code;
+      } else {
+        const uint32_t word = (j & 2) ? (uint32_t)(acc4[d][j >> 2] >> 32) : (uint32_t)acc4[d][j >> 2];
+        key[d][j] = (j & 1) ? ((word & 0xFFFF0000u) | code) : ((word << 16) | code);
+      }
+    }
+  const bool whole = w.dlo == 0 && w.dhi == N && w.jlo == 0 && w.jhi == N;
+  uint32_t kmin = 0xFFFFFFFFu;
+  if (__builtin_amdgcn_ballot_w64(!whole) == 0) {  // wave-uniform: no lane needs a mask
+#pragma unroll
+    for (int d = 0; d < N; ++d)
+#pragma unroll
+      for (int j = 0; j < N; ++j) kmin = min(kmin, key[d][j]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      const bool row_ok = d >= w.dlo && d < w.dhi;
+#pragma unroll
+      for (int j = 0; j < N; ++j) kmin = min(kmin, (row_ok && j >= w.jlo && j < w.jhi) ? key[d][j] : 0xFFFFFFFFu);
+    }
+  }
+  const uint32_t smin = (kmin >> 16) << SHIFT;  // no candidate at all: 0xFFFF << SHIFT, above every carried minimum
+  const int idx = (int)(kmin & CM);
+  const int bd = idx / N, bj = idx - bd * N;
+  if (smin < best && kmin != 0xFFFFFFFFu) {
+    best = smin;
+    mvx = w.wx + bj - ax;
+    mvy = w.wy + bd - ay;
+  }
+}
+
 // How the 2 RT + 1 horizontal candidates of a level map onto the SAD instructions: NQ v_qsad_pk_u16_u8 per anchor word
 // (four candidates each) and, when one candidate is left over (RT = 2, 4), one v_sad_u8.
 template <int RT>
@@ -233,13 +285,19 @@ __device__ __forceinline__ void search_level(const uint8_t* __restrict__ trk,
       }
     }
   }
-  select<RT, TOP, SHIFT>(
-      w, ax, ay,
-      [&](int d, int j) {
-        if (j >= 4 * NQ) return acc1[d];
-        return WIDE ? wide[WIDE ? d : 0][WIDE ? j : 0] : (uint32_t)(acc4[d][j >> 2] >> (16 * (j & 3))) & 0xFFFFu;
-      },
-      mvx, mvy, best);
+  // 9 candidates: the packed form wins 3 % on the 4-level search; with 25 it LOSES 1.5 % on the VALU-balanced 3-level
+  // kernel (keys held across the branch, or re-formed in both arms: both measured, profiles/r03_ab_select.txt)
+  if constexpr (!TOP && !WIDE && RT == 1) {
+    select_refine_packed<RT, SHIFT, NQ>(w, ax, ay, acc4, acc1, mvx, mvy, best);
+  } else {
+    select<RT, TOP, SHIFT>(
+        w, ax, ay,
+        [&](int d, int j) {
+          if (j >= 4 * NQ) return acc1[d];
+          return WIDE ? wide[WIDE ? d : 0][WIDE ? j : 0] : (uint32_t)(acc4[d][j >> 2] >> (16 * (j & 3))) & 0xFFFFu;
+        },
+        mvx, mvy, best);
+  }
 }
 
 // A top level of 2x2 blocks (reference motion.cpp:719-720: the 4-level search of 16x16 blocks; likewise 3 levels

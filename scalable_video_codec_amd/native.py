@@ -56,6 +56,7 @@ SIGNATURES = {
     "svc_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "svc_hip_pyramid_bytes": (_u64, [_u32, _u32, _u32]),
     "svc_hip_hbma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp]),
+    "svc_hip_hbma_kernel_name": (C.c_char_p, [_u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "svc_hip_ebma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "svc_hip_ransac_iter_count": (_u32, [RansacParams]),
     "svc_hip_ransac_frames": (C.c_int, [_vp, _u32, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
@@ -164,6 +165,16 @@ def hbma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_
                                      levels, w, h, search_range, block_w, block_h,
                                      _dev(mv, torch.float32), _dev(mad, torch.float32), flags, _stream()))
     return mv, mad
+
+
+def hbma_kernel_name(levels: int, w: int, h: int, search_range: int, block_w: int = 16, block_h: int = 16,
+                     flags: int = HBMA_AUTO) -> str:
+    """The kernel hbma_pairs launches for this shape and these flags (aligned pyramids); no GPU work."""
+    name = load().svc_hip_hbma_kernel_name(levels, w, h, search_range, block_w, block_h, flags)
+    if name is None:  # invalid parameters (the asserts of motion.cpp:417-433) or a forced kernel that does not cover the shape
+        msg = load().svc_hip_last_error().decode()
+        raise SvcError(SVC_ERR_UNSUPPORTED if "does not cover" in msg else SVC_ERR_INVALID_ARG, msg)
+    return name.decode()
 
 
 def ebma_pairs(tracked: torch.Tensor, anchor: torch.Tensor, pair_stride: int, n_pairs: int, w: int, h: int,

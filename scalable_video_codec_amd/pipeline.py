@@ -144,8 +144,7 @@ class ClipEncoder:
                                       cfg.seed + 7919 * rank, device)
         self._ev: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._steps_timed = 0
-        fused = cfg.mv_block == 16 and cfg.levels in (3, 4) and cfg.r_top in (1, 2)
-        self.hbma_kernel_name = "hbma_fused_kernel" if fused else "hbma_wave_level_kernel"
+        self.hbma_kernel_name = native.hbma_kernel_name(self.levels, self.pw, self.ph, cfg.search_range, cfg.mv_block, cfg.mv_block)
 
     def load_frames(self, frames: List[torch.Tensor]) -> None:
         assert len(frames) == self.n

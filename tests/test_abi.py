@@ -96,6 +96,29 @@ def test_pyramid_bytes_and_iter_count():
     assert native.ransac_iter_count(subset_sz=3) == 35
 
 
+def test_hbma_kernel_choice_is_queryable():
+    """svc_hip_hbma_kernel_name: the dispatch of svc_hip_hbma_pairs as a string (bench.py labels its roofline with it)."""
+    name = native.hbma_kernel_name
+    assert name(4, 3840, 2160, 8) == "hbma_tiled16_kernel"       # C5: the reference's default search, levels 2 and 1 from LDS tiles
+    assert name(4, 1920, 1088, 8) == "hbma_tiled16_kernel"       # C3b
+    assert name(3, 1920, 1088, 8) == "hbma_fused_kernel"         # C3 (headline): lane per block
+    assert name(4, 1920, 1088, 16) == "hbma_fused_kernel"        # r_top 2
+    assert name(4, 1936, 1088, 8) == "hbma_wave_level_kernel"    # top plane width not a multiple of 4
+    assert name(1, 352, 288, 8) == "hbma_wave_level_kernel"      # C1: one level is EBMA-shaped
+    assert name(3, 1920, 1088, 8, 8, 8) == "hbma_fused_kernel"
+    assert name(3, 1920, 1088, 8, 16, 8) == "hbma_wave_level_kernel"   # non-square blocks
+    assert name(4, 3840, 2160, 8, flags=native.HBMA_FORCE_LANE) == "hbma_fused_kernel"
+    assert name(4, 3840, 2160, 8, flags=native.HBMA_FORCE_WAVE_PER_BLOCK) == "hbma_wave_level_kernel"
+    assert name(4, 3840, 2160, 8, flags=native.HBMA_FORCE_TILED) == "hbma_tiled16_kernel"
+    for args, flags, status in (((3, 1920, 1088, 8), native.HBMA_FORCE_TILED, native.SVC_ERR_UNSUPPORTED),
+                                ((4, 1936, 1088, 8), native.HBMA_FORCE_LANE, native.SVC_ERR_UNSUPPORTED),
+                                ((4, 1920, 1080, 8), native.HBMA_AUTO, native.SVC_ERR_INVALID_ARG),     # 1080 % 16
+                                ((5, 1920, 1088, 8), native.HBMA_AUTO, native.SVC_ERR_INVALID_ARG)):    # range < 2^(L-1)
+        with pytest.raises(native.SvcError) as e:
+            name(*args, flags=flags)
+        assert e.value.status == status, (args, flags)
+
+
 def test_preconditions_are_statuses_not_ub():
     """The reference only asserts these (libs/motion.cpp:417-433); here they are
     SVC_ERR_INVALID_ARG, raised before any device call (so this runs without a GPU)."""

@@ -175,14 +175,17 @@ def test_hbma_pairs_batched_clip(native, oracle, levels):
         _assert_same(mvw[p].cpu().numpy(), madw[p].cpu().numpy(), exp_mv, exp_mad, f"wave pair {p}")
 
 
-@pytest.mark.parametrize("w,h,n", [(512, 128, 3), (640, 400, 3), (1024, 256, 2), (128, 128, 2), (1152, 640, 2), (192, 144, 2), (576, 1088, 2)])
+@pytest.mark.parametrize("w,h,n", [(512, 128, 3), (640, 400, 3), (1024, 256, 2), (128, 128, 2), (1152, 640, 2), (192, 144, 2), (576, 1088, 2),
+                                   (1920, 1088, 2), (2048, 64, 2)])
 @pytest.mark.parametrize("kind", ["clip", "noise"])
 def test_hbma_tiled_kernel(native, oracle, w, h, n, kind):
-    """The LDS-tiled form of the 4-level search (SVC_HBMA_FORCE_TILED: levels 2 and 1 from LDS tiles, 4 levels, R_top = 1,
-    frame width a multiple of 64): frames of one tile, of partial tiles in both directions (640 = 1.25 tiles of 32
-    blocks, 400 / 16 = 25 block rows = 3.1 tiles of 8), of several tiles, and smaller than a tile; coherent clips and uncorrelated
-    noise (every window clamp, vectors up to the +-6 / +-2 the tile margins are sized for).  Against the oracle, the
-    lane-per-block kernel and the per-level kernel, libs/motion.cpp:691-749."""
+    """The LDS-tiled form of the 4-level search (what SVC_HBMA_AUTO takes for 16 x 16 blocks, 4 levels, R_top = 1 and a
+    frame width that is a multiple of 64; SVC_HBMA_FORCE_TILED names it): levels 2 and 1 searched from LDS tiles.  Frames
+    of one tile, of partial tiles in both directions (640 = 1.25 tiles of 32 blocks, 400 / 16 = 25 block rows = 3.1 tiles
+    of 8), of several tiles, smaller than a tile, and shapes that take each of the three tile forms (16 x 16, 32 x 8 and
+    64 x 4 blocks: 1080p takes 64 x 4, 2048 x 64 too); coherent clips and uncorrelated noise (every window clamp, vectors
+    up to the +-6 / +-2 the tile margins are sized for).  Against the oracle, the lane-per-block kernel and the per-level
+    kernel, libs/motion.cpp:691-749."""
     levels, r = 4, 8
     if kind == "clip":
         _, pyrs, (pw, ph) = util.clip_frames(w, h, n, 0x711E + w, levels)
@@ -194,6 +197,7 @@ def test_hbma_tiled_kernel(native, oracle, w, h, n, kind):
     assert (pw, ph) == (w, h)
     stride = native.pyramid_stride(pw, ph, levels)
     buf = util.pack_clip(pyrs, stride, "cuda")
+    assert native.hbma_kernel_name(levels, pw, ph, r) == "hbma_tiled16_kernel"
     out = {}
     for name, f in (("tiled", native.HBMA_FORCE_TILED), ("lane", native.HBMA_FORCE_LANE), ("auto", native.HBMA_AUTO),
                     ("wave", native.HBMA_FORCE_WAVE_PER_BLOCK)):
