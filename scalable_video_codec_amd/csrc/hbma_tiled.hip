@@ -29,18 +29,23 @@ namespace svc {
 
 template <int B, int M, int RT, int TBX, int TBY>
 struct TileGeom {
-  static_assert(M + RT <= 16, "the tile starts 16 bytes left of its first anchor column");
+  static_assert(M + RT <= 16, "the tile starts at most 16 + 15 bytes left of its first anchor column");
   static constexpr int ND = B / 4 + 2;                                       // dwords a whole-block row read spans
-  static constexpr int X_LEFT = 16;                                          // bytes left of the first anchor column
+  // The tile's first byte is the 16-byte boundary at or below (first anchor column - (M + RT)): whole chunks of whole
+  // rows for the DMA.  Tiles whose width in pixels is a multiple of 16 start exactly 16 bytes left of their first anchor
+  // column; any other width (15 blocks) up to M + RT + 15.
+  static constexpr int X_LEFT_MAX = (TBX * B) % 16 == 0 ? 16 : M + RT + 15;
   static constexpr int Y_TOP = M + RT;                                       // rows above the first anchor row
   static constexpr int A0_MAX = ((TBX - 1) * B + M - RT) & ~3;               // last dword-aligned window origin
-  static constexpr int W = (A0_MAX + 4 * ND + X_LEFT + 15) & ~15;            // bytes per tile row (= LDS pitch)
+  static constexpr int W = (A0_MAX + 4 * ND + X_LEFT_MAX + 15) & ~15;        // bytes per tile row (= LDS pitch)
   static constexpr int CPR = W / 16;                                         // 16-byte chunks per row
   static constexpr int ROWS = Y_TOP + (TBY - 1) * B + (M - RT) + B + 2 * RT;
   static constexpr int CHUNKS = CPR * ROWS;
   // LDS bytes: whole wave instructions (1 KiB each)
   static constexpr int rounds(int nwaves) { return (CHUNKS + 64 * nwaves - 1) / (64 * nwaves); }
   static constexpr int BYTES = ((CHUNKS + 63) / 64) * 1024;
+  // x of the tile's first byte, for the tile whose first anchor column is ax0 (level pixels)
+  static __device__ __forceinline__ int origin_x(int ax0) { return (ax0 - (M + RT)) & ~15; }
 };
 
 // The tile of one level, global -> LDS, asynchronously.  Chunk i of the tile (row-major) is fetched by lane i % 64 of the
@@ -83,7 +88,9 @@ __device__ __forceinline__ void wait_vm_all() {
 template <int B, int RT, int SHIFT, class G>
 __device__ __forceinline__ void search_level_lds(uint32_t lds_tile, int x0, int y0, const uint32_t (&a)[B][B / 4], int fw,
                                                  int fh, int bx, int by, int& mvx, int& mvy, uint32_t& best) {
-  constexpr int NW = B / 4, ND = NW + 2, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  using P = SadPlan<RT>;
+  constexpr int NW = B / 4, NQ = P::NQ, NV = NW + NQ, ND = NV + 1, NDY = 2 * RT + 1, NT = B + 2 * RT;
+  static_assert(ND <= G::ND, "the tile's row pitch covers the widest read");
   const int ax = bx * B, ay = by * B;
   const Window w = make_window<B, RT>(ax + mvx, ay + mvy, fw, fh);
   const int a0 = w.wx & ~3;
@@ -91,18 +98,22 @@ __device__ __forceinline__ void search_level_lds(uint32_t lds_tile, int x0, int 
   const uint32_t p = lds_tile + (uint32_t)((w.wy - y0) * G::W + (a0 - x0));
   const __attribute__((address_space(3))) uint8_t* lp = (const __attribute__((address_space(3))) uint8_t*)(uintptr_t)p;
 
-  uint64_t acc4[NDY][1];
+  uint64_t acc4[NDY][NQ];
   uint32_t acc1[NDY];
 #pragma unroll
-  for (int d = 0; d < NDY; ++d) { acc4[d][0] = 0; acc1[d] = 0; }
+  for (int d = 0; d < NDY; ++d) {
+    acc1[d] = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc4[d][q] = 0;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    uint32_t m[ND], v[NW + 1];
+    uint32_t m[ND], v[NV];
 #pragma unroll
     for (int k = 0; k < ND; ++k)
       m[k] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(lp + (t * G::W + 4 * k));
 #pragma unroll
-    for (int k = 0; k <= NW; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
+    for (int k = 0; k < NV; ++k) v[k] = __builtin_amdgcn_alignbyte(m[k + 1], m[k], sh);
 #pragma unroll
     for (int d = 0; d < NDY; ++d) {
       const int r = t - d;  // anchor row that meets tracked row t at vertical offset d
@@ -110,18 +121,23 @@ __device__ __forceinline__ void search_level_lds(uint32_t lds_tile, int x0, int 
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
           const uint32_t av = a[r >= 0 && r < B ? r : 0][k];
-          acc4[d][0] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k], v[k + 1]), av, acc4[d][0]);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            acc4[d][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(v[k + q], v[k + q + 1]), av, acc4[d][q]);
+          if (P::kTail) acc1[d] = __builtin_amdgcn_sad_u8(v[k + NQ], av, acc1[d]);
         }
       }
     }
   }
   static_assert(RT == 1, "the tiled kernel is the R_top = 1 search");
-  select_refine_packed<RT, SHIFT, 1>(w, ax, ay, acc4, acc1, mvx, mvy, best);
+  select_refine_packed<RT, SHIFT, NQ>(w, ax, ay, acc4, acc1, mvx, mvy, best);
 }
 
+// A workgroup is the tile's TBX x TBY lanes rounded up to whole waves (tile widths that are not powers of two work, lanes
+// past the tile idle; none is instantiated: narrow tiles measured slower, see launch_hbma_tiled).
 template <int RT, int TBX, int TBY>
-__global__ __launch_bounds__(TBX* TBY) void hbma_tiled16_kernel(FusedArgs a, uint32_t tiles_x, uint32_t tiles) {
-  constexpr int NWAVES = TBX * TBY / 64;
+__global__ __launch_bounds__((TBX * TBY + 63) / 64 * 64) void hbma_tiled16_kernel(FusedArgs a, uint32_t tiles_x, uint32_t tiles) {
+  constexpr int NWAVES = (TBX * TBY + 63) / 64;
   using G1 = TileGeom<8, 6 * RT, RT, TBX, TBY>;  // |mv_in| <= 6 R_top at level 1
   using G2 = TileGeom<4, 2 * RT, RT, TBX, TBY>;  //           2 R_top at level 2
   constexpr uint32_t OFF2 = G1::BYTES;
@@ -139,9 +155,10 @@ __global__ __launch_bounds__(TBX* TBY) void hbma_tiled16_kernel(FusedArgs a, uin
   const uint32_t mfh = a.blocks / a.mfw;
 
   const uint32_t tid = threadIdx.x, wave = tid / 64u;
-  const uint32_t lx = tid % TBX, ly = tid / TBX;
+  const uint32_t slot = min(tid, (uint32_t)(TBX * TBY - 1));  // lanes past the tile (the workgroup is whole waves) idle on its last block
+  const uint32_t lx = slot % TBX, ly = slot / TBX;
   const uint32_t bxu = tk * TBX + lx, byu = tm * TBY + ly;
-  const bool live = bxu < a.mfw && byu < mfh;
+  const bool live = tid < (uint32_t)(TBX * TBY) && bxu < a.mfw && byu < mfh;
   // a lane beyond the frame searches the last block of its row / column again (in-tile addresses) and stores nothing
   const int bx = (int)min(bxu, a.mfw - 1), by = (int)min(byu, mfh - 1);
 
@@ -152,8 +169,8 @@ __global__ __launch_bounds__(TBX* TBY) void hbma_tiled16_kernel(FusedArgs a, uin
 
   // the tiles of levels 2 and 1, coarse to fine (completion order is issue order) ...
   const int tx = (int)(tk * TBX), ty = (int)(tm * TBY);
-  const int x2 = tx * 4 - G2::X_LEFT, y2 = ty * 4 - G2::Y_TOP;
-  const int x1 = tx * 8 - G1::X_LEFT, y1 = ty * 8 - G1::Y_TOP;
+  const int x2 = G2::origin_x(tx * 4), y2 = ty * 4 - G2::Y_TOP;
+  const int x1 = G1::origin_x(tx * 8), y1 = ty * 8 - G1::Y_TOP;
   stage_tile_async<G2, NWAVES>(trk + o2, w >> 2, h >> 2, x2, y2, lds0 + OFF2, wave, tid / (uint32_t)G2::CPR, tid % (uint32_t)G2::CPR);
   stage_tile_async<G1, NWAVES>(trk + o1, w >> 1, h >> 1, x1, y1, lds0, wave, tid / (uint32_t)G1::CPR, tid % (uint32_t)G1::CPR);
   // ... then what the lane keeps in registers: the top level's rows and the anchor blocks of levels 2 and 1
@@ -192,7 +209,9 @@ __global__ __launch_bounds__(TBX* TBY) void hbma_tiled16_kernel(FusedArgs a, uin
 }
 
 // The LDS-tiled kernel serves the 4-level search with R_top = 1 on planes whose rows are whole 16-byte chunks at the
-// three levels it stages (so the frame width is a multiple of 64; any height).
+// three levels it stages (so the frame width is a multiple of 64; any height).  (The 3-level search with R_top = 2, level 1
+// from LDS, was built the same way and is 4 - 5 % slower than the lane-per-block kernel at C3: the lanes past the frame
+// edge and 6 instead of 8 waves per SIMD cost more than the level-1 gathers: profiles/r03_ab_hbma_tiled_3L.txt.)
 bool tiled_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, uint32_t bw, uint32_t bh) {
   return fused_supported(levels, w, h, range, bw, bh) && bw == 16 && levels == 4 && (range >> 3) == 1 && w % 64 == 0;
 }
@@ -204,19 +223,23 @@ static int launch_tiled(FusedArgs a, uint32_t n_pairs, hipStream_t stream) {
   a.wgs_per_region = div_up(tiles, 8);
   const uint64_t wgs = (uint64_t)8 * a.wgs_per_region * n_pairs;
   if (wgs > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "hbma: %llu workgroups exceed one launch", (unsigned long long)wgs);
-  hipLaunchKernelGGL((hbma_tiled16_kernel<1, TBX, TBY>), dim3((uint32_t)wgs), dim3(TBX * TBY), 0, stream, a, tiles_x, tiles);
+  hipLaunchKernelGGL((hbma_tiled16_kernel<1, TBX, TBY>), dim3((uint32_t)wgs), dim3((TBX * TBY + 63) / 64 * 64), 0, stream, a, tiles_x, tiles);
   return check_launch("hbma_tiled16_kernel");
 }
 
 int launch_hbma_tiled(const FusedArgs& a, uint32_t n_pairs, hipStream_t stream) {
-  // tile shape: the one that leaves the fewest lanes on blocks past the frame's right / bottom edge (1080p: 64 x 4 wastes
-  // 6.7 %, 32 x 8 13 %, 16 x 16 25 %; 4K: 6.7 / 7.4 / 6.7 %); ties go to the squarer tile (smaller margins)
+  // Tile shape.  Fewer lanes on blocks past the frame's right / bottom edge is better (1080p, 120 x 68 blocks: 64 x 4
+  // wastes 6.7 %, 32 x 8 13 %, 16 x 16 25 %; 4K, 240 x 135: 6.7 / 7.4 / 6.7 %), and so is a wider tile: a wave that covers
+  // 64 blocks of ONE block row reads its anchor rows as one run and shares the most cache lines among its level-0 windows.
+  // Measured at 4K with the same number of lanes: 16 x 16 0.268 ms, 64 x 4 0.233 ms (profiles/r03_ab_hbma_tiled_wide.txt);
+  // a 15 x 17 tile, which fits both fields within 1 %, is 7 - 10 % slower than either (r03_ab_hbma_tiled_15x17.txt).  So a
+  // tile 16 blocks wide is costed at 1.15 lanes per lane, 32 wide at 1.02, and the cheapest shape wins.
   const uint32_t mfh = a.blocks / a.mfw;
-  const uint64_t t16 = (uint64_t)div_up(a.mfw, 16) * div_up(mfh, 16), t32 = (uint64_t)div_up(a.mfw, 32) * div_up(mfh, 8),
-                 t64 = (uint64_t)div_up(a.mfw, 64) * div_up(mfh, 4);
-  if (t16 <= t32 && t16 <= t64) return launch_tiled<16, 16>(a, n_pairs, stream);
-  if (t32 <= t64) return launch_tiled<32, 8>(a, n_pairs, stream);
-  return launch_tiled<64, 4>(a, n_pairs, stream);
+  const uint64_t c16 = (uint64_t)div_up(a.mfw, 16) * div_up(mfh, 16) * 115, c32 = (uint64_t)div_up(a.mfw, 32) * div_up(mfh, 8) * 102,
+                 c64 = (uint64_t)div_up(a.mfw, 64) * div_up(mfh, 4) * 100;
+  if (c64 <= c32 && c64 <= c16) return launch_tiled<64, 4>(a, n_pairs, stream);
+  if (c32 <= c16) return launch_tiled<32, 8>(a, n_pairs, stream);
+  return launch_tiled<16, 16>(a, n_pairs, stream);
 }
 
 }  // namespace svc

@@ -176,14 +176,15 @@ def test_hbma_pairs_batched_clip(native, oracle, levels):
 
 
 @pytest.mark.parametrize("w,h,n", [(512, 128, 3), (640, 400, 3), (1024, 256, 2), (128, 128, 2), (1152, 640, 2), (192, 144, 2), (576, 1088, 2),
-                                   (1920, 1088, 2), (2048, 64, 2)])
+                                   (1920, 1088, 2), (2048, 64, 2), (320, 528, 2), (704, 528, 2), (960, 544, 2)])
 @pytest.mark.parametrize("kind", ["clip", "noise"])
 def test_hbma_tiled_kernel(native, oracle, w, h, n, kind):
     """The LDS-tiled form of the 4-level search (what SVC_HBMA_AUTO takes for 16 x 16 blocks, 4 levels, R_top = 1 and a
     frame width that is a multiple of 64; SVC_HBMA_FORCE_TILED names it): levels 2 and 1 searched from LDS tiles.  Frames
     of one tile, of partial tiles in both directions (640 = 1.25 tiles of 32 blocks, 400 / 16 = 25 block rows = 3.1 tiles
-    of 8), of several tiles, smaller than a tile, and shapes that take each of the three tile forms (16 x 16, 32 x 8 and
-    64 x 4 blocks: 1080p takes 64 x 4, 2048 x 64 too); coherent clips and uncorrelated noise (every window clamp, vectors
+    of 8), of several tiles, smaller than a tile, and shapes that take each of the three tile forms (64 x 4 blocks: 1080p,
+    2048 x 64, 960 x 544, 704 x 528; 32 x 8: 512 x 128, 1152 x 640, 320 x 528; 16 x 16: 640 x 400, 192 x 144);
+    coherent clips and uncorrelated noise (every window clamp, vectors
     up to the +-6 / +-2 the tile margins are sized for).  Against the oracle, the lane-per-block kernel and the per-level
     kernel, libs/motion.cpp:691-749."""
     levels, r = 4, 8

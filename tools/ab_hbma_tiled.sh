@@ -8,7 +8,7 @@ d=json.loads(sys.stdin.readline()); k=d['kernel_ms_per_step']
 print('  value %8.0f  ms/step %.3f  hbma %.4f ms  frac %.3f   %s' % (d['value'], d['ms_per_step'], k.get('hbma',0), d['roofline']['frac'], d['roofline']['kernel'][:24]))"; }
 {
 for rep in 1 2; do
-for c in C5-4k-4L-dct16 C3b-1080p-4L-dct8-quant; do
+for c in ${CONFIGS:-C5-4k-4L-dct16 C3b-1080p-4L-dct8-quant C3-1080p-3L-dct8-quant}; do
   for k in lane tiled; do
     for s in serial pipelined; do echo "== $c kernel=$k schedule=$s"; run --config $c --hbma-kernel $k --schedule $s; done
   done

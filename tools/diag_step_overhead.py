@@ -8,10 +8,12 @@ import torch
 sys.path.insert(0, ".")
 from scalable_video_codec_amd import clip as clipmod, configs, synth  # noqa: E402
 
-cfg = configs.C3
+# usage: diag_step_overhead.py [config name [frames ...]]   (default: C3 at 38 and 300 frames)
+cfg = configs.ALL[sys.argv[1]] if len(sys.argv) > 1 else configs.C3
+sizes = [int(a) for a in sys.argv[2:]] or [38, 300]
 dev = torch.device("cuda")
 pw, ph = cfg.padded
-for n in (38, 300):
+for n in sizes:
     src = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
     frames = torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(n)]).contiguous()
     for label, kw, timed in (("timed", {}, True), ("untimed", {}, False), ("graph", {"graph": True}, False),
@@ -22,7 +24,7 @@ for n in (38, 300):
             enc.step()
         enc.sync()
         torch.cuda.synchronize()
-        k = 100 if n == 38 else 30
+        k = 100 if n <= 38 else 30
         t0 = time.perf_counter()
         for _ in range(k):
             enc.step(timed=timed)
