@@ -74,3 +74,18 @@ def test_fused_kernel_random_frames(native, oracle, mb, levels, rt, nbx, nby, se
         assert e.status == native.SVC_ERR_UNSUPPORTED
         mv, mad = native.hbma_host(t, a, r, mb, mb)
     assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (mb, levels, rt, w, h, kind)
+
+
+@settings(max_examples=fuzz_examples(30), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=not FUZZ_RANDOM)
+@given(nbx4=st.integers(2, 20), nby=st.integers(2, 36), r=st.integers(8, 15), seed=st.integers(0, 2 ** 31 - 1),
+       kind=st.sampled_from(["noise", "shifted", "flat", "periodic"]))
+def test_tiled_kernel_random_frames(native, oracle, nbx4, nby, r, seed, kind):
+    """The LDS-tiled kernel (4 levels, R_top 1 -- search ranges 8 .. 15 --, frame widths that are multiples of 64) on fields
+    of 8 .. 80 x 2 .. 36 blocks (smaller ones have no room for the top level's candidate grid and take the per-level kernel): every tile shape the launcher picks, whole and partial tiles, every window clamp."""
+    w, h = 64 * nbx4, 16 * nby
+    t, a = _planes(kind, np.random.default_rng(seed), w, h, 4)
+    exp_mv, exp_mad = oracle.hbma(t, a, r, 16, 16)
+    assert native.hbma_kernel_name(4, w, h, r) == "hbma_tiled16_kernel"
+    for flags in (native.HBMA_FORCE_TILED, native.HBMA_AUTO, native.HBMA_FORCE_LANE):
+        mv, mad = native.hbma_host(t, a, r, 16, 16, flags=flags)
+        assert np.array_equal(mv, exp_mv) and np.array_equal(mad, exp_mad), (w, h, r, kind, flags)
