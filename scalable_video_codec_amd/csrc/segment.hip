@@ -42,8 +42,8 @@ struct SegArgs {
   uint32_t bits_bytes;   // ... of which the bit fields at its start
   uint32_t packable;     // host check: field <= 512 x 512 blocks and x_px, y_px < 2^14 (32-bit distances)
   uint32_t take_all;     // the 256-lane attempt kernel also takes the heavy frames (no 1024-lane launch)
-  uint32_t wide_g;       // > 0: heavy frames' attempts run as launch sequences over wide_g workgroups each (the 1024-lane
-                         // attempt kernel then leaves them alone)
+  uint32_t wide_g;       // > 0: the attempts of every frame of packed points run as launch sequences over wide_g workgroups
+                         // each (the one attempt launch in front of them then takes the frames of unpacked points only)
   uint32_t wide_step;    // which launch of the sequence this is
 };
 
@@ -885,8 +885,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const uint32_t nf = *ws.nf();
-  if (nf == 0 || (!a.take_all && (nf > kLightMax) != (T == kTA))) return;
-  if (T == kTA && a.wide_g && *ws.packed() != 0) return;  // the launch sequence of segment_wide_*_kernel has this frame
+  if (nf == 0) return;
+  if (a.wide_g) {  // the launch sequence of segment_wide_*_kernel has every frame of packed points, light ones included;
+    if (*ws.packed() != 0) return;  // this (1024-lane, the only attempt launch then) takes the frames of unpacked points
+  } else if (!a.take_all && (nf > kLightMax) != (T == kTA)) {
+    return;
+  }
   const uint32_t te = T == kTA ? kTA : nf <= 256 ? 64u : 256u;  // one wave: no barrier ever waits
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
   uint8_t* lab = ws.lab(att);
@@ -931,7 +935,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 // so there is no spin-wait and no residency assumption.  A launch reads only what EARLIER launches wrote (WideState);
 // inside a launch every workgroup recomputes the shared quantities (draw, centres, convergence) redundantly from the
 // per-workgroup partial sums, which are exact integers -- so the result is the single-kernel path's, and
-// oracle/svc_segment.c's, bit for bit.  Workgroup g owns the g-th contiguous chunk of the foreground list.
+// oracle/svc_segment.c's, bit for bit.  Workgroup g owns the g-th contiguous chunk of the foreground list.  The light
+// frames of the batch ride along (most of their workgroups own nothing): the sequence is as long with them as without.
 constexpr uint32_t kTW = 256;  // lanes of a wide workgroup
 
 __device__ __forceinline__ void wide_chunk(uint32_t nf, uint32_t G, uint32_t g, uint32_t& w0, uint32_t& w1) {
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(kTW) void segment_wide_seed_kernel(SegArgs a) {
   const uint32_t g = blockIdx.x, G = a.wide_g, frame = blockIdx.y, att = blockIdx.z, n = a.n, j = a.wide_step;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const uint32_t nf = *ws.nf();
-  if (nf <= kLightMax || *ws.packed() == 0) return;  // light / unpackable frames stay on the single-kernel paths
+  if (nf == 0 || *ws.packed() == 0) return;  // frames of unpacked points stay on the single-kernel path
   const uint32_t k = min(a.k, nf);
   if (j >= k) return;
   WideState& W = *ws.wide(att);
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(kTW) void segment_wide_lloyd_kernel(SegArgs a) {
   const uint32_t g = blockIdx.x, G = a.wide_g, frame = blockIdx.y, att = blockIdx.z, n = a.n, it = a.wide_step;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   const uint32_t nf = *ws.nf();
-  if (nf <= kLightMax || *ws.packed() == 0) return;
+  if (nf == 0 || *ws.packed() == 0) return;
   const uint32_t k = min(a.k, nf);
   WideState& W = *ws.wide(att);
   if (W.done) return;  // written by an earlier launch
@@ -1446,6 +1451,14 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   };
   if (small) {
     hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
+  } else if (a.wide_g) {
+    // every frame of packed points, light or heavy, rides the launch sequence (its length is set by k and max_iter, not by
+    // the frames in it; a separate launch for the light frames would only add its 0.1 ms to the chain); the one attempt
+    // launch in front of it takes the frames of unpacked points (none after block matching) and exits otherwise
+    SegArgs heavy = a;
+    heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
+    hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, stream, heavy);
+    launch_wide(stream);
   } else if (a.n > kLightMax) {
     // The two attempt launches are independent (each frame belongs to exactly one): the heavy one goes to a
     // side stream, forked after the prepare kernel and joined before the labelling, so a scene cut's long
@@ -1463,13 +1476,11 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
       SVC_HIP_TRY(hipEventRecord(side->fork, stream));
       SVC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
       hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, side->stream, heavy);
-      if (a.wide_g) launch_wide(side->stream);
       SVC_HIP_TRY(hipEventRecord(side->join, side->stream));
       hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
       SVC_HIP_TRY(hipStreamWaitEvent(stream, side->join, 0));
     } else {
       hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, stream, heavy);
-      if (a.wide_g) launch_wide(stream);
       hipLaunchKernelGGL((segment_attempt_kernel<256>), grid_a, dim3(256), 0, stream, a);
     }
   } else {

@@ -141,3 +141,33 @@ def test_segment_wide_attempts_parameters(native, oracle, kw, frames):
     for f in range(min(frames, 3)):
         want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=5 + f, **okw)
         assert np.array_equal(wide[f].astype(np.uint32), want), f"frame {f}: {(wide[f] != want).sum()} blocks differ"
+
+
+@pytest.mark.parametrize("flags", [4, 6], ids=["wide", "wide-nofork"])
+def test_segment_wide_attempts_take_the_light_frames_too(native, oracle, flags):
+    """With the multi-launch form on, EVERY frame of the batch goes through it, not only the heavy ones: frames of 1, 2, 3
+    and 12 small foreground squares (9 .. 108 blocks: fewer points than the 10 clusters, fewer than one wave, fewer than
+    one workgroup's chunk), of a few hundred and of 2 000 - 2 100 blocks (either side of the old light / heavy line), an
+    empty one and a scene cut, in one batch: region ids == oracle/svc_segment.c == the one-workgroup form."""
+    mfw, mfh = 240, 135
+    n = mfw * mfh
+    rng = np.random.default_rng(99)
+    yy, xx = np.mgrid[0:mfh, 0:mfw]
+    masks, mvs = [], []
+    for squares, side in ((1, 3), (2, 3), (3, 3), (12, 3), (9, 6), (0, 0), (1, 45), (1, 46), (1, 120)):
+        mask = np.ones((mfh, mfw), np.uint8)
+        for q in range(squares):
+            y, x = 4 + (q // 4) * (side + 3), 5 + (q % 4) * (side + 4)
+            mask[y:y + side, x:x + side] = 0
+        mv = np.stack([np.round(5 * np.cos(yy / 11.0) + rng.integers(-2, 3, (mfh, mfw))), rng.integers(-9, 10, (mfh, mfw))],
+                      -1).astype(np.float32)
+        masks.append(mask.reshape(-1)); mvs.append(mv.reshape(n, 2))
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    tm, tv = torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda()
+    wide = native.segment_frames(tm, tv, mfw, mfh, seed=31, flags=flags).cpu().numpy()
+    narrow = native.segment_frames(tm, tv, mfw, mfh, seed=31, flags=8).cpu().numpy()
+    assert np.array_equal(wide, narrow)
+    for f in range(len(masks)):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=31 + f)
+        assert np.array_equal(wide[f].astype(np.uint32), want), f"frame {f}: {(wide[f] != want).sum()} blocks differ"
+    assert [int((w != 0).sum()) for w in wide[:4]] == [9, 18, 27, 108] and not wide[5].any()
