@@ -438,16 +438,16 @@ __device__ __forceinline__ bool lloyd_end_iter(uint64_t lc, uint64_t& compact, u
 
 // One k-means attempt with the lane's points in registers: lane t owns the list entries
 // [t * pper, (t + 1) * pper), pper <= P.  `pk` is only read once, and for the drawn centres.
+// The k-means++ seeding of an attempt with the lane's points in registers (v: filled here and kept for the caller): on
+// return L.cint[0 .. k - 1] are the drawn centres (a barrier has passed).
 template <uint32_t P>
-__device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab, KmLds& L, const SegArgs& a,
-                                                uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te,
-                                                unsigned long long* stamps) {
+__device__ __forceinline__ void seed_regs(const uint32_t* pk, uint32_t (&v)[P], KmLds& L, const SegArgs& a, uint32_t nf,
+                                          uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te) {
   const uint32_t nw = te >> 6, wave = tid >> 6, lane = tid & 63u;
   const uint32_t bw = a.mv_bw, bh = a.mv_bh;
-  (void)stamps;
   const uint32_t pper = (nf + te - 1) / te;  // block-uniform, <= P
   const uint32_t p0 = tid * pper;
-  uint32_t v[P], dm[P];
+  uint32_t dm[P];
 #pragma unroll
   for (uint32_t t = 0; t < P; ++t) {
     v[t] = (t < pper && p0 + t < nf) ? pk[p0 + t] : 0u;
@@ -465,6 +465,9 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
 #pragma unroll
     for (uint32_t t = 0; t < P; ++t)
       if (t < pper) {
+        // many points per lane: keep them packed across the rounds (unpacked once outside the loop they would be 3 P
+        // registers and spill)
+        if constexpr (P > 8) asm volatile("" : "+v"(v[t]));
         const uint32_t m = p0 + t < nf ? min(dm[t], dist2_u32(unpack_pt(v[t], bw, bh), c)) : 0u;
         dm[t] = m;
         lsum += m;
@@ -507,6 +510,19 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
     }
     __syncthreads();
   }
+}
+
+template <uint32_t P>
+__device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab, KmLds& L, const SegArgs& a,
+                                                uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te,
+                                                unsigned long long* stamps) {
+  const uint32_t lane = tid & 63u;
+  const uint32_t bw = a.mv_bw, bh = a.mv_bh;
+  (void)stamps;
+  const uint32_t pper = (nf + te - 1) / te;  // block-uniform, <= P
+  const uint32_t p0 = tid * pper;
+  uint32_t v[P];
+  seed_regs<P>(pk, v, L, a, nf, k, aseed, tid, te);
   lloyd_begin(L, k, tid);
   SEG_STAMP(4);
 
@@ -943,6 +959,38 @@ __device__ __forceinline__ void wide_chunk(uint32_t nf, uint32_t G, uint32_t g, 
   const uint32_t chunk = (((nf + G - 1) / G) + 63u) & ~63u;
   w0 = min(nf, g * chunk);
   w1 = min(nf, w0 + chunk);
+}
+
+// The head of the launch sequence, one workgroup per (frame, attempt): the whole k-means++ seeding with the points in
+// registers (k - 1 rounds of one distance per point and a block-wide draw: 0.02 ms for a 4K scene cut, against k launches
+// of segment_wide_seed_kernel at 8 us each), for fields of at most kWideRegPts x 1024 blocks; frames of unpacked points
+// (none after block matching) get their whole attempt here, on the generic path.
+constexpr uint32_t kWideRegPts = 32;
+__global__ __launch_bounds__(kTA) void segment_wide_head_kernel(SegArgs a) {
+  __shared__ KmLds L;
+  const uint32_t tid = threadIdx.x, frame = blockIdx.x, att = blockIdx.y, n = a.n;
+  const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
+  const uint32_t nf = *ws.nf();
+  if (nf == 0) return;
+  const uint32_t k = min(a.k, nf);
+  const uint64_t aseed = (a.seed + frame) ^ ((uint64_t)att << 32);
+  if (*ws.packed() == 0) {
+    const uint64_t compact = kmeans_generic(ws.pts(), ws.lab(att), L, a, nf, k, aseed, tid, kTA);
+    if (tid == 0) ws.compact()[att] = compact;
+    return;
+  }
+  const uint32_t te = nf <= 256 ? 64u : nf <= 256 * kRegPts ? 256u : kTA;  // as the single-kernel attempts
+  if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
+  uint32_t v[kWideRegPts];
+  if (te == kTA) {
+    seed_regs<kWideRegPts>(ws.pk(), v, L, a, nf, k, aseed, tid, te);
+  } else {
+    uint32_t v8[kRegPts];
+    seed_regs<kRegPts>(ws.pk(), v8, L, a, nf, k, aseed, tid, te);
+  }
+  WideState& W = *ws.wide(att);
+  if (tid < k) { W.cint[tid][0] = L.cint[tid][0]; W.cint[tid][1] = L.cint[tid][1]; W.cint[tid][2] = L.cint[tid][2]; }
+  if (tid == 0) W.done = 0;
 }
 
 // Launch j = a.wide_step of the seeding (j = 0 .. k - 1): fixes centre j, then folds it into the running minima of this
@@ -1437,10 +1485,10 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   }
   hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);
   a.lds_bytes = 0;
-  auto launch_wide = [&](hipStream_t st) {
+  auto launch_wide = [&](hipStream_t st, bool seeds) {
     SegArgs w = a;
     const dim3 grid_w(a.wide_g, n_frames, p.attempt_count);
-    for (uint32_t j = 0; j < a.k; ++j) {
+    for (uint32_t j = 0; seeds && j < a.k; ++j) {
       w.wide_step = j;
       hipLaunchKernelGGL(segment_wide_seed_kernel, grid_w, dim3(kTW), 0, st, w);
     }
@@ -1455,10 +1503,15 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
     // every frame of packed points, light or heavy, rides the launch sequence (its length is set by k and max_iter, not by
     // the frames in it; a separate launch for the light frames would only add its 0.1 ms to the chain); the one attempt
     // launch in front of it takes the frames of unpacked points (none after block matching) and exits otherwise
-    SegArgs heavy = a;
-    heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
-    hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, stream, heavy);
-    launch_wide(stream);
+    if (a.n <= kWideRegPts * kTA) {  // seeding in one launch (points in registers), then the Lloyd launches
+      hipLaunchKernelGGL(segment_wide_head_kernel, grid_a, dim3(kTA), 0, stream, a);
+      launch_wide(stream, false);
+    } else {
+      SegArgs heavy = a;
+      heavy.lds_bytes = (uint32_t)(8 * n4 <= kLdsBig ? 8 * n4 : kLdsBig);
+      hipLaunchKernelGGL((segment_attempt_kernel<kTA>), grid_a, dim3(kTA), heavy.lds_bytes, stream, heavy);
+      launch_wide(stream, true);
+    }
   } else if (a.n > kLightMax) {
     // The two attempt launches are independent (each frame belongs to exactly one): the heavy one goes to a
     // side stream, forked after the prepare kernel and joined before the labelling, so a scene cut's long
