@@ -171,3 +171,27 @@ def test_segment_wide_attempts_take_the_light_frames_too(native, oracle, flags):
         want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=31 + f)
         assert np.array_equal(wide[f].astype(np.uint32), want), f"frame {f}: {(wide[f] != want).sum()} blocks differ"
     assert [int((w != 0).sum()) for w in wide[:4]] == [9, 18, 27, 108] and not wide[5].any()
+
+
+def test_segment_wide_attempts_with_unpacked_frames(native, oracle):
+    """A frame whose points do not pack (|mv.x| >= 8192: never produced by block matching, allowed by the API) inside a batch
+    that runs the multi-launch form: the head launch of the sequence gives it its whole attempt on the generic path, the other
+    frames go through seeding + Lloyd launches; 240 x 135 (seeding in one launch) and 480 x 270 (one launch per centre)."""
+    for mfw, mfh in ((240, 135), (480, 270)):
+        n = mfw * mfh
+        rng = np.random.default_rng(mfw)
+        masks, mvs = [], []
+        for f, d in enumerate((0.6, 0.1, 0.9)):
+            mask = (~(rng.random((mfh, mfw)) < d)).astype(np.uint8).reshape(-1)
+            mv = np.stack([rng.integers(-6, 7, (mfh, mfw)), rng.integers(-6, 7, (mfh, mfw))], -1).astype(np.float32).reshape(n, 2)
+            if f == 1:
+                mv[mask == 0, 0] *= 2000.0
+            masks.append(mask); mvs.append(mv)
+        masks, mvs = np.stack(masks), np.stack(mvs)
+        tm, tv = torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda()
+        wide = native.segment_frames(tm, tv, mfw, mfh, seed=3, flags=4).cpu().numpy()
+        narrow = native.segment_frames(tm, tv, mfw, mfh, seed=3, flags=8).cpu().numpy()
+        assert np.array_equal(wide, narrow)
+        for f in (0, 1):
+            want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=3 + f)
+            assert np.array_equal(wide[f].astype(np.uint32), want), f"{mfw}x{mfh} frame {f}: {(wide[f] != want).sum()} blocks differ"
