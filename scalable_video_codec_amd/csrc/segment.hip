@@ -946,7 +946,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 // ---- an attempt as a SEQUENCE OF LAUNCHES over G workgroups (few frames, large fields) ---------------------------
 // One (frame, attempt) of the kernel above is bound to one CU by its ~40 workgroup barriers: 0.57 ms for a 4K scene cut
 // (29 600 foreground blocks), which is what an 8-frame shard of a 4K clip then waits for while 230 CUs idle.  When
-// frames x attempts is small the host instead runs the attempt as k + max_iter + 1 launches of G workgroups per (frame,
+// frames x attempts is small the host instead runs the attempt as a sequence of launches of G workgroups per (frame,
 // attempt): every grid-wide reduction of the algorithm (the k-means++ draw, the centre update) sits on a kernel boundary,
 // so there is no spin-wait and no residency assumption.  A launch reads only what EARLIER launches wrote (WideState);
 // inside a launch every workgroup recomputes the shared quantities (draw, centres, convergence) redundantly from the
@@ -1082,7 +1082,8 @@ __global__ __launch_bounds__(kTW) void segment_wide_seed_kernel(SegArgs a) {
 
 // Launch it = a.wide_step of the Lloyd iterations (it = 0 .. max_iter): closes iteration it - 1 (compactness, centre
 // update, convergence: lloyd_end_iter's arithmetic in lloyd_end_iter's order), then assigns this workgroup's chunk to
-// the new centres and publishes its per-cluster sums.  Launch max_iter only closes.
+// the new centres and publishes its per-cluster sums.  The close of the last iteration (it = max_iter: nothing but the sum of
+// the workgroups' compactness) is done by the labelling kernel, which saves a launch in a latency-bound chain.
 __global__ __launch_bounds__(kTW) void segment_wide_lloyd_kernel(SegArgs a) {
   __shared__ double s_c[kMaxK][3];
   __shared__ double s_shift[kMaxK];
@@ -1246,10 +1247,25 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   for (uint32_t i = tid; i < n; i += kTA) { types[i] = 0; cl[i] = 255; }  // :549-551
   if (nf == 0) return;
   const uint32_t k = min(a.k, nf);
+  __shared__ unsigned long long s_compact[kMaxAttempts];
+  if (tid < a.attempts) {
+    unsigned long long c = ws.compact()[tid];
+    if (a.wide_g && *ws.packed() != 0) {
+      // an attempt of the launch sequence that ran to the iteration cap: its last Lloyd launch left the per-workgroup
+      // compactness of iteration max_iter - 1, and lloyd_end_iter's "it + 1 >= max_iter" close is this sum
+      const WideState& W = *ws.wide(tid);
+      if (!W.done) {
+        c = 0;
+        for (uint32_t g = 0; g < a.wide_g; ++g) c += W.compact[(a.max_iter - 1) & 1u][g];
+      }
+    }
+    s_compact[tid] = c;
+  }
+  __syncthreads();
   uint32_t best = 0;
-  unsigned long long best_c = ws.compact()[0];
+  unsigned long long best_c = s_compact[0];
   for (uint32_t t = 1; t < a.attempts; ++t) {
-    const unsigned long long c = ws.compact()[t];
+    const unsigned long long c = s_compact[t];
     if (c < best_c) { best_c = c; best = t; }
   }
   const uint8_t* best_lab = ws.lab(best);
@@ -1492,7 +1508,7 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
       w.wide_step = j;
       hipLaunchKernelGGL(segment_wide_seed_kernel, grid_w, dim3(kTW), 0, st, w);
     }
-    for (uint32_t it = 0; it <= a.max_iter; ++it) {
+    for (uint32_t it = 0; it < a.max_iter; ++it) {  // the close of iteration max_iter - 1 is the labelling kernel's first step
       w.wide_step = it;
       hipLaunchKernelGGL(segment_wide_lloyd_kernel, grid_w, dim3(kTW), 0, st, w);
     }
