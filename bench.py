@@ -540,7 +540,7 @@ def main() -> None:
                 "avg_launch_ms": hbma_ms,
                 "launches_per_step": nl["hbma"],
                 "note": "HBM is the stated bound; measured VALU busy ~86 % (byte-SAD ops issue at 4 cycles/wave): VALU time ~= HBM floor, DESIGN.md 4.1"
-                        + ("; on shards (N > 1, short clips) it is timed beside the previous step's RANSAC + segmentation kernels (pipelined schedule, early fork)" if args.schedule == "pipelined" else ""),
+                        + ("; RANSAC + segmentation of an earlier step may still be running beside it (pipelined schedule)" if args.schedule == "pipelined" else ""),
             }
             if "dct_quant" in kt:
                 dct_bytes = cfg.dct_bytes_per_frame() * info.pairs

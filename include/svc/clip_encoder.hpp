@@ -19,9 +19,8 @@
 // Step() the main stream carries luma+pyramid of the newest step, the motion search of the one
 // before and the transform of the step four back -- the HBM-bound kernels, back to back -- while
 // RANSAC + segmentation (latency-bound: one workgroup per frame) of the step two back start beside
-// them on a stream of their own (forked at the start of the iteration on the shards of a multi-GPU run and on short
-// clips; behind the motion search when a whole long clip is on the GPU, where both forks cost the same and the late
-// one keeps the MAD kernel alone on the chip) and have two iterations to finish, consecutive steps alternating between
+// them on a stream of their own (forked at the start of the iteration, in front of the luma launch) and have two
+// iterations to finish, consecutive steps alternating between
 // two such streams, and the halo of the newest step crosses xGMI meanwhile.  The small per-frame outputs exist in four
 // sets, pyramids in two; Flush() drains the pipeline.
 #ifndef SVC_CLIP_ENCODER_HPP

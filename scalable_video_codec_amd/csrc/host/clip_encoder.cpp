@@ -86,11 +86,10 @@ struct ClipEncoder::Impl {
   HaloFn halo;
   // pipeline progress: steps whose stage has been enqueued
   uint64_t n_luma = 0, n_hbma = 0, n_lat = 0, n_dct = 0;
-  // Where RANSAC + segmentation fork off the main stream.  Measured at C3 (ms per step, late / early fork): 300 frames
-  // 2.558 / 2.554, 150 frames 1.353 / 1.310, 75 frames 0.726 / 0.689, 38 frames 0.419 / 0.376.  With a whole clip on the
-  // GPU the two are equal and the late fork keeps the MAD kernel alone on the chip (0.274 vs 0.297 ms); on the shards of
-  // a multi-GPU run the early fork gives the latency-bound stages the whole iteration to hide behind.
-  bool fork_early = false;
+  // RANSAC + segmentation fork off the main stream where the previous iteration's main-stream work ends (in front of the
+  // luma launch), not behind the motion search: measured at C3 (ms per step, late / early): 150 frames 1.353 / 1.310, 75
+  // frames 0.726 / 0.689, 38 frames 0.419 / 0.376 (round 2); whole clips on the round-3 build: C3 2.41 / 2.38, C3b 2.52 /
+  // 2.50, C5 2.35 / 2.34, and C5's MAD kernel runs alone (0.272 -> 0.238 ms): profiles/r03_ab_fork_full.txt, r03_ab_fork_4k.txt.
   // pipelined schedule: RANSAC + segmentation run beside the main stream's kernels and ask for shapes that fit there
   uint32_t lat_flags = 0;
   bool fused_records = false;  // wire output straight from the transform kernel (square transform blocks)
@@ -273,7 +272,7 @@ struct ClipEncoder::Impl {
     // draining (no new step) joins at once; otherwise the transform of step d waits until lat(d) has had its iterations
     const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Set(d)] >= (uint64_t)depth);
     const bool replay = c.graph && do_hbma && do_lat && do_dct && !timing;
-    if (do_lat && fork_early && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
+    if (do_lat && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
     if (new_step) {
       const uint64_t s = n_luma;
       const int b = Par(s);
@@ -306,9 +305,6 @@ struct ClipEncoder::Impl {
       Hip(hipGraphLaunch(gexec[b], sM), "hipGraphLaunch");
     } else {
       if (do_hbma) Hbma(h, sM, timing);
-      // big shards: forked BEHIND the motion search -- RANSAC + segmentation run beside the transform (the long,
-      // store-bound kernel) and the next step's luma + pyramid, never beside the MAD kernel
-      if (do_lat && !fork_early) ForkLat(l, timing);
       if (do_dct) {
         JoinLat(d);
         Transform(d, sM, timing);
@@ -351,7 +347,6 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   }
   if (c.narrow_attempts) m.lat_flags |= SVC_LAUNCH_NO_WIDE;
   if (c.lat_depth > (uint32_t)Impl::kMaxDepth) throw std::runtime_error("svc::ClipEncoder: lat_depth must be 0..3");
-  m.fork_early = c.world > 1 || (uint64_t)m.sh.pairs * ((uint64_t)((c.width + c.mv_block - 1) / c.mv_block) * ((c.height + c.mv_block - 1) / c.mv_block)) < 1600000ull;
   const uint32_t f = 1u << (c.levels - 1);
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
   m.ph = ClosestLargerDivisible(c.height, c.mv_block, f);
