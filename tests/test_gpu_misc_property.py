@@ -99,6 +99,36 @@ def test_segment_random_large_fields(native, oracle, mfw, mfh, density, blobs, s
         assert np.array_equal(got[f].astype(np.uint32), want), (f, mfw, mfh, density, blobs, conn, k, attempts, mw, mh, iters)
 
 
+@settings(max_examples=fuzz_examples(20), **_S)
+@given(mfw=st.integers(100, 260), mfh=st.integers(82, 160), dens=st.lists(st.floats(0.0, 1.0), min_size=1, max_size=4),
+       seed=st.integers(0, 2 ** 31 - 1), conn=st.sampled_from([4, 8]), k=st.integers(1, 24), attempts=st.integers(1, 4),
+       iters=st.integers(1, 12), eps=st.sampled_from([1.0, 25.0]))
+def test_segment_random_4k_fields_as_launch_sequences(native, oracle, mfw, mfh, dens, seed, conn, k, attempts, iters, eps):
+    """4K-sized fields (8 200 .. 41 600 blocks: the seeding in one launch up to 32 768 blocks, one launch per centre above) with
+    the multi-launch k-means attempts forced on: 1 .. 4 frames per call from empty to a scene cut, any cluster / attempt /
+    iteration count (the close of an attempt that runs to the cap is the labelling kernel's), against the oracle and the
+    one-workgroup form."""
+    rng = np.random.default_rng(seed)
+    n = mfw * mfh
+    yy, xx = np.mgrid[0:mfh, 0:mfw]
+    masks, mvs = [], []
+    for f, d in enumerate(dens):
+        fg = rng.random((mfh, mfw)) < d
+        mv = np.stack([np.round(6 * np.sin(xx / 19.0 + f) + 4 * (yy > mfh // 3) + rng.integers(-2, 3, (mfh, mfw))),
+                       rng.integers(-9, 10, (mfh, mfw))], -1).astype(np.float32).reshape(n, 2)
+        masks.append((~fg).astype(np.uint8).reshape(-1)); mvs.append(mv)
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    tm, tv = torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda()
+    kw = dict(seed=seed & 0xFFFF, connectivity=conn, cluster_count=k, attempt_count=attempts, max_iter_count=iters, epsilon=eps)
+    wide = native.segment_frames(tm, tv, mfw, mfh, flags=4, **kw).cpu().numpy()
+    narrow = native.segment_frames(tm, tv, mfw, mfh, flags=8, **kw).cpu().numpy()
+    assert np.array_equal(wide, narrow), (mfw, mfh, dens, conn, k, attempts, iters, eps)
+    f = int(np.argmax(dens))  # the heaviest frame against the oracle
+    want = oracle.segment(masks[f], mvs[f], mfw, mfh, connectivity=conn, cluster_count=k, attempts=attempts, max_iter=iters,
+                          epsilon=eps, seed=(seed & 0xFFFF) + f)
+    assert np.array_equal(wide[f].astype(np.uint32), want), (f, mfw, mfh, dens, conn, k, attempts, iters, eps)
+
+
 @settings(max_examples=fuzz_examples(25), **_S)
 @given(kx=st.integers(1, 6), ky=st.integers(1, 5), block=st.sampled_from([8, 16]), cut=st.integers(0, 1),
        seed=st.integers(0, 2 ** 31 - 1), quant=st.booleans())
