@@ -149,7 +149,7 @@ int svc_hip_ransac_frames(const float* d_mv_xy, uint32_t blocks, uint32_t n_fram
  * next kernel back for the length of an attempt kernel. */
 #define SVC_LAUNCH_NO_FORK 2u
 /* Segmentation, fields above 8 192 blocks: a heavy frame's k-means attempts as launch sequences over several workgroups
- * (default: only when frames x attempts would leave more than half of the CUs idle).  _WIDE forces that form, _NO_WIDE the
+ * (default: only when frames x attempts does not exceed the number of CUs).  _WIDE forces that form, _NO_WIDE the
  * one-workgroup form; results are identical. */
 #define SVC_LAUNCH_WIDE 4u
 #define SVC_LAUNCH_NO_WIDE 8u

@@ -1486,7 +1486,9 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
   a.take_all = small ? 1u : 0u;
   if (small) a.lds_bytes = a.bits_bytes + 16;  // the foreground list goes to the workspace
   // Few frames of a large field (the shard of a multi-GPU 4K run): a heavy frame's attempts run as launch sequences over
-  // wide_g workgroups each instead of one workgroup (segment_wide_*_kernel) -- when they would otherwise leave most CUs idle.
+  // wide_g workgroups each instead of one workgroup (segment_wide_*_kernel) -- when one workgroup per (frame, attempt) would
+  // not even fill the CUs.  (Up to frames x attempts = CUs: C5's whole 64-frame clip, 192 of them, runs 0.85 -> 0.56 ms alone and
+  // level beside the main stream's kernels, profiles/r03_ab_wide64.txt.)
   a.wide_g = 0;
   a.wide_step = 0;
   if (!small && a.packable && a.n > kRegPts * kTA && !(flags & SVC_LAUNCH_NO_WIDE)) {
@@ -1496,7 +1498,7 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
       return (uint32_t)v;
     }();
     const uint64_t work = (uint64_t)n_frames * p.attempt_count;
-    if ((flags & SVC_LAUNCH_WIDE) || 2 * work <= cus)
+    if ((flags & SVC_LAUNCH_WIDE) || work <= cus)
       a.wide_g = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4 * (uint64_t)cus / std::max<uint64_t>(work, 1), 2), kWideMaxG);  // ~4 workgroups per CU
   }
   hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);
