@@ -32,6 +32,9 @@ typedef struct svc_clip svc_clip;
 #define SVC_CLIP_TUNE_NARROW_ATTEMPTS 4u   /* segmentation: never spread a heavy frame's k-means attempts over workgroups */
 
 typedef struct svc_clip_config {
+  uint32_t struct_size;   /* sizeof(svc_clip_config) of the caller's build: svc_clip_create refuses any other value, so a
+                             caller compiled against an older / newer layout fails loudly instead of feeding garbage into
+                             the trailing fields */
   uint32_t width, height; /* source size (padded per libs/encoder.cpp:164-168) */
   uint32_t levels, mv_block, search_range;
   uint32_t dct_block_w, dct_block_h; /* 0 = no transform */
@@ -77,6 +80,8 @@ const char* svc_clip_last_error(void);
 int svc_clip_plan_shard(uint32_t clip_frames, uint32_t world, uint32_t rank, uint32_t* first_frame,
                         uint32_t* frames, uint32_t* pairs, uint32_t* first_encoded);
 
+/* 1 (with svc_clip_last_error set) for a null pointer, config->struct_size != sizeof(svc_clip_config), an hbma_flags / tuning
+ * bit this build does not know, lat_depth > 3, or any configuration svc::ClipEncoder rejects. */
 int svc_clip_create(const svc_clip_config* config, svc_clip** out);
 void svc_clip_destroy(svc_clip* clip);
 int svc_clip_get_info(svc_clip* clip, svc_clip_info* out);

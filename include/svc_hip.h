@@ -71,7 +71,7 @@ typedef struct svc_segment_params {
 #define SVC_HBMA_FORCE_LANE 8u           /* fused kernel, lane-per-block form without LDS (every fused shape) */
 
 const char* svc_hip_last_error(void);
-int svc_hip_abi_version(void); /* 3 (round 3: additions only -- SVC_HBMA_FORCE_TILED / _LANE, svc_hip_comm_available / _info, svc_hip_hbma_kernel_name) */
+int svc_hip_abi_version(void); /* 4 (round 4: additions only -- svc_hip_dct_planes_host and the per-call image operations svc_hip_bgr2yuv_host ... svc_hip_dct_tiles_host) */
 int svc_hip_device_count(int* count);
 
 /* Measurement aid, not part of the hot path: one launch of a plain streaming kernel (dwordx4 per lane,
@@ -418,6 +418,69 @@ int svc_hip_ransac_host(const float* mv_xy, uint32_t blocks,
 
 int svc_hip_dct_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h,
                      uint32_t block_w, uint32_t block_h, float* planes);
+
+/* The same with D2H straight into the caller's three plane buffers (B, G, R order; any may alias none): what the C++
+ * Dct() wrapper of include/svc/motion.hpp and the OpenCV-shaped adapter (compat/opencv2/) call -- no packed intermediate. */
+int svc_hip_dct_planes_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h, uint32_t block_w,
+                            uint32_t block_h, float* const planes[3]);
+
+/* ------------------------------------------------------------------------- *
+ * Image operations, host-pointer forms: ONE ENTRY POINT PER OpenCV CALL of the reference's per-frame loop
+ * (libs/encoder.cpp:447-640) that does arithmetic -- for a host whose control flow stays the reference's own
+ * Encoder::operator() (the adapter under compat/opencv2/ makes cv::cvtColor, cv::buildPyramid, cv::morphologyEx,
+ * cv::kmeans, cv::connectedComponents and cv::dct thin callers of these).  All images are tightly packed
+ * (row stride = width x channels); all calls are synchronous and thread-safe like the other *_host forms.  The OpenCV
+ * semantics followed are the ones stated in oracle/svc_oracle.h / oracle/svc_segment.c (parity with OpenCV itself is
+ * unpinned offline); the fused, batched device forms above (svc_hip_luma_pyramid_frames, svc_hip_segment_frames,
+ * svc_hip_dct_frames) compute the same values and are what a throughput-minded caller uses.
+ * ------------------------------------------------------------------------- */
+
+/* cv::cvtColor(src, dst, COLOR_BGR2YUV), 8-bit (libs/encoder.cpp:449, :468): 14-bit fixed point,
+ * Y = (1868 B + 9617 G + 4899 R + 8192) >> 14, U = ((B - Y) * 8061 + (128 << 14) + 8192) >> 14,
+ * V = ((R - Y) * 14369 + (128 << 14) + 8192) >> 14, saturated to 0..255; dst interleaved Y,U,V. */
+int svc_hip_bgr2yuv_host(const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* yuv);
+
+/* cv::buildPyramid(level0, levels, level_count - 1) (libs/encoder.cpp:451, :470) on one 8-bit plane: out_levels[l] for
+ * l = 1 .. level_count - 1 receives (w >> l) x (h >> l); out_levels[0] is ignored (OpenCV's level 0 IS the source).
+ * w and h must be divisible by 2^(level_count - 1) (what the encoder pads to, libs/encoder.cpp:164-168). */
+int svc_hip_build_pyramid_host(const uint8_t* level0, uint32_t w, uint32_t h, uint32_t level_count,
+                               uint8_t* const* out_levels);
+
+/* cv::erode / cv::dilate / cv::morphologyEx(MORPH_OPEN | MORPH_CLOSE) with a rectangular kernel_w x kernel_h element
+ * anchored at its centre (kernel_w / 2, kernel_h / 2), one iteration, on an 8-bit single-channel image
+ * (libs/encoder.cpp:524-527 on the MV-field mask).  Pixels outside the image are ignored
+ * (cv::morphologyDefaultBorderValue()).  src == dst is allowed. */
+#define SVC_MORPH_ERODE 0u
+#define SVC_MORPH_DILATE 1u
+#define SVC_MORPH_OPEN 2u
+#define SVC_MORPH_CLOSE 3u
+int svc_hip_morph_rect_host(const uint8_t* src, uint32_t w, uint32_t h, uint32_t kernel_w, uint32_t kernel_h,
+                            uint32_t op, uint8_t* dst);
+
+/* cv::kmeans(data, K, labels, TermCriteria(COUNT | EPS, max_iter, epsilon), attempts, KMEANS_PP_CENTERS)
+ * (libs/encoder.cpp:575-576) by this repo's deterministic definition (oracle/svc_segment.c): `features` is n points of
+ * `dims` (1..4) f32 coordinates, which must be integers of magnitude below 32768 (block-matching output and pixel
+ * positions are); k-means++ seeding with exact integer weights and a counter hash of `seed` in place of cv::theRNG(),
+ * Lloyd iterations with integer sums / counts and f64 distances in coordinate order, the attempt with the smallest
+ * fixed-point compactness wins (ties: the earlier one).  labels: n cluster ids in [0, k); *compactness (may be NULL):
+ * sum over the points of the squared distance to their centre, as cv::kmeans returns it (here in 1/256 steps).
+ * n >= k >= 1, k <= 64, attempts <= 16. */
+int svc_hip_kmeans_host(const float* features, uint32_t n, uint32_t dims, uint32_t k, uint32_t attempts,
+                        uint32_t max_iter, float epsilon, uint64_t seed, int32_t* labels, double* compactness);
+
+/* cv::connectedComponents(image, labels, connectivity, CV_32S) (libs/encoder.cpp:607-610): non-zero pixels of the
+ * 8-bit image are foreground; labels[y][x] = 0 for background, 1 .. n for the components, numbered in raster order of
+ * each component's first pixel; *count = n + 1 (OpenCV's return value counts the background label). */
+int svc_hip_connected_components_host(const uint8_t* image, uint32_t w, uint32_t h, uint32_t connectivity,
+                                      int32_t* labels, uint32_t* count);
+
+/* cv::dct(tile, tile) (flags 0: forward orthonormal DCT-II, libs/encoder.cpp:335) over MANY tiles of one f32 image
+ * in one launch, in place: tiles_xy holds n_tiles top-left corners {x, y} of block_w x block_h tiles inside the
+ * w x h image (they must not overlap); tiles_xy == NULL means every tile of the regular (w / block_w) x (h / block_h)
+ * grid.  Sides as svc_hip_dct_frames takes them (even, or a single row / column of even length, up to 64).  f64
+ * accumulation, rounded once to f32. */
+int svc_hip_dct_tiles_host(float* image, uint32_t w, uint32_t h, uint32_t block_w, uint32_t block_h,
+                           const uint32_t* tiles_xy, uint32_t n_tiles);
 
 int svc_hip_dct_quant_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h,
                            uint32_t block_w, uint32_t block_h,

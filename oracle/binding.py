@@ -82,6 +82,15 @@ class Oracle:
         L.svc_oracle_global_hbma.argtypes = [_u8pp, _u8pp] + [C.c_uint32] * 4 + [C.c_int, _f32p]
         L.svc_oracle_segment.restype = C.c_int
         L.svc_oracle_segment.argtypes = [_u8p, _f32p] + [C.c_uint32] * 9 + [C.c_float, C.c_uint32, C.c_uint64, _u32p]
+        _i32p = C.POINTER(C.c_int32)
+        L.svc_oracle_bgr2yuv.restype = None
+        L.svc_oracle_bgr2yuv.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p]
+        L.svc_oracle_morph_rect.restype = None
+        L.svc_oracle_morph_rect.argtypes = [_u8p] + [C.c_uint32] * 5 + [_u8p]
+        L.svc_oracle_kmeans.restype = C.c_int
+        L.svc_oracle_kmeans.argtypes = [_f32p] + [C.c_uint32] * 5 + [C.c_float, C.c_uint64, _i32p, _f64p]
+        L.svc_oracle_connected_components.restype = C.c_uint32
+        L.svc_oracle_connected_components.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
         L.svc_oracle_serialize_frame.restype = C.c_uint64
         L.svc_oracle_serialize_frame.argtypes = [_f32p, C.c_uint64, C.c_uint32, _u32p] + [C.c_uint32] * 7 + [_u8p]
         L.svc_oracle_decode_frame.restype = None
@@ -250,6 +259,71 @@ class Oracle:
         s = np.ascontiguousarray(src_bgr, np.uint8)
         r = np.ascontiguousarray(rec_bgr, np.float32)
         return int(self.lib.svc_oracle_sse_frame(_ptr(s, _u8p), _ptr(r, _f32p), s.shape[1], region_w, region_h))
+
+    # -- the per-call image operations (svc_imageops.c) --
+    def bgr2yuv(self, bgr):
+        src = np.ascontiguousarray(bgr, np.uint8)
+        out = np.empty_like(src)
+        self.lib.svc_oracle_bgr2yuv(_ptr(src, _u8p), src.shape[1], src.shape[0], _ptr(out, _u8p))
+        return out
+
+    def morph_rect(self, img, kw, kh, op):
+        src = np.ascontiguousarray(img, np.uint8)
+        out = np.empty_like(src)
+        self.lib.svc_oracle_morph_rect(_ptr(src, _u8p), src.shape[1], src.shape[0], kw, kh, op, _ptr(out, _u8p))
+        return out
+
+    def kmeans(self, features, k, attempts=3, max_iter=10, epsilon=1.0, seed=0):
+        f = np.ascontiguousarray(features, np.float32)
+        n, dims = f.shape
+        labels = np.empty(n, np.int32)
+        compact = C.c_double(0.0)
+        rc = self.lib.svc_oracle_kmeans(_ptr(f, _f32p), n, dims, k, attempts, max_iter, epsilon, seed,
+                                        labels.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(compact))
+        if rc:
+            raise ValueError("svc_oracle_kmeans: invalid parameter")
+        return labels, compact.value
+
+    def connected_components(self, img, connectivity=4):
+        src = np.ascontiguousarray(img, np.uint8)
+        labels = np.empty(src.shape, np.int32)
+        count = self.lib.svc_oracle_connected_components(_ptr(src, _u8p), src.shape[1], src.shape[0], connectivity,
+                                                         labels.ctypes.data_as(C.POINTER(C.c_int32)))
+        return labels, int(count)
+
+    def segment_by_calls(self, inlier_indices, mv, mfw, mfh, mv_bw=16, mv_bh=16, morph_w=3, morph_h=3, cluster_count=10,
+                         attempts=3, max_iter=10, epsilon=1.0, connectivity=4, seed=0):
+        """libs/encoder.cpp:507-623 composed from the per-call functions exactly as the reference composes the cv::
+        calls (mask, close, open, index list, BuildMvFeatures with its m.y overwrite, kmeans, one connectedComponents per
+        cluster, offset numbering): must equal segment()."""
+        n = mfw * mfh
+        fg = np.full(n, 255, np.uint8)
+        fg[np.asarray(inlier_indices, np.int64)] = 0                               # :507-513
+        fg = self.morph_rect(fg.reshape(mfh, mfw), morph_w, morph_h, 3)            # :524-525 close
+        fg = self.morph_rect(fg, morph_w, morph_h, 2).reshape(-1)                  # :526-527 open
+        idx = np.nonzero(fg == 255)[0]                                             # :538-546
+        types = np.zeros(n, np.uint32)                                             # :549-551
+        if len(idx) == 0:
+            return types
+        k = min(cluster_count, len(idx))                                           # :555
+        mvv = np.asarray(mv, np.float32).reshape(n, 2)
+        # :300-321 with libs/math.hpp:285-291: Vec4f is {w, x, y, z} and operator[](i) is (&x)[i], so features[i][0..2]
+        # write memory slots 1..3 and slot 0 (w) keeps the 0 of vector::resize: (0, m.x, x_px, y_px), m.y overwritten
+        feats = np.zeros((len(idx), 4), np.float32)
+        feats[:, 1] = mvv[idx, 0]
+        feats[:, 2] = (idx % mfw) * mv_bw
+        feats[:, 3] = (idx // mfw) * mv_bh
+        labels, _ = self.kmeans(feats, k, attempts, max_iter, epsilon, seed)       # :575-576
+        offset = 0
+        for cid in range(k):                                                       # :597-623
+            m = np.zeros(n, np.uint8)
+            m[idx[labels == cid]] = 255
+            cc, count = self.connected_components(m.reshape(mfh, mfw), connectivity)
+            cc = cc.reshape(-1)
+            sel = idx[cc[idx] != 0]
+            types[sel] = cc[sel].astype(np.uint32) + offset
+            offset += count
+        return types
 
     # -- quant / DCT --
     def quant(self, coeffs, step):

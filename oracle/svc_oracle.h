@@ -156,6 +156,17 @@ int svc_oracle_segment(const uint8_t* inlier_mask, const svc_oracle_vec2f* mv,
                        uint32_t attempts, uint32_t max_iter, float epsilon,
                        uint32_t connectivity, uint64_t seed, uint32_t* block_types);
 
+/* ---- the per-call forms (oracle/svc_imageops.c): one function per OpenCV call of libs/encoder.cpp:447-640, the checkers
+ * of include/svc_hip.h's "Image operations".  PARITY UNPINNED like the fused forms above (OpenCV absent). ---- */
+void svc_oracle_bgr2yuv(const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* yuv); /* cv::cvtColor(BGR2YUV), :449 */
+/* cv::erode / dilate / morphologyEx OPEN / CLOSE (:524-527); op 0 erode, 1 dilate, 2 open, 3 close */
+void svc_oracle_morph_rect(const uint8_t* src, uint32_t w, uint32_t h, uint32_t kw, uint32_t kh, uint32_t op, uint8_t* dst);
+/* cv::kmeans (:575-576) on n points of dims (1..4) integral coordinates; 0 = ok */
+int svc_oracle_kmeans(const float* features, uint32_t n, uint32_t dims, uint32_t k, uint32_t attempts, uint32_t max_iter,
+                      float epsilon, uint64_t seed, int32_t* labels, double* compactness);
+/* cv::connectedComponents (:607-610); returns the component count including the background label */
+uint32_t svc_oracle_connected_components(const uint8_t* image, uint32_t w, uint32_t h, uint32_t connectivity, int32_t* labels);
+
 /* libs/decoder.cpp:130-144 (quant lines of DecodeBlock), one coefficient run. */
 void svc_oracle_quant(float* coeffs, uint64_t n, uint32_t step);
 

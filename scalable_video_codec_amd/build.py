@@ -23,7 +23,7 @@ OBJ = os.path.join(PKG, "_obj")
 LIB_HIP = os.path.join(PKG, "libsvc_hip.so")
 LIB_MOTION = os.path.join(PKG, "libsvc_motion.so")
 
-HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "hbma_fused8.hip", "hbma_fused32.hip", "hbma_tiled.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip", "global_motion.hip"]
+HIP_SOURCES = ["capi.hip", "hbma_wave.hip", "hbma_fused.hip", "hbma_fused8.hip", "hbma_fused32.hip", "hbma_tiled.hip", "dct.hip", "ransac.hip", "luma_pyramid.hip", "segment.hip", "wire.hip", "idct.hip", "probe.hip", "comm.hip", "global_motion.hip", "imageops.hip"]
 HOST_SOURCES = [os.path.join("host", "motion_hip.cpp")]
 
 # -ffp-contract=off: the reference's float expressions (RANSAC inlier test, quant) are
@@ -32,7 +32,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
                "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
-# A/B experiments: extra device-compile flags (e.g. -DSVC_HBMA_WAVES8) without editing the sources
+# A/B experiments: extra device-compile flags (-D... of a variant under test) without editing the sources
 EXTRA_FLAGS = os.environ.get("SVC_EXTRA_HIPCC_FLAGS", "").split()
 
 
@@ -59,7 +59,7 @@ def _run(cmd: List[str]) -> None:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "hbma_fused_kernel.hpp"), os.path.join(CSRC, "dct_tables.inc"),
+    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "union_find.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "hbma_fused_kernel.hpp"), os.path.join(CSRC, "dct_tables.inc"),
                os.path.join(INCLUDE, "svc_hip.h")]
     jobs, objs = [], []
     for s in HIP_SOURCES:

@@ -29,7 +29,7 @@ COMM_ID_BYTES = 128
 
 
 class ClipConfig(C.Structure):
-    _fields_ = [("width", _u32), ("height", _u32), ("levels", _u32), ("mv_block", _u32), ("search_range", _u32),
+    _fields_ = [("struct_size", _u32), ("width", _u32), ("height", _u32), ("levels", _u32), ("mv_block", _u32), ("search_range", _u32),
                 ("dct_block_w", _u32), ("dct_block_h", _u32), ("fg_step", _u32), ("bg_step", _u32), ("wire", _u32),
                 ("segmentation", _u32), ("seed", _u64), ("ransac", RansacParams), ("segment", SegmentParams),
                 ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("graph", _u32),
@@ -150,7 +150,7 @@ class Clip:
         s = dict(native.DEFAULT_SEGMENT)
         s.update(segment or {})
         bw, bh = dct_block if dct_block is not None else (cfg.dct_block, cfg.dct_block)
-        self.config = ClipConfig(cfg.width, cfg.height, cfg.levels, cfg.mv_block, cfg.search_range, bw, bh,
+        self.config = ClipConfig(C.sizeof(ClipConfig), cfg.width, cfg.height, cfg.levels, cfg.mv_block, cfg.search_range, bw, bh,
                                  cfg.fg_step, cfg.bg_step, int(wire), int(segmentation),
                                  cfg.seed if seed is None else seed, RansacParams(**r), SegmentParams(**s),
                                  clip_frames, rank, world, schedule, int(graph), hbma_flags, lat_depth, tuning)

@@ -56,34 +56,27 @@ int launch_hbma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64_t pair
 }
 
 // ---- per-thread staging for the host-pointer entry points ----------------------
-struct Staging {
-  hipStream_t stream = nullptr;
-  uint8_t* dev = nullptr;
-  uint8_t* pin = nullptr;
-  size_t cap = 0;
-  ~Staging() {
-    if (dev) (void)hipFree(dev);
-    if (pin) (void)hipHostFree(pin);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-  int ensure(size_t bytes) {
-    if (!stream) SVC_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    if (bytes <= cap) return SVC_OK;
-    if (dev) { (void)hipFree(dev); dev = nullptr; }
-    if (pin) { (void)hipHostFree(pin); pin = nullptr; }
-    cap = 0;
-    size_t want = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
-    SVC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), want));
-    SVC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), want, hipHostMallocDefault));
-    cap = want;
-    return SVC_OK;
-  }
-};
+Staging::~Staging() {
+  if (dev) (void)hipFree(dev);
+  if (pin) (void)hipHostFree(pin);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+int Staging::ensure(size_t bytes) {
+  if (!stream) SVC_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  if (bytes <= cap) return SVC_OK;
+  if (dev) { (void)hipFree(dev); dev = nullptr; }
+  if (pin) { (void)hipHostFree(pin); pin = nullptr; }
+  cap = 0;
+  size_t want = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+  SVC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), want));
+  SVC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), want, hipHostMallocDefault));
+  cap = want;
+  return SVC_OK;
+}
 static thread_local Staging g_stage;
+Staging& host_stage() { return g_stage; }
 
-static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-static int require_device() {
+int require_device() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -99,7 +92,7 @@ using namespace svc;
 extern "C" {
 
 const char* svc_hip_last_error(void) { return g_err; }
-int svc_hip_abi_version(void) { return 3; }  // 3: + SVC_HBMA_FORCE_TILED / _LANE, svc_hip_comm_available / _info
+int svc_hip_abi_version(void) { return 4; }  // 4: + svc_hip_dct_planes_host, the per-call image operations of imageops.hip
 
 int svc_hip_device_count(int* count) {
   SVC_REQUIRE(count, "device_count: null output");
@@ -573,8 +566,8 @@ int svc_hip_ransac_host(const float* mv_xy, uint32_t blocks, svc_ransac_params p
 
 static int dct_host_common(const uint8_t* bgr, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh,
                            const uint32_t* types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg, uint32_t bg,
-                           bool quant, float* planes) {
-  int rc = validate_dct(bgr, planes, w, h, bw, bh);
+                           bool quant, float* planes, float* const* planes3 = nullptr) {
+  int rc = validate_dct(bgr, planes3 ? planes3[0] : planes, w, h, bw, bh);
   if (rc) return rc;
   if ((rc = require_device())) return rc;
   const size_t in_b = up256((size_t)w * h * 3), out_b = (size_t)w * h * 12;
@@ -589,8 +582,18 @@ static int dct_host_common(const uint8_t* bgr, uint32_t w, uint32_t h, uint32_t 
   if (rc) return rc;
   SVC_HIP_TRY(hipMemcpyAsync(g_stage.pin + in_b + t_b, d_out, out_b, hipMemcpyDeviceToHost, g_stage.stream));
   SVC_HIP_TRY(hipStreamSynchronize(g_stage.stream));
-  std::memcpy(planes, g_stage.pin + in_b + t_b, out_b);
+  if (planes3) {
+    for (int c = 0; c < 3; ++c) std::memcpy(planes3[c], g_stage.pin + in_b + t_b + (size_t)c * w * h * 4, (size_t)w * h * 4);
+  } else {
+    std::memcpy(planes, g_stage.pin + in_b + t_b, out_b);
+  }
   return SVC_OK;
+}
+
+int svc_hip_dct_planes_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h, uint32_t block_w, uint32_t block_h,
+                            float* const planes[3]) {
+  SVC_REQUIRE(planes && planes[0] && planes[1] && planes[2], "dct: null plane pointer");
+  return dct_host_common(bgr, frame_w, frame_h, block_w, block_h, nullptr, 0, 0, 1, 1, false, nullptr, planes);
 }
 
 int svc_hip_dct_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame_h, uint32_t block_w, uint32_t block_h,

@@ -509,6 +509,84 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   return check_launch("dct_kernel");
 }
 
+// ---- cv::dct over a LIST of tiles of one f32 image, in place -------------------------------------
+// The reference's Dct calls cv::dct(block, block) once per transform block of an f32 plane (libs/encoder.cpp:330-337).
+// A host that keeps that control flow (compat/opencv2/: the per-tile calls are collected and flushed together) hands
+// over the plane and the tiles' corners; this is dct_general_kernel's arithmetic (same basis, same f64 FMA chains in the
+// same order, rounded once to f32) on f32 input, TPB tiles per workgroup trip.
+struct DctTilesArgs {
+  float* img;
+  const uint32_t* xy;  // [n_tiles][2] corners, or null: the regular grid, row-major
+  uint32_t w, h, bw, bh, n_tiles, grid_w, tpb;
+};
+
+__global__ __launch_bounds__(256) void dct_tiles_kernel(DctTilesArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t tiles_lds[];
+  const uint32_t tid = threadIdx.x, bw = a.bw, bh = a.bh, area = bw * bh;
+  const uint32_t pw = bw + 1, ph = bh + 1;
+  double* cw = reinterpret_cast<double*>(tiles_lds);  // [bw][pw]
+  double* ch = cw + bw * pw;                          // [bh][ph]
+  double* yrow = ch + bh * ph;                        // [tpb][bh][bw] row-pass results
+  float* xin = reinterpret_cast<float*>(yrow + (size_t)a.tpb * area);  // [tpb][bh][bw]
+  for (uint32_t i = tid; i < bw * bw; i += 256) cw[(i / bw) * pw + i % bw] = dct_basis(i / bw, i % bw, bw);
+  for (uint32_t i = tid; i < bh * bh; i += 256) ch[(i / bh) * ph + i % bh] = dct_basis(i / bh, i % bh, bh);
+  __syncthreads();
+  for (uint32_t base = blockIdx.x * a.tpb; base < a.n_tiles; base += gridDim.x * a.tpb) {
+    const uint32_t nt = a.n_tiles - base < a.tpb ? a.n_tiles - base : a.tpb, ne = nt * area;
+    auto origin = [&](uint32_t t, uint32_t& tx, uint32_t& ty) {
+      const uint32_t g = base + t;
+      if (a.xy) { tx = a.xy[2 * g]; ty = a.xy[2 * g + 1]; }
+      else { ty = (g / a.grid_w) * bh; tx = (g % a.grid_w) * bw; }
+    };
+    for (uint32_t i = tid; i < ne; i += 256) {
+      const uint32_t t = i / area, e = i - t * area, r = e / bw, u = e - r * bw;
+      uint32_t tx, ty;
+      origin(t, tx, ty);
+      xin[i] = a.img[(size_t)(ty + r) * a.w + tx + u];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ne; i += 256) {  // rows: y[r][u] = sum_k Cw[u][k] x[r][k]
+      const uint32_t t = i / area, e = i - t * area, r = e / bw, u = e - r * bw;
+      const float* xr = xin + t * area + r * bw;
+      const double* cr = cw + u * pw;
+      double acc = 0.0;
+      for (uint32_t k = 0; k < bw; ++k) acc = __builtin_fma(cr[k], (double)xr[k], acc);
+      yrow[i] = acc;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ne; i += 256) {  // columns: Y[v][u] = sum_m Ch[v][m] y[m][u]
+      const uint32_t t = i / area, e = i - t * area, v = e / bw, u = e - v * bw;
+      const double* cr = ch + v * ph;
+      const double* yc = yrow + t * area + u;
+      double acc = 0.0;
+      for (uint32_t m = 0; m < bh; ++m) acc = __builtin_fma(cr[m], yc[m * bw], acc);
+      uint32_t tx, ty;
+      origin(t, tx, ty);
+      a.img[(size_t)(ty + v) * a.w + tx + u] = (float)acc;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_dct_tiles(float* d_img, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_xy, uint32_t n_tiles,
+                     hipStream_t stream) {
+  if ((bw > 1 && bw % 2) || (bh > 1 && bh % 2) || (bw == 1 && bh == 1) || bw == 0 || bh == 0)
+    return fail(SVC_ERR_INVALID_ARG, "dct: transform block %ux%u: cv::dct implements even sizes only", bw, bh);
+  if (bw > kDctGenMaxSide || bh > kDctGenMaxSide)
+    return fail(SVC_ERR_UNSUPPORTED, "dct: transform block %ux%u exceeds %ux%u", bw, bh, kDctGenMaxSide, kDctGenMaxSide);
+  if (n_tiles == 0) return SVC_OK;
+  DctTilesArgs a{};
+  a.img = d_img; a.xy = d_xy;
+  a.w = w; a.h = h; a.bw = bw; a.bh = bh; a.n_tiles = n_tiles;
+  a.grid_w = w / bw;
+  uint32_t tpb = 4096 / (bw * bh);
+  a.tpb = tpb < 1 ? 1 : tpb > 64 ? 64 : tpb;
+  const size_t lds = 8 * ((size_t)bw * (bw + 1) + (size_t)bh * (bh + 1)) + (size_t)a.tpb * bw * bh * 12;
+  const uint32_t trips = div_up(n_tiles, a.tpb);
+  hipLaunchKernelGGL(dct_tiles_kernel, dim3(trips < 2048 ? trips : 2048), dim3(256), lds, stream, a);
+  return check_launch("dct_tiles_kernel");
+}
+
 // ---- standalone quantise/dequantise (libs/decoder.cpp:140-144) ----------------
 
 __global__ __launch_bounds__(256) void quant_kernel(float* c, uint64_t n, float step) {

@@ -67,7 +67,7 @@ __device__ __forceinline__ void stage_tile_async(const uint8_t* plane, int fw, i
     const uint32_t slice = (uint32_t)r * NWAVES + wave;  // this wave instruction's 64 chunks
     if (slice * 64u < (uint32_t)G::CHUNKS) {            // wave-uniform
       const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_addr + slice * 1024u);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(plane) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(plane) : "memory", "m0");
     }
     c += DC;
     row += DR;

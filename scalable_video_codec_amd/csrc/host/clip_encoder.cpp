@@ -80,7 +80,8 @@ struct ClipEncoder::Impl {
   DevBuf<uint32_t> count[kSets], types[kSets], samples;
   hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {}, e_rfork = nullptr, e_rmse[kSets] = {};
   bool halo_recorded[2] = {false, false}, join_pending[kSets] = {}, rmse_pending[kSets] = {};
-  bool defer_rmse = false;  // pipelined, no graph, large fields: RANSAC leaves its in-order RMSE sum to a kernel on sC (nothing downstream needs it)
+  bool defer_rmse = false;  // pipelined, no graph, large fields: RANSAC leaves its in-order RMSE sum to a later kernel (nothing downstream
+                            // needs it): on sC beside the segmentation at world 1, on the latency stream behind it on a multi-rank run
   uint64_t iter = 0, fork_iter[kSets] = {};
   void* comm = nullptr;
   HaloFn halo;
@@ -168,6 +169,10 @@ struct ClipEncoder::Impl {
     if (!sh.pairs) return;
     const int b = Par(s), q = Set(s);
     const uint64_t t0 = sh.needs_halo ? 0 : 1;  // slot of the first tracked pyramid
+    if (rmse_pending[q]) {  // the deferred RMSE kernel of the set's previous step still reads the motion field this rewrites
+      Hip(hipStreamWaitEvent(st, e_rmse[q], 0), "hipStreamWaitEvent");
+      rmse_pending[q] = false;
+    }
     Run(Stage::kHbma, st, timing, [&] {
       Abi(svc_hip_hbma_pairs(pyr[b].p + t0 * pyr_stride, pyr[b].p + (t0 + 1) * pyr_stride, pyr_stride, sh.pairs, c.levels, pw, ph,
                              c.search_range, c.mv_block, c.mv_block, mv[q].p, mad[q].p, c.hbma_flags, st), "svc_hip_hbma_pairs");
@@ -185,12 +190,14 @@ struct ClipEncoder::Impl {
       Abi(svc_hip_ransac_frames_ex(mv[b].p, blocks, sh.pairs, c.ransac, samples.p, iters, gm[b].p, rmse[b].p, mask[b].p,
                                    count[b].p, lat_flags | (defer_rmse ? SVC_LAUNCH_DEFER_RMSE : 0u), st), "svc_hip_ransac_frames");
     });
-    if (defer_rmse) {
+    if (defer_rmse && c.world == 1) {
       // the serial tail of RANSAC (one dependent f32 add per MV block) beside the segmentation: it reads what the launch
-      // above left (gm, mask, count: final) and is picked up with the step's join.  On the COMMUNICATION stream, not a
-      // stream of its own: HIP multiplexes streams onto four hardware queues, and a fifth stream shares the main stream's
-      // queue -- its 0.13 ms single-wave kernel then holds every main-stream kernel back (measured: C5 2.43 -> 2.95 ms
-      // per step).  The halo that shares this stream has a whole iteration to arrive.
+      // above left (gm, mask, count: final) and is waited for only where the set's motion field is next rewritten (Hbma).
+      // On the COMMUNICATION stream, not a stream of its own: HIP multiplexes streams onto four hardware queues, and a
+      // fifth stream shares the main stream's queue -- its 0.13 ms single-wave kernel then holds every main-stream kernel
+      // back (measured: C5 2.43 -> 2.95 ms per step).  Only while that stream carries no halo (one rank): on a multi-rank
+      // run the next step's ncclSend / ncclRecv would queue behind this rank's RANSAC + this kernel and stall the
+      // NEIGHBOUR's receive with it (round 3's ADVICE) -- there the kernel goes behind the segmentation instead (ForkLat).
       Hip(hipEventRecord(e_rfork, st), "hipEventRecord");
       Hip(hipStreamWaitEvent(sC, e_rfork, 0), "hipStreamWaitEvent");
       Abi(svc_hip_ransac_rmse_frames(mv[b].p, blocks, sh.pairs, c.ransac, gm[b].p, mask[b].p, count[b].p, rmse[b].p, sC),
@@ -239,12 +246,17 @@ struct ClipEncoder::Impl {
     Hip(hipEventRecord(e_join[Set(l)], st), "hipEventRecord");
     join_pending[Set(l)] = true;
     fork_iter[Set(l)] = iter;
+    if (defer_rmse && c.world > 1 && sh.pairs) {
+      // multi-rank: the RMSE tail on this latency stream BEHIND the region ids (and behind the join event, so the transform
+      // does not wait for it); the communication stream stays free for the halo
+      const int b = Set(l);
+      Abi(svc_hip_ransac_rmse_frames(mv[b].p, blocks, sh.pairs, c.ransac, gm[b].p, mask[b].p, count[b].p, rmse[b].p, st),
+          "svc_hip_ransac_rmse_frames");
+      Hip(hipEventRecord(e_rmse[b], st), "hipEventRecord");
+      rmse_pending[b] = true;
+    }
   }
   void JoinLat(uint64_t l) {
-    if (rmse_pending[Set(l)]) {  // the set's motion field is rewritten by a later motion search on this stream
-      Hip(hipStreamWaitEvent(sM, e_rmse[Set(l)], 0), "hipStreamWaitEvent");
-      rmse_pending[Set(l)] = false;
-    }
     if (!join_pending[Set(l)]) return;
     Hip(hipStreamWaitEvent(sM, e_join[Set(l)], 0), "hipStreamWaitEvent");
     join_pending[Set(l)] = false;
@@ -553,6 +565,15 @@ int svc_clip_plan_shard(uint32_t clip_frames, uint32_t world, uint32_t rank, uin
 int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
   return Guard([&] {
     if (!k || !out) throw std::runtime_error("svc_clip_create: null pointer");
+    if (k->struct_size != sizeof(svc_clip_config))
+      throw std::runtime_error("svc_clip_create: config->struct_size is " + std::to_string(k->struct_size) + ", this build's svc_clip_config has " +
+                               std::to_string(sizeof(svc_clip_config)) + " bytes (set struct_size = sizeof(svc_clip_config))");
+    constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
+    constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE;
+    if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
+    if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
+    if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
+    if (k->schedule != SVC_CLIP_SERIAL && k->schedule != SVC_CLIP_PIPELINED) throw std::runtime_error("svc_clip_create: unknown schedule");
     svc::ClipEncoderConfig c;
     c.width = k->width; c.height = k->height; c.levels = k->levels; c.mv_block = k->mv_block;
     c.search_range = k->search_range; c.dct_block_w = k->dct_block_w; c.dct_block_h = k->dct_block_h;

@@ -138,11 +138,8 @@ void EstimateGlobalMotionHierarchical(const uchar* const* tracked_pyramid, const
 }
 
 void Dct(const uchar* bgr, uint frame_w, uint frame_h, uint block_w, uint block_h, float* const planes[3]) {
-  const size_t plane = static_cast<size_t>(frame_w) * frame_h;
-  std::vector<float> packed(plane * 3);
-  int rc = svc_hip_dct_host(bgr, frame_w, frame_h, block_w, block_h, packed.data());
+  int rc = svc_hip_dct_planes_host(bgr, frame_w, frame_h, block_w, block_h, planes);  // D2H lands in the caller's planes
   if (rc) Die("Dct", rc);
-  for (int c = 0; c < 3; ++c) std::memcpy(planes[c], packed.data() + plane * c, plane * sizeof(float));
 }
 
 void QuantizeDequantize(float* coeffs, unsigned long long count, uint quant_step) {

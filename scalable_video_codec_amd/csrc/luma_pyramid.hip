@@ -301,6 +301,14 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     if ((rc = check_launch("luma_kernel"))) return rc;
   }
 
+  return launch_pyr_down_levels(d_pyr, pyr_stride, n_frames, w, h, levels, first_plain_level, stream);
+}
+
+// Levels first_plain_level + 1 .. levels - 1 of n_frames packed pyramids whose levels 0 .. first_plain_level exist
+// (cv::buildPyramid from a given level-0 plane is first_plain_level = 0: svc_hip_build_pyramid_host).
+int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
+                           uint32_t first_plain_level, hipStream_t stream) {
+  int rc;
   uint64_t off = 0;
   for (uint32_t l = 0; l + 1 < levels; ++l) {
     PyrDownArgs pa;

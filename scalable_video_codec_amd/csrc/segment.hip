@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "svc_common.hpp"
+#include "union_find.hpp"
 
 namespace svc {
 
@@ -144,27 +145,6 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// Lock-free union-find on `parent` (LDS or global): a set's root is its smallest block index
-// (= its first block in raster order); links always go from the larger root to the smaller
-// with atomicMin, so concurrent unions commute.
-__device__ __forceinline__ uint32_t uf_find(const uint32_t* parent, uint32_t x) {
-  uint32_t p = parent[x];
-  while (p != x) { x = p; p = parent[x]; }
-  return x;
-}
-
-__device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t b) {
-  for (;;) {
-    a = uf_find(parent, a);
-    b = uf_find(parent, b);
-    if (a == b) return;
-    if (a < b) { const uint32_t t = a; a = b; b = t; }
-    const uint32_t old = atomicMin(&parent[a], b);
-    if (old == a) return;  // a was still a root and now points at b
-    a = old;               // someone linked a first: carry on from where it points
-  }
-}
-
 constexpr uint32_t kTA = 1024;  // lanes both kernels are launched with
 
 // ---- morphology on bit rows ------------------------------------------------------------------
@@ -240,7 +220,8 @@ struct WideState {
   unsigned long long seed_sum[kMaxK][kWideMaxG];    // seeding step j: sum of the running minima per workgroup
   long long part[2][kWideMaxG][kMaxK][4];           // Lloyd: count, sum mv.x, sum column, sum row per workgroup and cluster
   unsigned long long compact[2][kWideMaxG];         // Lloyd: fixed-point compactness per workgroup
-  uint32_t done;                                    // the attempt is over: ws.compact()[att] is final, later launches leave
+  uint32_t done;                                    // 0, or the Lloyd launch step that found the attempt over (>= 1): ws.compact()[att] is
+                                                    // final; only launches of a LATER step leave on it (see segment_wide_lloyd_kernel)
   uint32_t pad[3];
 };
 
@@ -1097,7 +1078,14 @@ __global__ __launch_bounds__(kTW) void segment_wide_lloyd_kernel(SegArgs a) {
   if (nf == 0 || *ws.packed() == 0) return;
   const uint32_t k = min(a.k, nf);
   WideState& W = *ws.wide(att);
-  if (W.done) return;  // written by an earlier launch
+  // The verdict of an EARLIER launch only: the launch that finds the attempt over writes its own step number (below), which
+  // no workgroup of that same launch honours whenever it is dispatched -- a late workgroup whose waves loaded the flag on
+  // either side of the store would otherwise split (some waves leave, the barriers count the rest, the partial sums lose
+  // lanes).  Every workgroup of the writing launch derives the same `over` from the partial sums and leaves by itself.
+  {
+    const uint32_t d = W.done;
+    if (d != 0 && d < it) return;
+  }
   const uint32_t bw = a.mv_bw, bh = a.mv_bh;
   const uint32_t par = it & 1u, prev = par ^ 1u;
 
@@ -1149,7 +1137,7 @@ __global__ __launch_bounds__(kTW) void segment_wide_lloyd_kernel(SegArgs a) {
       over = shift <= a.eps2;
     }
     if (over) {  // the labels of iteration it - 1 stand; every workgroup sees the same verdict
-      if (g == 0 && tid == 0) { ws.compact()[att] = compact; W.done = 1; }
+      if (g == 0 && tid == 0) { ws.compact()[att] = compact; W.done = it; }  // it >= 1 here
       return;
     }
   }
@@ -1498,7 +1486,12 @@ int launch_segment(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint3
       return (uint32_t)v;
     }();
     const uint64_t work = (uint64_t)n_frames * p.attempt_count;
-    if ((flags & SVC_LAUNCH_WIDE) || work <= cus)
+    if ((flags & SVC_LAUNCH_WIDE) && (n_frames > 65535u || p.attempt_count > 65535u))
+      return fail(SVC_ERR_UNSUPPORTED, "segment: SVC_LAUNCH_WIDE takes at most 65535 frames per call (grid.y), got %u", n_frames);
+    // The sequence is one launch per Lloyd iteration (plus one per centre above kWideRegPts x 1024 blocks) whether or not the
+    // attempts have converged: 5-10 us each, so beyond ~32 launches it is no shorter than the one-workgroup form it replaces.
+    const uint64_t seq = (uint64_t)p.max_iter_count + (a.n > kWideRegPts * kTA ? p.cluster_count : 1u);
+    if ((flags & SVC_LAUNCH_WIDE) || (work <= cus && seq <= 32))
       a.wide_g = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4 * (uint64_t)cus / std::max<uint64_t>(work, 1), 2), kWideMaxG);  // ~4 workgroups per CU
   }
   hipLaunchKernelGGL(segment_prepare_kernel, dim3(n_frames), dim3(kTA), a.lds_bytes, stream, a);

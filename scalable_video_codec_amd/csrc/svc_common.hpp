@@ -51,6 +51,20 @@ inline uint64_t pyramid_bytes(uint32_t w, uint32_t h, uint32_t levels) {
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// Per-thread staging of the host-pointer entry points (*_host): one internal stream, one device buffer and one
+// pinned bounce buffer, grown on demand and kept (capi.hip owns the thread_local instance).
+struct Staging {
+  hipStream_t stream = nullptr;
+  uint8_t* dev = nullptr;
+  uint8_t* pin = nullptr;
+  size_t cap = 0;
+  ~Staging();
+  int ensure(size_t bytes);
+};
+Staging& host_stage();
+int require_device();
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so blocks b and
 // b + 8 share an L2 but b and b + 1 do not.  This bijective remap gives every XCD one
 // CONTIGUOUS range of logical work (rows that overlap stay in one L2).  Speed only: nothing
@@ -76,6 +90,8 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
                hipStream_t stream, uint8_t* d_records = nullptr, uint64_t records_stride = 0,
                uint32_t emit_h = 0);
+int launch_dct_tiles(float* d_img, uint32_t w, uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_xy, uint32_t n_tiles,
+                     hipStream_t stream);
 int launch_quant(float* d_coeffs, uint64_t n, uint32_t step, hipStream_t stream);
 int launch_quant_frames(float* d_planes, uint32_t n_frames, uint32_t w, uint32_t h,
                         uint32_t mv_bw, uint32_t mv_bh, const uint32_t* d_types,
@@ -105,6 +121,8 @@ int launch_global_ebma(const uint8_t* d_tracked, const uint8_t* d_anchor, uint64
                        uint32_t h, uint32_t range, uint8_t* d_ws, float* d_gm, float* d_min_mad, bool combine,
                        hipStream_t stream);
 int launch_global_avg(const float* d_mv, uint32_t blocks, uint32_t n_frames, float* d_out, hipStream_t stream);
+int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
+                           uint32_t first_plain_level, hipStream_t stream);
 int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames,
                         uint32_t w, uint32_t h, uint32_t levels, uint8_t* d_pyr,
                         uint64_t pyr_stride, hipStream_t stream);

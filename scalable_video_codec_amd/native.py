@@ -96,6 +96,14 @@ SIGNATURES = {
     "svc_hip_comm_create": (C.c_int, [_vp, _u32, _u32, C.POINTER(_vp)]),
     "svc_hip_comm_destroy": (C.c_int, [_vp]),
     "svc_hip_halo_shift": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    # round 4: the per-call image operations behind compat/opencv2/ (host pointers)
+    "svc_hip_dct_planes_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "svc_hip_bgr2yuv_host": (C.c_int, [_vp, _u32, _u32, _vp]),
+    "svc_hip_build_pyramid_host": (C.c_int, [_vp, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "svc_hip_morph_rect_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp]),
+    "svc_hip_kmeans_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, C.c_float, _u64, _vp, C.POINTER(C.c_double)]),
+    "svc_hip_connected_components_host": (C.c_int, [_vp, _u32, _u32, _u32, _vp, C.POINTER(_u32)]),
+    "svc_hip_dct_tiles_host": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _vp, _u32]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -496,3 +504,84 @@ def global_avg_frames(mv: torch.Tensor) -> torch.Tensor:
     out = torch.empty((frames, 2), dtype=torch.float32, device=mv.device)
     _check(load().svc_hip_global_avg_frames(_dev(mv, torch.float32), blocks, frames, _dev(out, torch.float32), _stream()))
     return out
+
+
+# ---- per-call image operations (host numpy arrays in, numpy arrays out): what compat/opencv2/ forwards to ----------
+def _np(a, dtype):
+    import numpy as np
+    return np.ascontiguousarray(a, dtype)
+
+
+def bgr2yuv_host(bgr):
+    import numpy as np
+    src = _np(bgr, np.uint8)
+    h, w, _ = src.shape
+    out = np.empty_like(src)
+    _check(load().svc_hip_bgr2yuv_host(src.ctypes.data, w, h, out.ctypes.data))
+    return out
+
+
+def build_pyramid_host(level0, levels: int):
+    import numpy as np
+    src = _np(level0, np.uint8)
+    h, w = src.shape
+    planes = [src] + [np.empty((h >> l, w >> l), np.uint8) for l in range(1, levels)]
+    ptrs = (_vp * levels)(*[p.ctypes.data for p in planes])
+    _check(load().svc_hip_build_pyramid_host(src.ctypes.data, w, h, levels, ptrs))
+    return planes
+
+
+MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE = 0, 1, 2, 3
+
+
+def morph_rect_host(img, kw: int, kh: int, op: int):
+    import numpy as np
+    src = _np(img, np.uint8)
+    h, w = src.shape
+    out = np.empty_like(src)
+    _check(load().svc_hip_morph_rect_host(src.ctypes.data, w, h, kw, kh, op, out.ctypes.data))
+    return out
+
+
+def kmeans_host(features, k: int, attempts: int = 3, max_iter: int = 10, epsilon: float = 1.0, seed: int = 0):
+    import numpy as np
+    f = _np(features, np.float32)
+    n, dims = f.shape
+    labels = np.empty(n, np.int32)
+    compact = C.c_double(0.0)
+    _check(load().svc_hip_kmeans_host(f.ctypes.data, n, dims, k, attempts, max_iter, epsilon, seed, labels.ctypes.data,
+                                      C.byref(compact)))
+    return labels, compact.value
+
+
+def connected_components_host(img, connectivity: int = 4):
+    import numpy as np
+    src = _np(img, np.uint8)
+    h, w = src.shape
+    labels = np.empty((h, w), np.int32)
+    count = _u32(0)
+    _check(load().svc_hip_connected_components_host(src.ctypes.data, w, h, connectivity, labels.ctypes.data, C.byref(count)))
+    return labels, int(count.value)
+
+
+def dct_tiles_host(image, bw: int, bh: int, tiles_xy=None):
+    """In-place cv::dct over the listed tiles (or the whole regular grid) of an f32 image; returns the image."""
+    import numpy as np
+    img = np.array(image, np.float32, order="C")
+    h, w = img.shape
+    if tiles_xy is None:
+        _check(load().svc_hip_dct_tiles_host(img.ctypes.data, w, h, bw, bh, None, 0))
+    else:
+        xy = _np(tiles_xy, np.uint32)
+        _check(load().svc_hip_dct_tiles_host(img.ctypes.data, w, h, bw, bh, xy.ctypes.data, len(xy)))
+    return img
+
+
+def dct_planes_host(bgr, bw: int, bh: int):
+    import numpy as np
+    src = _np(bgr, np.uint8)
+    h, w, _ = src.shape
+    planes = [np.empty((h, w), np.float32) for _ in range(3)]
+    ptrs = (_vp * 3)(*[p.ctypes.data for p in planes])
+    _check(load().svc_hip_dct_planes_host(src.ctypes.data, w, h, bw, bh, ptrs))
+    return np.stack(planes)

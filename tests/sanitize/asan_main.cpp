@@ -188,7 +188,17 @@ void AbiPart() {
   CHECK(svc_clip_plan_shard(300, 8, 8, &a, &b, &c, &d) != 0 && std::strlen(svc_clip_last_error()) > 0);
   svc_clip* h = nullptr;
   svc_clip_config cc{};
-  CHECK(svc_clip_create(&cc, &h) != 0 && h == nullptr);
+  CHECK(svc_clip_create(&cc, &h) != 0 && h == nullptr);  // struct_size 0: a caller built against another layout
+  CHECK(std::strstr(svc_clip_last_error(), "struct_size") != nullptr);
+  cc.struct_size = sizeof(cc);
+  cc.tuning = 1u << 20;
+  CHECK(svc_clip_create(&cc, &h) != 0 && h == nullptr && std::strstr(svc_clip_last_error(), "tuning") != nullptr);
+  cc.tuning = 0; cc.lat_depth = 4;
+  CHECK(svc_clip_create(&cc, &h) != 0 && h == nullptr && std::strstr(svc_clip_last_error(), "lat_depth") != nullptr);
+  cc.lat_depth = 0; cc.hbma_flags = 64;
+  CHECK(svc_clip_create(&cc, &h) != 0 && h == nullptr && std::strstr(svc_clip_last_error(), "hbma_flags") != nullptr);
+  cc.hbma_flags = 0;
+  CHECK(svc_clip_create(&cc, &h) != 0 && h == nullptr);  // all-zero configuration: rejected by the encoder itself
   CHECK(svc_clip_create(nullptr, &h) != 0);
   if (no_gpu) {
     svc::ClipEncoderConfig k;

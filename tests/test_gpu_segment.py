@@ -195,3 +195,45 @@ def test_segment_wide_attempts_with_unpacked_frames(native, oracle):
         for f in (0, 1):
             want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=3 + f)
             assert np.array_equal(wide[f].astype(np.uint32), want), f"{mfw}x{mfh} frame {f}: {(wide[f] != want).sum()} blocks differ"
+
+
+def test_segment_wide_attempts_staggered_workgroups(native, oracle):
+    """SVC_LAUNCH_WIDE forced on a batch whose launch sequence has more workgroups (420 frames x 3 attempts x 2) than the
+    chip holds at once (256 CUs x 8 workgroups of 4 waves): the late workgroups of a Lloyd launch start after the early
+    ones have published "this attempt is over".  The verdict of a launch must never be honoured inside that same launch
+    (round 3's ADVICE: WideState::done is now the step number of the launch that wrote it); attempts that converge at
+    different iterations are mixed on purpose (epsilon 6: some frames stop after two updates, scene cuts run on)."""
+    mfw, mfh, frames = 240, 135, 420
+    n = mfw * mfh
+    rng = np.random.default_rng(2024)
+    yy, xx = np.mgrid[0:mfh, 0:mfw]
+    masks = np.ones((frames, n), np.uint8)
+    mvs = np.zeros((frames, n, 2), np.float32)
+    for f in range(frames):
+        d = (0.9, 0.03, 0.3, 0.0, 0.6, 0.01)[f % 6]
+        masks[f] = (~(rng.random((mfh, mfw)) < d)).astype(np.uint8).reshape(-1)
+        mvs[f, :, 0] = np.round(7 * np.sin(xx / 19.0 + f) + rng.integers(-3, 4, (mfh, mfw))).reshape(-1)
+        mvs[f, :, 1] = rng.integers(-9, 10, n)
+    tm, tv = torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda()
+    wide = native.segment_frames(tm, tv, mfw, mfh, seed=9, flags=4, epsilon=6.0).cpu().numpy()
+    narrow = native.segment_frames(tm, tv, mfw, mfh, seed=9, flags=8, epsilon=6.0).cpu().numpy()
+    assert np.array_equal(wide, narrow)
+    for f in (0, 1, 2, 4, 419):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=9 + f, epsilon=6.0)
+        assert np.array_equal(wide[f].astype(np.uint32), want), f"frame {f}: {(wide[f] != want).sum()} blocks differ"
+
+
+def test_segment_wide_rule_counts_the_sequence_length(native):
+    """The automatic rule for the launch-sequence form looks at the length of the sequence as well (max_iter + 1 launches, or
+    max_iter + k above 32 768 blocks): with 100 iterations asked for, the default stays with the one-workgroup form -- seen
+    from outside as identical region ids whatever the rule picks, and a forced wide form beyond grid.y is refused."""
+    mfw, mfh = 240, 135
+    n = mfw * mfh
+    rng = np.random.default_rng(5)
+    mask = (~(rng.random((1, n)) < 0.8)).astype(np.uint8)
+    mv = rng.integers(-7, 8, (1, n, 2)).astype(np.float32)
+    tm, tv = torch.from_numpy(mask).cuda(), torch.from_numpy(mv).cuda()
+    auto = native.segment_frames(tm, tv, mfw, mfh, seed=1, max_iter_count=100).cpu().numpy()
+    narrow = native.segment_frames(tm, tv, mfw, mfh, seed=1, max_iter_count=100, flags=8).cpu().numpy()
+    wide = native.segment_frames(tm, tv, mfw, mfh, seed=1, max_iter_count=100, flags=4).cpu().numpy()
+    assert np.array_equal(auto, narrow) and np.array_equal(wide, narrow)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B: a heavy frame's k-means attempts as one workgroup each (--narrow-attempts) vs as launch sequences over
-# several workgroups (default on small shards of large fields).  C5 shards of an 8 / 4-GPU run, and the whole clip (where
-# the default stays narrow: frames x attempts >= CUs / 2).
+# several workgroups (default when frames x attempts <= CUs and the sequence is at most ~32 launches: small shards of large
+# fields AND C5's whole 64-frame clip).  C5 shards of an 8 / 4-GPU run, and the whole clip.
 row() { python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-hbm-probe --sustain-seconds 0 "$@" 2>/dev/null | python3 -c "
 import json,sys
 d=json.load(sys.stdin); o=d.get('overlapped_ms_per_step',{})
