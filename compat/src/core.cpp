@@ -1,0 +1,327 @@
+// compat/src/core.cpp -- cv::Mat storage and the core functions of compat/opencv2/core.hpp.
+// PRODUCT-SIDE ADAPTER, NOT AN ORACLE (see compat/opencv2/core/mat.hpp).  Arithmetic goes to include/svc_hip.h; what
+// stays on the host is allocation, copies, interleaving and type conversion of pixel data.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <utility>
+
+#include <type_traits>
+
+#include "internal.hpp"
+#include "opencv2/core.hpp"
+#include "svc_hip.h"
+
+namespace cv {
+namespace detail {
+
+void Fail(const char* where, const char* what) {
+  std::fprintf(stderr, "svc opencv-compat: %s: %s\n", where, what);
+  std::abort();
+}
+
+void Abi(int rc, const char* where) {
+  if (rc != SVC_OK) Fail(where, svc_hip_last_error());
+}
+
+Mat Continuous(const Mat& m) {
+  m.sync();
+  return m.isContinuous() ? m : m.clone();
+}
+
+static size_t ElemSize(int type) {
+  static const size_t sz[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+  return sz[CV_MAT_DEPTH(type)] * (size_t)CV_MAT_CN(type);
+}
+
+Buffer::Buffer(int rows_, int cols_, int type_) : rows(rows_), cols(cols_), type(type_) {
+  step = (size_t)cols_ * ElemSize(type_);
+  bytes = step * (size_t)rows_;
+  base = static_cast<uchar*>(std::aligned_alloc(64, (bytes + 63) / 64 * 64 + 64));
+  if (!base) Fail("cv::Mat::create", "out of memory");
+}
+
+Buffer::~Buffer() { std::free(base); }  // cv::dct calls still collected die with the data nobody looked at
+
+// Executes the collected cv::dct calls of one allocation: one svc_hip_dct_tiles_host per tile shape (the reference
+// issues a single shape per plane).  The regular full grid -- what libs/encoder.cpp:330-337 produces -- needs no list.
+void Flush(Buffer& b) {
+  std::vector<DeferredDct> todo;
+  todo.swap(b.pending);  // first: anything below that touches a Mat over this buffer must not recurse
+  if (CV_MAT_DEPTH(b.type) != CV_32F || CV_MAT_CN(b.type) != 1) Fail("cv::dct", "only single-channel 32-bit float matrices");
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> by_shape;
+  for (const DeferredDct& t : todo) {
+    auto& xy = by_shape[{t.w, t.h}];
+    xy.push_back(t.x);
+    xy.push_back(t.y);
+  }
+  for (auto& kv : by_shape) {
+    const uint32_t bw = kv.first.first, bh = kv.first.second;
+    const std::vector<uint32_t>& xy = kv.second;
+    const uint32_t n = (uint32_t)(xy.size() / 2);
+    bool grid = (uint32_t)b.cols % bw == 0 && (uint32_t)b.rows % bh == 0 && n == ((uint32_t)b.cols / bw) * ((uint32_t)b.rows / bh);
+    for (uint32_t i = 0; grid && i < n; ++i)  // issued in raster order, as the reference's loops do
+      grid = xy[2 * i] == (i % ((uint32_t)b.cols / bw)) * bw && xy[2 * i + 1] == (i / ((uint32_t)b.cols / bw)) * bh;
+    Abi(svc_hip_dct_tiles_host(reinterpret_cast<float*>(b.base), (uint32_t)b.cols, (uint32_t)b.rows, bw, bh,
+                               grid ? nullptr : xy.data(), n), "cv::dct");
+  }
+}
+
+}  // namespace detail
+
+// ---- Mat -------------------------------------------------------------------------------------------------------------
+void Mat::create(int rows_, int cols_, int type_) {
+  type_ &= 4095;
+  if (rows_ < 0 || cols_ < 0) detail::Fail("cv::Mat::create", "negative size");
+  if (data && rows == rows_ && cols == cols_ && type() == type_) return;  // reuse (OpenCV does not look at sharing here)
+  release();
+  flags = type_;
+  dims = 2;
+  rows = rows_;
+  cols = cols_;
+  step = (size_t)cols_ * elemSize();
+  if (rows_ == 0 || cols_ == 0) return;
+  buf_ = std::make_shared<detail::Buffer>(rows_, cols_, type_);
+  data = buf_->base;
+}
+
+Mat Mat::clone() const {
+  Mat m;
+  copyTo(m);
+  return m;
+}
+
+void Mat::copyTo(Mat& dst) const {
+  sync();
+  if (empty()) { dst.release(); return; }
+  dst.create(rows, cols, type());
+  dst.sync();
+  if (dst.data == data) return;
+  const size_t row = (size_t)cols * elemSize();
+  for (int y = 0; y < rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, data + (size_t)y * step, row);
+}
+
+namespace {
+
+template <typename T> T Saturate(double v);
+template <> uchar Saturate<uchar>(double v) { const long r = std::lrint(v); return (uchar)(r < 0 ? 0 : r > 255 ? 255 : r); }
+template <> int Saturate<int>(double v) { return (int)std::lrint(v); }
+template <> float Saturate<float>(double v) { return (float)v; }
+template <> double Saturate<double>(double v) { return v; }
+
+template <typename S, typename D> void ConvertRows(const Mat& src, Mat& dst, double alpha, double beta) {
+  const size_t n = (size_t)src.cols * (size_t)src.channels();
+  const bool plain = alpha == 1.0 && beta == 0.0;
+  for (int y = 0; y < src.rows; ++y) {
+    const S* s = reinterpret_cast<const S*>(src.data + (size_t)y * src.step);
+    D* d = reinterpret_cast<D*>(dst.data + (size_t)y * dst.step);
+    if (plain && sizeof(D) >= sizeof(S) && !(std::is_integral<D>::value && std::is_floating_point<S>::value))
+      for (size_t i = 0; i < n; ++i) d[i] = (D)s[i];  // widening: exact
+    else
+      for (size_t i = 0; i < n; ++i) d[i] = Saturate<D>((double)s[i] * alpha + beta);
+  }
+}
+
+template <typename S> void ConvertFrom(const Mat& src, Mat& dst, double a, double b) {
+  switch (dst.depth()) {
+    case CV_8U: ConvertRows<S, uchar>(src, dst, a, b); break;
+    case CV_32S: ConvertRows<S, int>(src, dst, a, b); break;
+    case CV_32F: ConvertRows<S, float>(src, dst, a, b); break;
+    case CV_64F: ConvertRows<S, double>(src, dst, a, b); break;
+    default: detail::Fail("cv::Mat::convertTo", "destination depth outside {8U, 32S, 32F, 64F}");
+  }
+}
+
+}  // namespace
+
+// libs/encoder.cpp:638: 8-bit B,G,R -> 32-bit float, the transform's input.  A change of representation (exact), done
+// on the host where both matrices live.
+void Mat::convertTo(Mat& dst, int rtype, double alpha, double beta) const {
+  sync();
+  if (empty()) { dst.release(); return; }
+  const int dtype = CV_MAKETYPE(rtype < 0 ? depth() : CV_MAT_DEPTH(rtype), channels());
+  if (dtype == type() && alpha == 1.0 && beta == 0.0) { copyTo(dst); return; }
+  Mat out = dst.data == data ? Mat() : dst;
+  out.create(rows, cols, dtype);
+  out.sync();
+  switch (depth()) {
+    case CV_8U: ConvertFrom<uchar>(*this, out, alpha, beta); break;
+    case CV_32S: ConvertFrom<int>(*this, out, alpha, beta); break;
+    case CV_32F: ConvertFrom<float>(*this, out, alpha, beta); break;
+    case CV_64F: ConvertFrom<double>(*this, out, alpha, beta); break;
+    default: detail::Fail("cv::Mat::convertTo", "source depth outside {8U, 32S, 32F, 64F}");
+  }
+  dst = out;
+}
+
+Mat& Mat::setTo(const Scalar& value) {
+  sync();
+  const int cn = channels();
+  if (cn > 4) detail::Fail("cv::Mat::setTo", "more than four channels");
+  for (int y = 0; y < rows; ++y) {
+    uchar* row = data + (size_t)y * step;
+    for (int x = 0; x < cols; ++x)
+      for (int c = 0; c < cn; ++c) {
+        const size_t i = (size_t)x * cn + c;
+        switch (depth()) {
+          case CV_8U: row[i] = Saturate<uchar>(value[c]); break;
+          case CV_32S: reinterpret_cast<int*>(row)[i] = Saturate<int>(value[c]); break;
+          case CV_32F: reinterpret_cast<float*>(row)[i] = (float)value[c]; break;
+          case CV_64F: reinterpret_cast<double*>(row)[i] = value[c]; break;
+          default: detail::Fail("cv::Mat::setTo", "depth outside {8U, 32S, 32F, 64F}");
+        }
+      }
+  }
+  return *this;
+}
+
+Mat Mat::zeros(int rows_, int cols_, int type_) {
+  Mat m(rows_, cols_, type_);
+  if (!m.empty()) std::memset(m.data, 0, m.step * (size_t)m.rows);
+  return m;
+}
+
+Mat Mat::ones(int rows_, int cols_, int type_) {  // OpenCV: 1 in the first channel only
+  Mat m(rows_, cols_, type_);
+  m.setTo(Scalar(1.0));
+  return m;
+}
+
+Mat operator*(const Mat& m, double s) {
+  Mat out;
+  m.convertTo(out, -1, s, 0.0);
+  if (out.data == m.data) out = out.clone();
+  return out;
+}
+
+void swap(Mat& a, Mat& b) { std::swap(a, b); }
+
+// ---- core functions --------------------------------------------------------------------------------------------------
+void copyMakeBorder(const Mat& src, Mat& dst, int top, int bottom, int left, int right, int borderType, const Scalar& value) {
+  if (borderType != BORDER_CONSTANT) detail::Fail("cv::copyMakeBorder", "only BORDER_CONSTANT (libs/encoder.cpp:447-448)");
+  if (top < 0 || bottom < 0 || left < 0 || right < 0 || src.empty()) detail::Fail("cv::copyMakeBorder", "bad arguments");
+  src.sync();
+  Mat out = dst.data == src.data ? Mat() : dst;
+  out.create(src.rows + top + bottom, src.cols + left + right, src.type());
+  out.sync();
+  const bool zero = value[0] == 0 && value[1] == 0 && value[2] == 0 && value[3] == 0;
+  if (zero) {
+    for (int y = 0; y < out.rows; ++y) std::memset(out.data + (size_t)y * out.step, 0, (size_t)out.cols * out.elemSize());
+  } else {
+    out.setTo(value);
+  }
+  const size_t es = src.elemSize(), row = (size_t)src.cols * es;
+  for (int y = 0; y < src.rows; ++y)
+    std::memcpy(out.data + (size_t)(y + top) * out.step + (size_t)left * es, src.data + (size_t)y * src.step, row);
+  dst = out;
+}
+
+void extractChannel(const Mat& src, Mat& dst, int coi) {
+  if (src.empty() || coi < 0 || coi >= src.channels()) detail::Fail("cv::extractChannel", "bad channel index");
+  src.sync();
+  const size_t e1 = src.elemSize1(), es = src.elemSize();
+  Mat out = dst.data == src.data ? Mat() : dst;
+  out.create(src.rows, src.cols, CV_MAKETYPE(src.depth(), 1));
+  out.sync();
+  for (int y = 0; y < src.rows; ++y) {
+    const uchar* s = src.data + (size_t)y * src.step + (size_t)coi * e1;
+    uchar* d = out.data + (size_t)y * out.step;
+    if (e1 == 1) {
+      for (int x = 0; x < src.cols; ++x) d[x] = s[(size_t)x * es];
+    } else {
+      for (int x = 0; x < src.cols; ++x) std::memcpy(d + (size_t)x * e1, s + (size_t)x * es, e1);
+    }
+  }
+  dst = out;
+}
+
+void detail::SplitInto(const Mat& src, Mat* const* planes, int n) {
+  if (src.empty() || n != src.channels()) Fail("cv::split", "plane count does not match the channel count");
+  src.sync();
+  const int cn = src.channels();
+  for (int c = 0; c < n; ++c) {
+    planes[c]->create(src.rows, src.cols, CV_MAKETYPE(src.depth(), 1));
+    if (Buffer* b = planes[c]->compat_buffer()) b->pending.clear();  // the plane is overwritten whole
+  }
+  if (src.depth() == CV_32F && cn == 3) {  // the reference's case (libs/encoder.cpp:328): one pass over the pixels
+    for (int y = 0; y < src.rows; ++y) {
+      const float* s = reinterpret_cast<const float*>(src.data + (size_t)y * src.step);
+      float* d0 = reinterpret_cast<float*>(planes[0]->data + (size_t)y * planes[0]->step);
+      float* d1 = reinterpret_cast<float*>(planes[1]->data + (size_t)y * planes[1]->step);
+      float* d2 = reinterpret_cast<float*>(planes[2]->data + (size_t)y * planes[2]->step);
+      for (int x = 0; x < src.cols; ++x) { d0[x] = s[3 * x]; d1[x] = s[3 * x + 1]; d2[x] = s[3 * x + 2]; }
+    }
+    return;
+  }
+  const size_t e1 = src.elemSize1(), es = src.elemSize();
+  for (int c = 0; c < n; ++c)
+    for (int y = 0; y < src.rows; ++y) {
+      const uchar* s = src.data + (size_t)y * src.step + (size_t)c * e1;
+      uchar* d = planes[c]->data + (size_t)y * planes[c]->step;
+      for (int x = 0; x < src.cols; ++x) std::memcpy(d + (size_t)x * e1, s + (size_t)x * es, e1);
+    }
+}
+
+void split(const Mat& src, std::vector<Mat>& mv) {
+  mv.resize((size_t)src.channels());
+  std::vector<Mat*> p;
+  for (auto& m : mv) p.push_back(&m);
+  detail::SplitInto(src, p.data(), (int)p.size());
+}
+
+void dct(const Mat& src, Mat& dst, int flags) {
+  if (flags != 0) detail::Fail("cv::dct", "only the forward 2-D transform (flags = 0; libs/encoder.cpp:335)");
+  if (src.empty() || src.type() != CV_32FC1) detail::Fail("cv::dct", "only single-channel 32-bit float matrices");
+  const bool odd = (src.cols > 1 && src.cols % 2) || (src.rows > 1 && src.rows % 2) || (src.cols == 1 && src.rows == 1);
+  if (odd) detail::Fail("cv::dct", "odd sizes are not implemented (OpenCV asserts here as well)");
+  if (dst.data != src.data || dst.rows != src.rows || dst.cols != src.cols || dst.step != src.step) {
+    src.copyTo(dst);  // out of place: transform the copy
+  }
+  detail::Buffer* b = dst.compat_buffer();
+  if (b && dst.step == b->step && CV_MAT_DEPTH(b->type) == CV_32F && CV_MAT_CN(b->type) == 1) {
+    const size_t off = (size_t)(dst.data - b->base);
+    b->pending.push_back({(uint32_t)((off % b->step) / sizeof(float)), (uint32_t)(off / b->step), (uint32_t)dst.cols, (uint32_t)dst.rows});
+    return;
+  }
+  // caller-owned memory (or a view of a multi-channel allocation): nothing to hang the call on -- run it now
+  Mat tmp;
+  dst.copyTo(tmp);
+  detail::Abi(svc_hip_dct_tiles_host(reinterpret_cast<float*>(tmp.data), (uint32_t)tmp.cols, (uint32_t)tmp.rows, (uint32_t)tmp.cols,
+                                     (uint32_t)tmp.rows, nullptr, 0), "cv::dct");
+  for (int y = 0; y < dst.rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, tmp.data + (size_t)y * tmp.step, (size_t)dst.cols * 4);
+}
+
+RNG& theRNG() {
+  static thread_local RNG rng;
+  return rng;
+}
+
+void setRNGSeed(int seed) { theRNG() = RNG((uint64_t)(unsigned)seed); }
+
+double kmeans(const Mat& data, int K, Mat& bestLabels, TermCriteria criteria, int attempts, int flags) {
+  if (flags != KMEANS_PP_CENTERS) detail::Fail("cv::kmeans", "only KMEANS_PP_CENTERS (libs/encoder.cpp:576)");
+  if (data.empty() || data.depth() != CV_32F) detail::Fail("cv::kmeans", "data must be 32-bit float");
+  const int dims = data.cols * data.channels();
+  if (dims < 1 || dims > 4) detail::Fail("cv::kmeans", "1 to 4 coordinates per point");
+  if (K < 1 || attempts < 1) detail::Fail("cv::kmeans", "K and attempts must be positive");
+  // OpenCV's reading of the criterion: without COUNT up to 100 iterations, without EPS an epsilon of ~0
+  const uint32_t max_iter = (criteria.type & TermCriteria::COUNT) ? (uint32_t)std::max(criteria.maxCount, 1) : 100u;
+  const float eps = (criteria.type & TermCriteria::EPS) ? (float)std::max(criteria.epsilon, 1e-12) : 1.1920929e-07f;
+  Mat pts = detail::Continuous(data);
+  Mat labels = bestLabels;
+  labels.create(data.rows, 1, CV_32SC1);
+  labels.sync();
+  RNG& rng = theRNG();
+  const uint64_t seed = rng.state;
+  rng.next();
+  double compactness = 0.0;
+  detail::Abi(svc_hip_kmeans_host(reinterpret_cast<const float*>(pts.data), (uint32_t)data.rows, (uint32_t)dims, (uint32_t)K,
+                                  (uint32_t)attempts, max_iter, eps, seed, reinterpret_cast<int32_t*>(labels.data), &compactness),
+              "cv::kmeans");
+  bestLabels = labels;
+  return compactness;
+}
+
+}  // namespace cv

@@ -3,6 +3,8 @@
   libsvc_hip.so     HIP kernels + the C ABI of include/svc_hip.h
   libsvc_motion.so  C++ wrappers with the reference's own signatures
                     (include/svc/motion.hpp), on top of the C ABI
+  libsvc_opencv_compat.so  compat/opencv2: the OpenCV-shaped adapter the reference's own
+                    encoder application compiles against, on top of the C ABI
 
 Both land next to this file; they are git-ignored but travel to the GPU box.
 """
@@ -131,10 +133,71 @@ def build_dropin(force: bool = False) -> List[str]:
     return out
 
 
+COMPAT = os.path.join(ROOT, "compat")
+LIB_COMPAT = os.path.join(PKG, "libsvc_opencv_compat.so")
+
+
+def build_compat(force: bool = False) -> str:
+    """compat/opencv2: the slice of the OpenCV API the reference's encoder uses, every arithmetic call forwarding to
+    include/svc_hip.h (a product-side adapter -- never an oracle).  Plain C++ on top of the C ABI."""
+    srcs = [os.path.join(COMPAT, "src", f) for f in ("core.cpp", "imgproc.cpp", "videoio.cpp")]
+    hdrs = [os.path.join(COMPAT, "src", "internal.hpp"), os.path.join(INCLUDE, "svc_hip.h")] + \
+        [os.path.join(COMPAT, "opencv2", f) for f in ("core.hpp", "imgproc.hpp", "videoio.hpp", os.path.join("core", "mat.hpp"))]
+    if force or not _newer(LIB_COMPAT, srcs + hdrs + [LIB_HIP]):
+        cxx = shutil.which("g++") or "g++"
+        _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", f"-I{COMPAT}", f"-I{INCLUDE}", "-o", LIB_COMPAT,
+              *srcs, f"-L{PKG}", "-lsvc_hip", "-Wl,-rpath,$ORIGIN"])
+    return LIB_COMPAT
+
+
+REFERENCE_APPS = os.environ.get("SVC_REFERENCE_DIR", "/root/reference") + "/apps"
+
+
+def reference_encoder_command(exe: str, sse2: bool, extra_sources: List[str] = ()) -> List[str]:
+    """THE build line of INTEGRATION.md section 6: the reference's own apps/encoder.cpp + libs/encoder.cpp + libs/cli.cpp,
+    compiled where they lie (never copied, never edited), against compat/opencv2 instead of OpenCV, with this repo's
+    ThreadGuard in place of the reference's thread.cpp (which does not compile), linked to the three product libraries."""
+    cxx = shutil.which("g++") or "g++"
+    return [cxx, "-std=c++17", "-O2", "-DNDEBUG", "-msse2", *(["-DSVC_MOTION_SSE2"] if sse2 else []),
+            f"-I{COMPAT}", f"-I{REFERENCE_LIBS}", "-o", exe,
+            os.path.join(REFERENCE_APPS, "encoder.cpp"), os.path.join(REFERENCE_LIBS, "encoder.cpp"),
+            os.path.join(REFERENCE_LIBS, "cli.cpp"), os.path.join(COMPAT, "src", "thread_guard.cpp"), *extra_sources,
+            f"-L{PKG}", "-lsvc_opencv_compat", "-lsvc_motion", "-lsvc_hip", "-pthread",
+            f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd"]
+
+
+def build_reference_encoder(force: bool = False) -> List[str]:
+    """tests/dropin/ref_encoder_{sse2,generic}: the reference's unchanged encoder application on the HIP path,
+    built where /root/reference exists; the binaries travel to the GPU box like the other drop-in callers.  The only extra
+    object is tests/dropin/ransac_seed.cpp, a TEST seam (it seeds the wrapper's RANSAC engine before main() so that the
+    output stream is repeatable; the reference seeds from std::random_device)."""
+    if not os.path.exists(os.path.join(REFERENCE_APPS, "encoder.cpp")):
+        return []
+    here = os.path.dirname(DROPIN_SRC)
+    seed_src = os.path.join(here, "ransac_seed.cpp")
+    deps = [LIB_COMPAT, LIB_MOTION, seed_src, os.path.join(COMPAT, "src", "thread_guard.cpp")] + \
+        [os.path.join(COMPAT, "opencv2", f) for f in ("core.hpp", "imgproc.hpp", "videoio.hpp", os.path.join("core", "mat.hpp"))]
+    out = []
+    for name, sse2 in (("ref_encoder_sse2", True), ("ref_encoder_generic", False)):
+        exe = os.path.join(here, name)
+        if force or not _newer(exe, deps):
+            _run(reference_encoder_command(exe, sse2, [seed_src]))
+        out.append(exe)
+    # the libstdc++ engine + distribution the C++ RANSAC wrapper draws with, for tests that mirror its draws
+    exe = os.path.join(here, "ransac_draws")
+    src = os.path.join(here, "ransac_draws.cpp")
+    if force or not _newer(exe, [src]):
+        _run([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-o", exe, src])
+    out.append(exe)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
     build_motion(force)
+    build_compat(force)
     build_dropin(force)
+    build_reference_encoder(force)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,78 @@
+"""compat/opencv2 (the OpenCV-shaped product adapter the reference's encoder compiles against), host side, no GPU:
+the matrix semantics the reference relies on, the data-movement functions and the clip containers (a C++ program,
+tests/compat/compat_host_main.cpp); that the adapter library exports what its headers declare; that it stays out of the
+oracle; and -- where /root/reference exists -- that the reference's unchanged sources still compile against it."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from scalable_video_codec_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, "compat")
+
+
+@pytest.fixture(scope="module")
+def compat_lib():
+    if not shutil.which("g++") or not os.path.exists(build.LIB_HIP):
+        pytest.skip("needs g++ and the built libsvc_hip.so")
+    return build.build_compat()
+
+
+def test_host_semantics(compat_lib, tmp_path):
+    exe = tmp_path / "compat_host"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", f"-I{COMPAT}", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "compat", "compat_host_main.cpp"), f"-L{build.PKG}", "-lsvc_opencv_compat",
+                           "-lsvc_hip", f"-Wl,-rpath,{build.PKG}"])
+    frames = [((np.arange(4 * 6 * 3) + 50 * t) & 255).astype(np.uint8).reshape(4, 6, 3) for t in range(3)]
+    raw, ppm = tmp_path / "c.svcbgr", tmp_path / "c.ppm"
+    with open(raw, "wb") as f:
+        f.write(b"SVCBGR1\0" + struct.pack("<4I", 6, 4, 3, 0))
+        for fr in frames:
+            f.write(fr.tobytes())
+    with open(ppm, "wb") as f:
+        for fr in frames:
+            f.write(b"P6\n# a comment\n6 4\n255\n" + np.ascontiguousarray(fr[..., ::-1]).tobytes())
+    out = subprocess.run([str(exe), str(raw), str(ppm)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "compat host semantics ok" in out.stdout
+
+
+def test_adapter_forwards_and_stays_out_of_the_oracle(compat_lib):
+    """Every cv:: function with arithmetic is a caller of include/svc_hip.h (undefined svc_hip_* symbols of the library), and
+    nothing under oracle/ or tests/golden/ touches compat/ (an OpenCV stand-in must never pin parity)."""
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", compat_lib], text=True)
+    for s in ("svc_hip_bgr2yuv_host", "svc_hip_build_pyramid_host", "svc_hip_morph_rect_host", "svc_hip_kmeans_host",
+              "svc_hip_connected_components_host", "svc_hip_dct_tiles_host"):
+        assert s in syms, s
+    for base in ("oracle", os.path.join("tests", "golden")):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".c", ".h", ".cpp", ".hpp", ".py", "Makefile")):
+                    text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                    assert "opencv2" not in text and "svc_opencv_compat" not in text and "compat/" not in text, (dirpath, fn)
+    for fn in ("core.cpp", "imgproc.cpp", "videoio.cpp"):
+        assert "oracle" not in open(os.path.join(COMPAT, "src", fn)).read().replace("NOT AN ORACLE", "")
+
+
+def test_reference_encoder_sources_compile_unchanged(compat_lib, tmp_path):
+    """g++ -fsyntax-only of the reference's apps/encoder.cpp, libs/encoder.cpp, libs/cli.cpp where they lie, both ways
+    (-DSVC_MOTION_SSE2 and without), against compat/ -- and the committed INTEGRATION.md carries that build line."""
+    ref = os.path.dirname(build.REFERENCE_LIBS)
+    if not os.path.exists(os.path.join(ref, "apps", "encoder.cpp")):
+        pytest.skip("/root/reference is not on this box")
+    for sse2 in (True, False):
+        cmd = build.reference_encoder_command(str(tmp_path / "enc"), sse2)
+        srcs = [a for a in cmd if a.endswith(".cpp")]
+        assert sum(s.startswith(ref) for s in srcs) == 3 and not any("ransac_seed" in s for s in srcs)
+        flags = [a for a in cmd if a.startswith(("-I", "-D", "-std", "-m"))]
+        subprocess.check_call(["g++", "-fsyntax-only", *flags, *srcs])
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for piece in ("apps/encoder.cpp", "libs/encoder.cpp", "libs/cli.cpp", "compat/src/thread_guard.cpp", "-lsvc_opencv_compat",
+                  "-DSVC_MOTION_SSE2"):
+        assert piece in text, piece

@@ -1,0 +1,165 @@
+"""SURVEY 8f-3, second half: the reference's OWN encoder application -- /root/reference/apps/encoder.cpp +
+libs/encoder.cpp + libs/cli.cpp, compiled unchanged where they lie against compat/opencv2 (scalable_video_codec_amd/build.py,
+build_reference_encoder) and linked to libsvc_opencv_compat.so + libsvc_motion.so + libsvc_hip.so -- encodes a seeded clip
+on the GPU, and its stdout is checked against the oracle run stage by stage over the same frames:
+
+  Header (libs/codec.hpp:8-17, libs/encoder.cpp:360-381) byte for byte; per frame and tile the u32 region id EXACTLY and the
+  3 x bh x bw f32 coefficients within 1e-4 max(1, |ref|) of oracle.serialize_frame(oracle DCT, oracle region ids, ...) --
+  where the oracle's region ids come from oracle luma + pyramid -> oracle HBMA -> oracle RANSAC (fed the draws the C++
+  wrapper makes: tests/dropin/ransac_draws mirrors its libstdc++ engine) -> oracle segmentation (fed the seed the adapter's
+  cv::kmeans takes from its cv::theRNG()).
+
+The compat layer is a PRODUCT adapter: it forwards to the HIP kernels and pins nothing about OpenCV (parity of the float /
+OpenCV-defined steps stays "unpinned"); what this test pins is that the reference's unmodified control flow drives them."""
+import os
+import struct
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from scalable_video_codec_amd import synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+RANSAC_SEED = 777
+
+
+def _write_clip(path, frames):
+    h, w, _ = frames[0].shape
+    with open(path, "wb") as f:
+        f.write(b"SVCBGR1\0" + struct.pack("<4I", w, h, len(frames), 0))
+        for fr in frames:
+            f.write(np.ascontiguousarray(fr, np.uint8).tobytes())
+
+
+def _write_ppm_stream(path, frames):
+    with open(path, "wb") as f:
+        for fr in frames:
+            h, w, _ = fr.shape
+            f.write(b"P6\n%d %d\n255\n" % (w, h) + np.ascontiguousarray(fr[..., ::-1]).tobytes())  # PPM is R,G,B
+
+
+def _encode(exe, clip, *args):
+    path = os.path.join(BIN, exe)
+    if not os.path.exists(path):
+        pytest.skip(f"{exe} not built (needs /root/reference at build time)")
+    env = dict(os.environ, SVC_TEST_RANSAC_SEED=str(RANSAC_SEED))
+    t0 = time.time()
+    r = subprocess.run([path, *args, str(clip)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout, r.stderr.decode(), time.time() - t0
+
+
+def _draws(n_blocks, iters, subset, calls):
+    out = subprocess.check_output([os.path.join(BIN, "ransac_draws"), str(RANSAC_SEED), str(n_blocks), str(iters), str(subset), str(calls)],
+                                  text=True)
+    return [np.array(line.split(), np.uint32) for line in out.strip().split("\n")]
+
+
+class _TheRng:  # cv::theRNG() of compat/opencv2/core.hpp: OpenCV's multiply-with-carry step, default state
+    def __init__(self):
+        self.state = 0xffffffff
+
+    def next(self):
+        self.state = ((self.state & 0xffffffff) * 4164903690 + (self.state >> 32)) & 0xffffffffffffffff
+
+
+def _expected_stream(oracle, frames, levels, sse2_entry, tb, search_range=8):
+    """Header bytes + per encoded frame (tile types u32, tile coefficients f32 [tiles, 3 * tb * tb])."""
+    h, w, _ = frames[0].shape
+    pw, ph = synth.padded_dims(w, h, 16, 16, levels)
+    mfw, mfh = pw // 16, ph // 16
+    header = struct.pack("<8I", len(frames) - 1, w, h, pw - w, ph - h, tb, tb, 3)
+    padded = []
+    for fr in frames:
+        p = np.zeros((ph, pw, 3), np.uint8)  # cv::copyMakeBorder(..., BORDER_CONSTANT, 0), libs/encoder.cpp:447, :459
+        p[:h, :w] = fr
+        padded.append(p)
+    pyrs = [oracle.luma_pyramid(p, levels) for p in padded]
+    iters = oracle.ransac_iter_count(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+    draws = _draws(mfw * mfh, iters, 1, len(frames) - 1)
+    rng = _TheRng()
+    out = []
+    for t in range(1, len(frames)):
+        if sse2_entry:
+            mv, _ = oracle.hbma16_sse2(pyrs[t - 1], pyrs[t], search_range)
+        else:
+            mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, 16, 16)
+        _, _, inliers = oracle.ransac(mv, draws[t - 1], subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+        mask = np.zeros(mfw * mfh, np.uint8)
+        mask[inliers] = 1
+        types = oracle.segment(mask, mv, mfw, mfh, seed=rng.state)
+        if types.any():  # libs/encoder.cpp:553: cv::kmeans runs (and theRNG advances) only with a non-empty foreground
+            rng.next()
+        planes = oracle.dct_frame_f32(padded[t], tb, tb)
+        rec = oracle.serialize_frame(planes, types, w, h, tb, tb, mfw)  # the UNPADDED size, as libs/encoder.cpp:647-650 passes it
+        rec = rec.view(np.uint32).reshape(-1, 1 + 3 * tb * tb)
+        out.append((rec[:, 0].copy(), rec[:, 1:].copy().view(np.float32)))
+    return header, out
+
+
+def _check(got, header, expected, tb):
+    assert got[:32] == header
+    per = expected[0][0].size * (4 + 12 * tb * tb)
+    assert len(got) == 32 + per * len(expected), (len(got), per, len(expected))
+    fg_tiles = 0
+    for i, (types, coefs) in enumerate(expected):
+        rec = np.frombuffer(got, np.uint32, per // 4, 32 + i * per).reshape(-1, 1 + 3 * tb * tb)
+        assert np.array_equal(rec[:, 0], types), f"frame {i + 1}: {(rec[:, 0] != types).sum()} tile types differ"
+        c = rec[:, 1:].view(np.float32)
+        assert (np.abs(c - coefs) <= 1e-4 * np.maximum(1.0, np.abs(coefs))).all(), f"frame {i + 1}: coefficients"
+        fg_tiles += int((types != 0).sum())
+    return fg_tiles
+
+
+@pytest.mark.parametrize("exe,args,levels,sse2", [("ref_encoder_sse2", [], 4, True),
+                                                  ("ref_encoder_generic", ["--pyr-lvl-count", "3"], 3, False)],
+                         ids=["default-4-level-sse2-entry", "pyr-lvl-count-3"])
+def test_reference_encoder_1080p(native, oracle, tmp_path, exe, args, levels, sse2):
+    """A seeded 1080p clip through the reference's unchanged main(): reader thread -> Encoder::operator() -> writer thread."""
+    n = 5
+    clip = synth.SynthClip(1920, 1080, n, seed=0x5C0DEC02)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.svcbgr"
+    _write_clip(path, frames)
+    got, err, secs = _encode(exe, path, "--verbose", "1", *args)
+    assert "Width: 1920" in err and "Height: 1080" in err and f"Frame count: {n}" in err  # apps/encoder.cpp:206-211
+    header, expected = _expected_stream(oracle, frames, levels, sse2, 8)
+    fg = _check(got, header, expected, 8)
+    assert fg > 0  # the moving rectangles of the synthetic clip are foreground: k-means and the labelling really ran
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"ref_encoder_{exe}.txt"), "w") as f:
+        f.write(f"{exe} {' '.join(args)}: {n - 1} encoded 1080p frames in {secs:.2f} s (process start to exit, first-call "
+                f"GPU initialisation included), {len(got)} bytes, {fg} foreground tiles\n")
+
+
+def test_reference_encoder_odd_size_and_options(native, oracle, tmp_path):
+    """344 x 280 pads to 352 x 288, so the reference's serialiser -- which walks the UNPADDED size and uses the unpadded
+    width as the row stride of the padded planes (libs/encoder.cpp:243-258) -- shows its quirk, unchanged; a PPM stream as
+    the container; 16 x 16 transform blocks and non-default segmentation options from the command line."""
+    n = 7
+    clip = synth.SynthClip(344, 280, n, seed=99)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.ppm"
+    _write_ppm_stream(path, frames)
+    got, _, _ = _encode("ref_encoder_sse2", path, "--verbose", "0", "--transform-block-w", "16", "--transform-block-h", "16")
+    header, expected = _expected_stream(oracle, frames, 4, True, 16)
+    _check(got, header, expected, 16)
+    # the same clip from the other container gives the same bytes
+    path2 = tmp_path / "clip.svcbgr"
+    _write_clip(path2, frames)
+    got2, _, _ = _encode("ref_encoder_sse2", path2, "--verbose", "0", "--transform-block-w", "16", "--transform-block-h", "16")
+    assert got2 == got
+
+
+def test_reference_encoder_rejects_what_the_reference_rejects(native, tmp_path):
+    """Validate() (libs/encoder.cpp:62-142) and the capture check (apps/encoder.cpp:192-196) are the reference's own code."""
+    exe = os.path.join(BIN, "ref_encoder_generic")
+    if not os.path.exists(exe):
+        pytest.skip("ref_encoder_generic not built")
+    r = subprocess.run([exe, "--pyr-lvl-count", "5", "nothing.bgr"], capture_output=True, timeout=60)
+    assert r.returncode != 0 and b"validating configuration" in r.stderr
+    r = subprocess.run([exe, str(tmp_path / "missing.svcbgr")], capture_output=True, timeout=60)
+    assert r.returncode != 0 and b"failed to initialize video capturing" in r.stderr
