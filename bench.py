@@ -42,110 +42,242 @@ from scalable_video_codec_amd import configs, native, pipeline, synth  # noqa: E
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 12.0):
-    """Times the CPU path on THIS host, one core, on the first few frames of the same
-    clip.  Motion search: the unmodified reference (oracle/_ref) when it was built,
-    else the C restatement; RANSAC / DCT / quant: the restatement (cv::dct cannot be
-    built offline).  Only this leg and tests may touch oracle/."""
+def cpu_baseline(cfg: configs.CodecConfig, frames_bgr, budget_s: float = 7.0):
+    """Times the CPU path on THIS host on the first frames of the same clip, one core and all cores, in TWO rows:
+    the configuration's own level count, and the reference's default build (its SSE2 entry exists for 4 levels / 16x16 only,
+    libs/motion.hpp:143-147).  Motion search: the UNMODIFIED reference (oracle/_ref) when it was built, else the C
+    restatement.  RANSAC / segmentation / quant: the restatement.  Transform: oracle/svc_cpu_dct.c, an f32 separable DCT
+    with an AVX2 + FMA path (cv::dct cannot be built offline, so the reference's own transform cannot be timed;
+    `dct_is_reference` says so).  Only this leg and tests may touch oracle/."""
+    import concurrent.futures as cf
     import numpy as np
     from oracle import binding
     orc = binding.Oracle()
     ref = binding.Reference() if binding.Reference.available() else None
-    pw, ph = cfg.padded
-    # a bounded sample of the same clip: enough frames for ~10-15 s of single-core work
+    impl = ref if ref is not None else orc
     n = min(len(frames_bgr), 128)
     host = [f.cpu() for f in frames_bgr[:n]]
-    pyrs = {}
-
-    def pyr(i):  # built lazily (the pre-step is not part of the timed CPU work, as on the GPU side's input)
-        if i not in pyrs:
-            pyrs[i] = [p.numpy() for p in synth.build_pyramid(synth.bgr_to_y(host[i]), cfg.levels)]
-        return pyrs[i]
+    host_np = [f.numpy() for f in host]
     k = orc.ransac_iter_count(**binding.DEFAULT_RANSAC)
-    t_hbma = t_rest = 0.0
-    done = 0
-    t_start = time.perf_counter()
-    # the reference's default build runs its SSE2 entry, which exists for 4 levels / 16x16 only
-    # (libs/motion.hpp:143-147, libs/encoder.cpp:472-476); other level counts run the generic path
-    use_sse2 = cfg.levels == 4 and cfg.mv_block == 16
-    if ref is not None:
-        search = (lambda t, a: ref.hbma16_sse2(t, a, cfg.search_range)) if use_sse2 else \
-                 (lambda t, a: ref.hbma(t, a, cfg.search_range, cfg.mv_block, cfg.mv_block))
-        search_name = "unmodified reference " + ("EstimateMotionHierarchical16x16Sse2" if use_sse2 else
-                                                "EstimateMotionHierarchical (generic path; the SSE2 path only exists for 4 levels)")
-    else:
-        search = (lambda t, a: orc.hbma16_sse2(t, a, cfg.search_range)) if use_sse2 else \
-                 (lambda t, a: orc.hbma(t, a, cfg.search_range, cfg.mv_block, cfg.mv_block))
-        search_name = "C restatement" + (" (SSE2 path)" if use_sse2 else "")
-    search(pyr(0), pyr(1))  # warm-up: page in, let the core clock up
     mfw, mfh = cfg.mv_field
-
-    def encode_frame(i, ta, tb_):  # everything the hot path does for encoded frame i, on the CPU
-        t0 = time.perf_counter()
-        mv, _ = search(ta, tb_)
-        t1 = time.perf_counter()
-        samples = (np.arange(k, dtype=np.uint32) * 2654435761 % len(mv)).astype(np.uint32)
-        _, _, inl = orc.ransac(mv, samples, **binding.DEFAULT_RANSAC)
-        inl_mask = np.zeros(len(mv), np.uint8)
-        inl_mask[inl] = 1
-        types = orc.segment(inl_mask, mv, mfw, mfh, cfg.mv_block, cfg.mv_block, seed=i)
-        if cfg.dct_block:
-            planes = orc.dct_frame_f32(host[i].numpy(), cfg.dct_block, cfg.dct_block)
-            orc.quant_frame(planes, cfg.mv_block, cfg.mv_block, types, cfg.fg_step, cfg.bg_step)
-        return t1 - t0, time.perf_counter() - t1
-
-    busy = 0.0
-    for i in range(1, n):
-        ta, tb_ = pyr(i - 1), pyr(i)
-        pyrs.pop(i - 2, None)
-        dt_search, dt_rest = encode_frame(i, ta, tb_)
-        t_hbma += dt_search
-        t_rest += dt_rest
-        busy += dt_search + dt_rest
-        done += 1
-        if busy > budget_s:
-            break
-    # the same work frame-parallel on the host's cores (the reference itself encodes on one thread,
-    # apps/encoder.cpp:228; this is what a frame-parallel CPU deployment of it would get): the C entry
-    # points release the GIL, so plain threads scale
-    import concurrent.futures as cf
     cores = max(1, min(len(os.sched_getaffinity(0)), 32))
-    all_cores = None
-    if cores > 1 and done:
-        m = min(n - 1, 3 * cores)
-        pp = [pyr(i) for i in range(m + 1)]  # pre-step, untimed as above
-        with cf.ThreadPoolExecutor(max_workers=cores) as ex:
-            list(ex.map(lambda i: encode_frame(i, pp[i - 1], pp[i]), range(1, min(m, cores) + 1)))  # warm the pool
+    fast_dct = cfg.dct_block in (8, 16)
+
+    def run_row(levels: int, sse2: bool, label: str):
+        pyrs = {}
+
+        def pyr(i):  # built lazily; the pre-step is not part of the timed CPU work (the GPU side's input is the same frames)
+            if i not in pyrs:
+                pyrs[i] = [p.numpy() for p in synth.build_pyramid(synth.bgr_to_y(host[i]), levels)]
+            return pyrs[i]
+        search = (lambda t, a: impl.hbma16_sse2(t, a, cfg.search_range)) if sse2 else \
+                 (lambda t, a: impl.hbma(t, a, cfg.search_range, cfg.mv_block, cfg.mv_block))
+        local = __import__("threading").local()
+
+        def encode_frame(i, ta, tb_):  # everything the hot path does for encoded frame i, on the CPU
             t0 = time.perf_counter()
-            list(ex.map(lambda i: encode_frame(i, pp[i - 1], pp[i]), range(1, m + 1)))
-            wall = time.perf_counter() - t0
-        all_cores = {"value": m / wall, "unit": "frames/s", "cores": cores,
-                     "sample": f"{m} encoded frames of the same clip, one frame per task on {cores} threads"}
-        del pp
-    # the reference's own fast path (SSE2, fixed 4 levels) on the same frames, for context
-    sse2_ms = None
-    if ref is not None and not use_sse2 and cfg.mv_block == 16 and cfg.padded[0] % 8 == 0 and cfg.padded[1] % 8 == 0:
-        p4 = [[p.numpy() for p in synth.build_pyramid(synth.bgr_to_y(f), 4)] for f in host[:2]]
-        ref.hbma16_sse2(p4[0], p4[1], cfg.search_range)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            ref.hbma16_sse2(p4[0], p4[1], cfg.search_range)
-        sse2_ms = (time.perf_counter() - t0) / 3 * 1e3
-    total = t_hbma + t_rest
+            mv, _ = search(ta, tb_)
+            t1 = time.perf_counter()
+            samples = (np.arange(k, dtype=np.uint32) * 2654435761 % len(mv)).astype(np.uint32)
+            _, _, inl = orc.ransac(mv, samples, **binding.DEFAULT_RANSAC)
+            inl_mask = np.zeros(len(mv), np.uint8)
+            inl_mask[inl] = 1
+            types = orc.segment(inl_mask, mv, mfw, mfh, cfg.mv_block, cfg.mv_block, seed=i)
+            t2 = time.perf_counter()
+            if cfg.dct_block:
+                if fast_dct:
+                    if not hasattr(local, "planes"):
+                        local.planes = np.empty((3,) + host_np[i].shape[:2], np.float32)
+                    planes = orc.cpu_dct_frame_f32(host_np[i], cfg.dct_block, local.planes)
+                else:
+                    planes = orc.dct_frame_f32(host_np[i], cfg.dct_block, cfg.dct_block)
+                t3 = time.perf_counter()
+                orc.cpu_quant_frame_f32(np.ascontiguousarray(planes), cfg.mv_block, cfg.mv_block, types, cfg.fg_step, cfg.bg_step)
+            else:
+                t3 = t2
+            return t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3
+
+        search(pyr(0), pyr(1))  # warm-up: page in, let the core clock up
+        tot = [0.0, 0.0, 0.0, 0.0]
+        done, busy = 0, 0.0
+        for i in range(1, n):
+            ta, tb_ = pyr(i - 1), pyr(i)
+            pyrs.pop(i - 2, None)
+            dts = encode_frame(i, ta, tb_)
+            tot = [a + b for a, b in zip(tot, dts)]
+            busy += sum(dts)
+            done += 1
+            if busy > budget_s:
+                break
+        # the same work frame-parallel on the host's cores (the reference itself encodes on one thread, apps/encoder.cpp:228;
+        # this is what a frame-parallel CPU deployment of it would get): the C entry points release the GIL
+        all_cores = None
+        if cores > 1 and done:
+            m = min(n - 1, 3 * cores)
+            pp = [pyr(i) for i in range(m + 1)]  # pre-step, untimed as above
+            with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+                list(ex.map(lambda i: encode_frame(i, pp[i - 1], pp[i]), range(1, min(m, cores) + 1)))  # warm the pool
+                t0 = time.perf_counter()
+                list(ex.map(lambda i: encode_frame(i, pp[i - 1], pp[i]), range(1, m + 1)))
+                wall = time.perf_counter() - t0
+            all_cores = {"value": m / wall, "unit": "frames/s", "cores": cores,
+                         "sample": f"{m} encoded frames of the same clip, one frame per task on {cores} threads"}
+        total = sum(tot)
+        return {
+            "label": label, "levels": levels,
+            "value": done / total if total > 0 else None, "unit": "frames/s", "cores": 1, "frames_timed": done,
+            "hbma_ms_per_frame": tot[0] / done * 1e3 if done else None,
+            "ransac_segment_ms_per_frame": tot[1] / done * 1e3 if done else None,
+            "dct_ms_per_frame": tot[2] / done * 1e3 if done else None,
+            "quant_ms_per_frame": tot[3] / done * 1e3 if done else None,
+            "all_cores": all_cores,
+        }
+
+    who = "unmodified reference" if ref is not None else "C restatement of"
+    own_sse2 = cfg.levels == 4 and cfg.mv_block == 16
+    rows = {}
+    if own_sse2:
+        rows["config"] = run_row(4, True, f"{who} EstimateMotionHierarchical16x16Sse2 (the reference's default build) + the CPU transform")
+        rows["generic"] = run_row(4, False, f"{who} EstimateMotionHierarchical, 4 levels, generic path (SVC_MOTION_SSE2 off) + the CPU transform")
+    else:
+        rows["config"] = run_row(cfg.levels, False, f"{who} EstimateMotionHierarchical, {cfg.levels} levels (generic path: the reference's SSE2 path "
+                                 "exists for 4 levels only) + the CPU transform")
+        pw, ph = cfg.padded
+        if cfg.mv_block == 16 and pw % 8 == 0 and ph % 8 == 0:
+            rows["sse2_4level"] = run_row(4, True, f"{who} EstimateMotionHierarchical16x16Sse2 -- the reference's default build, 4 levels, "
+                                          "NOT this configuration's level count -- + the CPU transform")
+    main = rows["config"]
     return {
-        "value": done / total if total > 0 else None,
+        "value": main["value"],
         "unit": "frames/s",
         "cores": 1,
         "kind": "reference" if ref is not None else "port",
-        "sample": (f"first {done} encoded frames of the same clip, 1 thread: motion search = {search_name}"
-                   f", RANSAC/segmentation/DCT(f64 separable)/quant = C restatement (cv::dct is not buildable offline)"),
-        "hbma_ms_per_frame": t_hbma / done * 1e3 if done else None,
-        "ransac_dct_quant_ms_per_frame": t_rest / done * 1e3 if done else None,
-        "dct_leg": "own f64 separable DCT-II (C restatement), not cv::dct: OpenCV is not installed, the reference's transform cannot be timed",
+        "sample": (f"first {main['frames_timed']} encoded frames of the same clip, 1 thread: motion search = {main['label']}; "
+                   "RANSAC / segmentation = C restatement; transform + quant = oracle/svc_cpu_dct.c (f32 separable, "
+                   f"{orc.cpu_dct_isa() if fast_dct else 'f64 from the definition: block size outside 8 / 16'}), not cv::dct"),
+        "rows": rows,
+        "hbma_ms_per_frame": main["hbma_ms_per_frame"],
+        "ransac_dct_quant_ms_per_frame": (main["ransac_segment_ms_per_frame"] or 0) + (main["dct_ms_per_frame"] or 0) + (main["quant_ms_per_frame"] or 0),
+        "dct_leg": ("own f32 separable DCT-II with an AVX2 + FMA path (oracle/svc_cpu_dct.c; checked against the f64 oracle at 1e-4 max(1, |ref|)), "
+                    "not cv::dct: OpenCV is not installed, the reference's transform cannot be timed"),
+        "dct_isa": orc.cpu_dct_isa(),
         "dct_is_reference": False,
-        "reference_sse2_4level_hbma_ms_per_frame": sse2_ms,
-        "all_cores": all_cores,
+        "reference_sse2_4level_hbma_ms_per_frame": (rows.get("sse2_4level") or rows["config"])["hbma_ms_per_frame"] if (own_sse2 or "sse2_4level" in rows) else None,
+        "all_cores": main["all_cores"],
     }
+
+
+def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
+    """PCIe-INCLUSIVE rates of the three host-facing ways into the path ("plus a separate end-to-end
+    number including PCIe"), measured on this box OUTSIDE the timed region, frames starting in host memory and every
+    output landing back in host memory:
+      reference_signatures_fps   one frame per call through the reference's own signatures (svc_hip_hbma_host + _ransac_host +
+                                 _dct_quant_host, what libsvc_motion.so's wrappers call), synchronous, one host thread;
+      stream_encoder_fps         svc::StreamEncoder (C++, tests/dropin/stream_main): batches, H2D / kernels / D2H on three streams;
+      reference_application_fps  the reference's UNCHANGED apps/encoder.cpp + libs/encoder.cpp on compat/opencv2
+                                 (tests/dropin/ref_encoder_*), two clip lengths so that process start-up cancels.
+    `value` of the line never includes any of this."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    out = {"unit": "frames/s", "pcie_inclusive": True, "config": cfg.name,
+           "bound": "PCIe D2H of the f32 coefficients (25 MB per 1080p frame: 63 GB/s caps a host-fed pipeline near 2 000 frames/s) for the batched "
+                    "driver; host-side copies and per-call round trips for the two per-frame forms"}
+    pw, ph = cfg.padded
+    host = [f.cpu().numpy() for f in frames_padded[:66]]
+    # (a) the reference's one-frame-per-call signatures
+    try:
+        pyr = [[p.numpy() for p in synth.build_pyramid(synth.bgr_to_y(torch.from_numpy(f)), cfg.levels)] for f in host[:2]]
+        types = np.zeros(cfg.blocks, np.uint32)
+        smp = (np.arange(native.ransac_iter_count(), dtype=np.uint32) * 977) % cfg.blocks
+
+        def one_frame():
+            mv, _ = native.hbma_host(pyr[0], pyr[1], cfg.search_range, cfg.mv_block, cfg.mv_block)
+            native.ransac_host(mv, smp)
+            if cfg.dct_block:
+                native.dct_quant_host(host[1], cfg.dct_block, types, cfg.mv_block, cfg.fg_step, cfg.bg_step)
+        one_frame(); one_frame()
+        t0 = time.perf_counter()
+        for _ in range(12):
+            one_frame()
+        out["reference_signatures_fps"] = 12 / (time.perf_counter() - t0)
+    except Exception as e:  # noqa: BLE001
+        out["reference_signatures_fps"] = None
+        out["reference_signatures_note"] = f"not measured: {e}"
+    bin_dir = os.path.join(ROOT, "tests", "dropin")
+    tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=tmp_root) as d:
+        src = np.stack([f[:cfg.height, :cfg.width] for f in host])  # the unpadded source frames
+        # (b) the batched C++ driver
+        exe = os.path.join(bin_dir, "stream_main")
+        try:
+            raw = os.path.join(d, "clip.raw")
+            n = min(len(src), 65)
+            src[:n].tofile(raw)
+            r = subprocess.run([exe, raw, str(cfg.width), str(cfg.height), str(n), str(cfg.levels), str(cfg.dct_block), "0", "16",
+                                str(cfg.seed), "-"], capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
+            out["stream_encoder_fps"] = float(r.stdout.split("encoded frames,")[1].split("frames/s")[0])
+            out["stream_encoder_sample"] = f"{n - 1} encoded frames, batch 16, second pass over the clip (first pass = warm-up)"
+            os.remove(raw)
+        except Exception as e:  # noqa: BLE001
+            out["stream_encoder_fps"] = None
+            out["stream_encoder_note"] = f"not measured: {e}"
+        # (c) the reference's own application
+        sse2 = cfg.levels == 4 and cfg.mv_block == 16
+        exe = os.path.join(bin_dir, "ref_encoder_sse2" if sse2 else "ref_encoder_generic")
+        try:
+            if not os.path.exists(exe):
+                raise RuntimeError("tests/dropin/ref_encoder_* not built (needs /root/reference at build time)")
+            args = ["--verbose", "0", "--transform-block-w", str(cfg.dct_block or 8), "--transform-block-h", str(cfg.dct_block or 8)]
+            if not sse2:
+                args += ["--pyr-lvl-count", str(cfg.levels), "--mv-block-w", str(cfg.mv_block), "--mv-block-h", str(cfg.mv_block)]
+            times = {}
+            for n in (5, min(len(src), 37)):
+                path = os.path.join(d, f"clip{n}.svcbgr")
+                with open(path, "wb") as f:
+                    f.write(b"SVCBGR1\0" + np.array([cfg.width, cfg.height, n, 0], np.uint32).tobytes())
+                    src[:n].tofile(f)
+                t0 = time.perf_counter()
+                with open(os.devnull, "wb") as sink:
+                    r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600)
+                times[n] = time.perf_counter() - t0
+                os.remove(path)
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr.decode()[-300:])
+            (n1, t1), (n2, t2) = sorted(times.items())
+            out["reference_application_fps"] = (n2 - n1) / max(t2 - t1, 1e-9)
+            out["reference_application_sample"] = (f"{os.path.basename(exe)} {' '.join(args)}: {n1} and {n2} frame clips, stdout to /dev/null; "
+                                                   f"({n2} - {n1}) frames / ({t2:.2f} - {t1:.2f}) s, so process start-up and GPU initialisation cancel")
+        except Exception as e:  # noqa: BLE001
+            out["reference_application_fps"] = None
+            out["reference_application_note"] = f"not measured: {e}"
+    return out
+
+
+def predicted_step(cfg: configs.CodecConfig, frames_per_gpu: int, measured_ms: float, world: int) -> dict:
+    """What DESIGN.md section 6 PREDICTS for this run, next to what it measured: the repo's scaling table is built from the step
+    time ONE MI355X needs for the shard a rank holds (tools/shard_sizes.sh -> profiles/r0N_shard_sizes.json, halo assumed off
+    the critical path, eight ranks assumed to behave like one).  The first real N-GPU run grades that model by itself:
+    ratio = measured / predicted (1.0 = the model holds; > 1 = the ranks, the halo or the launcher cost what the 1-GPU
+    model does not see)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_shard_sizes.json")))
+    if not files:
+        return {"predicted_ms_per_step": None, "note": "no profiles/r0N_shard_sizes.json in this checkout"}
+    with open(files[-1]) as f:
+        rows = [r for r in json.load(f)["rows"] if r["workload"].startswith(cfg.name)]
+    same = [r["ms_per_step"] for r in rows if r["frames_per_gpu"] == frames_per_gpu]
+    whole = [r["ms_per_step"] for r in rows if r["frames_per_gpu"] == cfg.frames]
+    if not same:
+        return {"predicted_ms_per_step": None, "source": os.path.basename(files[-1]),
+                "note": f"no 1-GPU measurement of a {frames_per_gpu}-frame shard of {cfg.name} in that file"}
+    pred = sum(same) / len(same)
+    return {"predicted_ms_per_step": pred, "measured_ms_per_step": measured_ms, "ratio_measured_over_predicted": measured_ms / pred,
+            "predicted_speedup_vs_1_gpu": (sum(whole) / len(whole)) / pred if whole else None,
+            "frames_per_gpu": frames_per_gpu, "n_gpus": world, "source": "profiles/" + os.path.basename(files[-1]),
+            "model": "step time of the largest shard on ONE MI355X, pipelined schedule; halo off the critical path"}
 
 
 def hbm_streaming_rates(device) -> dict:
@@ -208,8 +340,6 @@ def _torch_halo_transport(rank: int, world: int, staged: bool):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()  # nccl: orders the stream behind the transfer, does not block the host
             if staged and rank > 0:
-                if os.environ.get("SVC_BENCH_CORRUPT_HALO") == "1":  # test hook (gloo rehearsal only): the self-check must catch it
-                    recv_h[12345] ^= 0x40
                 recv.copy_(recv_h)
                 stream.synchronize()
     return fn
@@ -379,6 +509,7 @@ def main() -> None:
                     help="segmentation: one workgroup per (frame, k-means attempt) even on small shards of large fields (A/B of the multi-launch form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="N = 1: skip the PCIe-inclusive end_to_end object (measured outside the timed region)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -510,6 +641,7 @@ def main() -> None:
                         "between barriers.  halo_exchange_ms: event-to-event on the communication stream (includes waiting for the "
                         "neighbour's pyramid kernel)",
             }
+            out["multi_gpu"]["prediction"] = predicted_step(cfg, max(int(x[2]) for x in pr), out["ms_per_step"], world) if main_mode == "strong" else None
         if "weak" in results and main_mode != "weak":
             w = results["weak"]
             out["weak"] = {"value": w["encoded_per_step"] * args.steps / w["elapsed"], "unit": "frames/s",
@@ -571,6 +703,8 @@ def main() -> None:
             # context only: what plain streaming kernels get from this box's HBM (not a ceiling: the DCT kernel beats the 1:4 probe)
             out["hbm_streaming_measured"] = {"unit": "GB/s", **hbm_streaming_rates(dev),
                                              "note": "svc_hip_probe_stream on this GPU, context only; roofline fractions are against the 8 TB/s peak"}
+        if r["sample_frames"] is not None and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end_rates(cfg, r["sample_frames"])
         if r["sample_frames"] is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, r["sample_frames"])
             cb = out["cpu_baseline"]

@@ -430,7 +430,7 @@ int svc_hip_dct_planes_host(const uint8_t* bgr, uint32_t frame_w, uint32_t frame
  * Encoder::operator() (the adapter under compat/opencv2/ makes cv::cvtColor, cv::buildPyramid, cv::morphologyEx,
  * cv::kmeans, cv::connectedComponents and cv::dct thin callers of these).  All images are tightly packed
  * (row stride = width x channels); all calls are synchronous and thread-safe like the other *_host forms.  The OpenCV
- * semantics followed are the ones stated in oracle/svc_oracle.h / oracle/svc_segment.c (parity with OpenCV itself is
+ * semantics followed are the ones stated in oracle/svc_imageops.c / oracle/svc_segment.c (parity with OpenCV itself is
  * unpinned offline); the fused, batched device forms above (svc_hip_luma_pyramid_frames, svc_hip_segment_frames,
  * svc_hip_dct_frames) compute the same values and are what a throughput-minded caller uses.
  * ------------------------------------------------------------------------- */

@@ -91,6 +91,11 @@ class Oracle:
         L.svc_oracle_kmeans.argtypes = [_f32p] + [C.c_uint32] * 5 + [C.c_float, C.c_uint64, _i32p, _f64p]
         L.svc_oracle_connected_components.restype = C.c_uint32
         L.svc_oracle_connected_components.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
+        L.svc_cpu_dct_frame_f32.restype = C.c_int
+        L.svc_cpu_dct_frame_f32.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+        L.svc_cpu_dct_isa.restype = C.c_int
+        L.svc_cpu_quant_frame_f32.restype = None
+        L.svc_cpu_quant_frame_f32.argtypes = [_f32p] + [C.c_uint32] * 4 + [_u32p, C.c_uint32, C.c_uint32]
         L.svc_oracle_serialize_frame.restype = C.c_uint64
         L.svc_oracle_serialize_frame.argtypes = [_f32p, C.c_uint64, C.c_uint32, _u32p] + [C.c_uint32] * 7 + [_u8p]
         L.svc_oracle_decode_frame.restype = None
@@ -324,6 +329,27 @@ class Oracle:
             types[sel] = cc[sel].astype(np.uint32) + offset
             offset += count
         return types
+
+    # -- the CPU baseline's transform (svc_cpu_dct.c): f32 separable, AVX2 where available --
+    def cpu_dct_frame_f32(self, bgr, block, out=None):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        if out is None:
+            out = np.empty((3, h, w), np.float32)
+        if self.lib.svc_cpu_dct_frame_f32(_ptr(bgr, _u8p), w, h, block, _ptr(out, _f32p)):
+            raise ValueError("svc_cpu_dct_frame_f32: block must be 8 or 16 and divide the frame")
+        return out
+
+    def cpu_quant_frame_f32(self, planes, mv_bw, mv_bh, block_types, fg_step, bg_step):
+        """In place on a C-contiguous (3, H, W) f32 array; returns it."""
+        assert planes.dtype == np.float32 and planes.flags["C_CONTIGUOUS"]
+        bt = np.ascontiguousarray(block_types, np.uint32)
+        self.lib.svc_cpu_quant_frame_f32(_ptr(planes, _f32p), planes.shape[2], planes.shape[1], mv_bw, mv_bh, _ptr(bt, _u32p),
+                                         fg_step, bg_step)
+        return planes
+
+    def cpu_dct_isa(self) -> str:
+        return "avx2+fma" if self.lib.svc_cpu_dct_isa() == 2 else "sse2 (baseline x86-64)"
 
     # -- quant / DCT --
     def quant(self, coeffs, step):

@@ -199,6 +199,14 @@ void svc_oracle_dct_frame_f32(const uint8_t* bgr, uint32_t w, uint32_t h,
                               uint32_t block_w, uint32_t block_h,
                               float* planes32);
 
+/* The CPU BASELINE's transform (oracle/svc_cpu_dct.c): f32 separable 8x8 / 16x16 DCT-II, AVX2 + FMA where the host has it.
+ * Timed by bench.py's cpu_baseline leg, checked against svc_oracle_dct_frame_f64; not the oracle and not cv::dct. */
+int svc_cpu_dct_frame_f32(const uint8_t* bgr, uint32_t w, uint32_t h, uint32_t block, float* planes32);
+/* svc_oracle_quant_frame's bits at CPU-deployment speed (same file) */
+void svc_cpu_quant_frame_f32(float* planes, uint32_t w, uint32_t h, uint32_t mv_bw, uint32_t mv_bh, const uint32_t* block_types,
+                             uint32_t fg_step, uint32_t bg_step);
+int svc_cpu_dct_isa(void); /* 2 = the avx2 + fma clone runs on this host, 0 = the baseline x86-64 clone */
+
 /* libs/decoder.cpp:128-149 + :183-207, headless: reconstructed B,G,R (H x W x 3 doubles). */
 void svc_oracle_decode_frame(const float* planes, uint32_t w, uint32_t h, uint32_t block_w, uint32_t block_h,
                              const uint32_t* block_types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg_step,

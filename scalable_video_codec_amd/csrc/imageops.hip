@@ -5,7 +5,7 @@
 //
 // These are the PER-CALL forms: a frame's worth of small, latency-bound work behind a PCIe round trip each.  The
 // throughput path is the fused, batched device forms (luma_pyramid.hip, segment.hip, dct.hip); the definitions are the
-// same (oracle/svc_oracle.h, oracle/svc_segment.c), and tests/test_gpu_imageops.py checks that composing these calls
+// same (stated in oracle/svc_segment.c and oracle/svc_imageops.c), and tests/test_gpu_imageops.py checks that composing these calls
 // the way the reference composes the cv:: ones reproduces svc_hip_segment_frames' region ids.
 #include <cstring>
 

@@ -255,12 +255,6 @@ struct Workspace {
   __device__ WideState* wide(uint32_t a) const { return reinterpret_cast<WideState*>(base + off_wide()) + a; }
 };
 
-#ifdef SVC_SEG_TIMING  // diagnostic build only (tools/diag_segment_phases.py): shader-clock stamps of the phases
-#define SEG_STAMP(slot) do { if (tid == 0) stamps[slot] = (unsigned long long)clock64(); } while (0)
-#else
-#define SEG_STAMP(slot) do { } while (0)
-#endif
-
 // The labelling kernel is launched kTA lanes wide, which is what its field-sized sweeps (clears, runs)
 // want; once those are done the workgroup keeps only the lanes the frame's foreground count can feed:
 // the rest of its waves end there (s_barrier counts surviving waves only).
@@ -495,17 +489,14 @@ __device__ __forceinline__ void seed_regs(const uint32_t* pk, uint32_t (&v)[P], 
 
 template <uint32_t P>
 __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab, KmLds& L, const SegArgs& a,
-                                                uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te,
-                                                unsigned long long* stamps) {
+                                                uint32_t nf, uint32_t k, uint64_t aseed, uint32_t tid, uint32_t te) {
   const uint32_t lane = tid & 63u;
   const uint32_t bw = a.mv_bw, bh = a.mv_bh;
-  (void)stamps;
   const uint32_t pper = (nf + te - 1) / te;  // block-uniform, <= P
   const uint32_t p0 = tid * pper;
   uint32_t v[P];
   seed_regs<P>(pk, v, L, a, nf, k, aseed, tid, te);
   lloyd_begin(L, k, tid);
-  SEG_STAMP(4);
 
   uint32_t oldpack[P / 4];  // the points' current labels, a byte each
 #pragma unroll
@@ -531,9 +522,7 @@ __device__ __forceinline__ uint64_t kmeans_regs(const uint32_t* pk, uint8_t* lab
         for (uint32_t u = 0; u < 4; ++u) np |= (act[u] ? bj[u] : 0xFFu) << (8 * u);
         oldpack[g] = np;
       }
-    SEG_STAMP(5 + 2 * it);
     const bool done = lloyd_end_iter(lc, compact, it, L, a, k, tid, lane);
-    SEG_STAMP(6 + 2 * it);
     if (done) break;
   }
 #pragma unroll
@@ -747,10 +736,6 @@ __global__ __launch_bounds__(kTA) void segment_prepare_kernel(SegArgs a) {
   const float2* mv = reinterpret_cast<const float2*>(a.mv) + (size_t)frame * n;
   const Workspace ws{a.ws + (size_t)frame * a.ws_stride, n, a.attempts};
   uint32_t* idx = ws.idx();
-#ifdef SVC_SEG_TIMING
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws.dmin(0) + ((n - 64) & ~1u));
-#endif
-  SEG_STAMP(0);
 
   BitField bf;
   bf.W32 = (a.mfw + 31) / 32; bf.H = a.mfh; bf.NW = bf.W32 * bf.H;
@@ -795,7 +780,6 @@ __global__ __launch_bounds__(kTA) void segment_prepare_kernel(SegArgs a) {
   bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, true, tid);
   bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, true, tid);
   bit_morph(bitA, bitB, bitA, bf, a.morph_w, a.morph_h, false, tid);
-  SEG_STAMP(1);
 
   // ---- foreground list in raster order (:538-546) -> feature points (:300-321) ------------
   const uint32_t wper = (bf.NW + kTA - 1) / kTA;
@@ -859,7 +843,6 @@ __global__ __launch_bounds__(kTA) void segment_prepare_kernel(SegArgs a) {
       }
     }
   }
-  SEG_STAMP(2);
 }
 
 // Kernel A: one workgroup per (frame, k-means attempt).  Attempts are independent restarts
@@ -891,12 +874,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const uint32_t te = T == kTA ? kTA : nf <= 256 ? 64u : 256u;  // one wave: no barrier ever waits
   if (tid >= te) return;  // whole waves; the barriers below count the surviving ones only
   uint8_t* lab = ws.lab(att);
-#ifdef SVC_SEG_TIMING
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(lab + ((n - 256) & ~7u));
-#else
-  unsigned long long* stamps = nullptr;
-#endif
-  SEG_STAMP(3);
   const uint32_t k = min(a.k, nf);  // :555
   const bool packed = *ws.packed() != 0;
 
@@ -904,7 +881,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const uint64_t aseed = (a.seed + frame) ^ ((uint64_t)att << 32);
   uint64_t compact;
   if (packed && nf <= kRegPts * te) {
-    compact = kmeans_regs<kRegPts>(ws.pk(), lab, L, a, nf, k, aseed, tid, te, stamps);
+    compact = kmeans_regs<kRegPts>(ws.pk(), lab, L, a, nf, k, aseed, tid, te);
   } else if (packed) {
     const size_t lds_cap = T == kTA ? a.lds_bytes : 0;  // the 256-lane launch has no dynamic LDS: workspace
     uint32_t* pk = ws.pk();
@@ -921,7 +898,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     compact = kmeans_generic(ws.pts(), lab, L, a, nf, k, aseed, tid, te);
   }
   if (tid == 0) ws.compact()[att] = compact;
-  SEG_STAMP(31);
 }
 
 // ---- an attempt as a SEQUENCE OF LAUNCHES over G workgroups (few frames, large fields) ---------------------------
@@ -1227,10 +1203,6 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   const uint32_t* idx = ws.idx();
   uint32_t* roots = ws.roots();
   const uint32_t nf = *ws.nf();
-#ifdef SVC_SEG_TIMING
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(roots + ((n - 64) & ~1u));
-#endif
-  SEG_STAMP(0);
 
   for (uint32_t i = tid; i < n; i += kTA) { types[i] = 0; cl[i] = 255; }  // :549-551
   if (nf == 0) return;
@@ -1262,7 +1234,6 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   __syncthreads();
   for (uint32_t i = tid; i < nf; i += kTA) cl[idx[i]] = best_lab[i];
   __syncthreads();
-  SEG_STAMP(1);
   // Horizontal runs first, without a single union: a wave looks at 64 consecutive blocks, one ballot
   // says which of them continue the run of their left neighbour, and every block of a run is pointed
   // straight at the run's first block inside the window (the smallest index, as the forest wants).
@@ -1312,14 +1283,12 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
     }
   }
   __syncthreads();
-  SEG_STAMP(2);
   for (uint32_t q = tid; q < nf; q += te) {
     const uint32_t i = idx[q];
     const uint32_t r = uf_find(parent, i);
     if (r != i) parent[i] = r;  // still an ancestor for any concurrent walker; roots are never rewritten
   }
   __syncthreads();
-  SEG_STAMP(3);
   // component roots, compacted in raster order (lane-contiguous ranges of the list + one block scan)
   const uint32_t pper = (nf + te - 1) / te;
   const uint32_t p0 = min(nf, tid * pper), p1 = min(nf, p0 + pper);
@@ -1339,7 +1308,6 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
   // the clusters present, across waves and rounds by the small per-(wave, cluster) table.  A root's
   // parent entry becomes 0x80000000 | its 1-based number (nobody walks the forest any more).
   const uint32_t R = (uint32_t)total_roots;
-  SEG_STAMP(4);
   for (uint32_t r0 = 0; r0 < R; r0 += te) {
     const uint32_t q = r0 + tid;
     const bool act = q < R;
@@ -1369,7 +1337,6 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
     }
     __syncthreads();
   }
-  SEG_STAMP(5);
   if (tid == 0) {  // BLOCK_TYPE_BACKGROUND = 0 (libs/codec.hpp:6); :620, the count includes label 0
     uint32_t offset = 0;
     for (uint32_t cid = 0; cid < k; ++cid) {
@@ -1385,10 +1352,6 @@ __global__ __launch_bounds__(kTA) void segment_label_kernel(SegArgs a) {
     if (!(pv & 0x80000000u)) pv = parent[pv];
     types[i] = (pv & 0x7FFFFFFFu) + s_base[cl[i]];  // :617
   }
-  SEG_STAMP(6);
-#ifdef SVC_SEG_TIMING
-  if (tid == 0) stamps[7] = R;
-#endif
 }
 
 // One side stream + fork/join events per host thread and device, created on first use and kept.

@@ -2,6 +2,7 @@
 // reads a raw B,G,R clip, encodes it through svc::StreamEncoder, writes every output in clip
 // order.  tests/test_gpu_stream.py compares the files with the resident Python path.
 //   stream_main <clip.raw> <w> <h> <frames> <levels> <dct_block> <wire 0|1> <batch> <seed> <out_prefix>
+// out_prefix "-": no output files, only the PCIe-inclusive rate (bench.py's end_to_end.stream_encoder_fps).
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -28,15 +29,17 @@ int main(int argc, char** argv) {
   if (!f || std::fread(clip.data(), 1, clip.size(), f) != clip.size()) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
   std::fclose(f);
 
-  FILE* f_mv = std::fopen((prefix + ".mv").c_str(), "wb");
-  FILE* f_ty = std::fopen((prefix + ".types").c_str(), "wb");
-  FILE* f_gm = std::fopen((prefix + ".gm").c_str(), "wb");
-  FILE* f_big = std::fopen((prefix + ".big").c_str(), "wb");
+  const bool files = prefix != "-";
+  const char* sink_path = files ? nullptr : "/dev/null";
+  FILE* f_mv = std::fopen(files ? (prefix + ".mv").c_str() : sink_path, "wb");
+  FILE* f_ty = std::fopen(files ? (prefix + ".types").c_str() : sink_path, "wb");
+  FILE* f_gm = std::fopen(files ? (prefix + ".gm").c_str() : sink_path, "wb");
+  FILE* f_big = std::fopen(files ? (prefix + ".big").c_str() : sink_path, "wb");
   if (!f_mv || !f_ty || !f_gm || !f_big) { std::fprintf(stderr, "cannot open outputs under %s\n", prefix.c_str()); return 1; }
   try {
     svc::StreamEncoder enc(cfg);
     uint32_t next = 1, total = 0;
-    bool dump = true;
+    bool dump = files;
     // the documented lifetime: a delivered view stays valid until depth - 2 = 1 more batch has been delivered
     const float* held = nullptr;
     std::vector<float> held_copy;
@@ -48,7 +51,7 @@ int main(int argc, char** argv) {
       held = b.mv_xy;
       held_copy.assign(b.mv_xy, b.mv_xy + (size_t)b.count * b.mv_field_w * b.mv_field_h * 2);
       if ((b.header != nullptr) != (cfg.wire && b.first_frame == 1)) { std::fprintf(stderr, "header on the wrong batch\n"); std::exit(1); }
-      if (b.header && dump) {
+      if (b.header && dump && files) {
         FILE* f_h = std::fopen((prefix + ".hdr").c_str(), "wb");
         if (f_h) { std::fwrite(b.header, sizeof(*b.header), 1, f_h); std::fclose(f_h); }
       }

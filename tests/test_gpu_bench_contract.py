@@ -103,9 +103,10 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
 def test_bench_halo_check_failure_is_collective():
     """A halo that does not arrive intact must end EVERY rank non-zero (a one-sided exit would leave the others in the next
     barrier until the launcher times out), naming the failing rank."""
-    env = dict(os.environ, SVC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SVC_BENCH_CORRUPT_HALO="1")
+    env = dict(os.environ, SVC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    # bench.py itself carries no fault hook: tests/helpers/bench_corrupt_halo.py wraps its halo transport and runs its main()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "9", "--steps", "2",
+                        "--master-port", "29519", os.path.join(ROOT, "tests", "helpers", "bench_corrupt_halo.py"), "--gpus", "2", "--frames", "9", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0
     assert "halo self-check failed on rank(s) [1]" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

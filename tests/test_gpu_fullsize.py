@@ -105,6 +105,49 @@ def test_bench_driver_on_one_shard_of_eight(native, encoded):
     drv.close()
 
 
+def test_all_eight_ranks_of_config_4_at_full_size(native, encoded):
+    """BASELINE config 4 (the 300-frame 1080p clip over 8 ranks) with EVERY rank run at full size, one after the other on
+    this GPU: rank 0 (no halo, 37 pairs from 38 frames), ranks 1-3 (38 frames, 38 pairs), ranks 4-7 (37 / 37) -- each with
+    the halo handed over through the transport hook as its predecessor would send it; the concatenation of the ranks'
+    outputs is the unsharded clip, every buffer bit for bit, and the shard plan tiles the clip without gap or overlap."""
+    import ctypes as C
+    cfg, ref = encoded
+    dev = torch.device("cuda")
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    world, done, next_frame = 8, 0, 0
+    for r in range(world):
+        first, cnt, pairs, first_encoded = clipmod.plan_shard(cfg.frames, world, r)
+        assert first == next_frame and cnt == (38 if r < 4 else 37) and pairs == (cnt - 1 if r == 0 else cnt)
+        next_frame += cnt
+        drv = clipmod.Clip(cfg, cfg.frames, rank=r, world=world, schedule=clipmod.PIPELINED)
+        assert bool(drv.info.needs_halo) == (r > 0)
+        drv.load_frames(torch.stack(ref.frames_bgr[first:first + cnt]).contiguous())
+        calls = []
+
+        def transport(send, recv, nbytes, stream, first=first, calls=calls):
+            calls.append(nbytes)
+            if first > 0:  # what rank r - 1 sends: the pyramid of clip frame first - 1 (slot = frame + 1)
+                assert hip.hipMemcpyAsync(recv, ref.pyr.data_ptr() + first * ref.stride, nbytes, 3, stream) == 0
+        drv.set_halo_transport(transport)
+        for _ in range(4):
+            drv.step()
+        drv.sync()
+        assert calls == [ref.stride] * 4
+        g0 = first_encoded - 1
+        assert g0 == done
+        out = drv.outputs(device=dev)
+        for k, want in (("mv", ref.mv), ("min_mad", ref.mad), ("inlier_mask", ref.mask), ("inlier_count", ref.count),
+                        ("block_types", ref.types)):
+            assert torch.equal(out[k], want[g0:g0 + pairs]), (r, k)
+        assert out["global_motion"].cpu().numpy().tobytes() == ref.gm[g0:g0 + pairs].cpu().numpy().tobytes(), r
+        assert out["rmse"].cpu().numpy().tobytes() == ref.rmse[g0:g0 + pairs].cpu().numpy().tobytes(), r
+        assert torch.equal(drv.read("coeffs", device=dev).view(pairs, *ref.coeffs.shape[1:]), ref.coeffs[g0:g0 + pairs]), r
+        done += pairs
+        drv.close()
+    assert done == cfg.frames - 1 and next_frame == cfg.frames
+
+
 def test_two_kernels_agree_on_every_pair(native, encoded):
     """The fused lane-per-block kernel and the per-level LDS-staged kernel are independent
     implementations; on all 299 x 8160 blocks they must give identical MVs and min-MADs."""
