@@ -364,7 +364,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     hbma_flags = hbma_flags_of(args)
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
              (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0)
-    enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule, graph=args.graph,
+    enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
                        lat_depth=args.lat_depth, tuning=tuning)
     info = enc.info
@@ -424,7 +424,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     # `stride`-th step of the timed region, which is what the per-kernel averages below are taken over
     stride = 1 if args.steps < 8 else args.time_every
     for k in range(args.steps):
-        enc.step(timed=(not args.graph) and k % stride == 0)
+        enc.step(timed=k % stride == 0)
     enc.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -482,8 +482,6 @@ def main() -> None:
     ap.add_argument("--schedule", choices=("pipelined", "serial"), default="pipelined",
                     help="pipelined: software pipeline over consecutive steps (HBM-bound kernels back to back on one stream, RANSAC + "
                          "segmentation of the previous step beside them, halo in flight meanwhile); serial: one stream, stages back to back")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the steady-state iteration from a captured hipGraph (no per-kernel events, so no roofline object)")
     ap.add_argument("--scaling", choices=("both", "strong", "weak"), default="both",
                     help="N > 1: which shardings to measure (default: strong = the BASELINE config 4/5 workload, then weak)")
     ap.add_argument("--no-segmentation", action="store_true",
@@ -614,7 +612,7 @@ def main() -> None:
                 "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-4) back to back on one stream; "
                              "RANSAC+segmentation(s-2) beside them for up to two iterations, consecutive steps on two alternating streams (forked behind the "
                              "motion search when a whole long clip is on the GPU, at the start of the iteration on shards); halo(s) on its own stream" if args.schedule == "pipelined"
-                             else "one stream, stages back to back") + ("; steady-state iteration replayed from a hipGraph" if args.graph else ""),
+                             else "one stream, stages back to back"),
                 "driver": "svc::ClipEncoder (C++, include/svc/clip_encoder.hpp)",
                 "parallelism": f"frame-sharded x{world}" + (f", halo = 1 pyramid/rank/step via {r['halo']}" if world > 1 else ""),
             },

@@ -2,6 +2,9 @@
 // PRODUCT-SIDE ADAPTER, NOT AN ORACLE (see compat/opencv2/core/mat.hpp).  Arithmetic goes to include/svc_hip.h; what
 // stays on the host is allocation, copies, interleaving and type conversion of pixel data.
 #include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <string>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +29,32 @@ void Abi(int rc, const char* where) {
   if (rc != SVC_OK) Fail(where, svc_hip_last_error());
 }
 
+namespace {
+struct Profile {
+  bool on = std::getenv("SVC_COMPAT_PROFILE") != nullptr;
+  std::mutex mu;
+  std::map<std::string, std::pair<double, uint64_t>> rows;
+  ~Profile() {
+    if (!on || rows.empty()) return;
+    std::fprintf(stderr, "svc opencv-compat profile (wall ms summed over calls):\n");
+    for (auto& kv : rows) std::fprintf(stderr, "  %-28s %10.2f ms  %8llu calls\n", kv.first.c_str(), kv.second.first * 1e3, (unsigned long long)kv.second.second);
+  }
+};
+Profile& Prof() { static Profile p; return p; }
+double Now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+Timed::Timed(const char* n) : name(n), t0(Prof().on ? Now() : 0.0) {}
+Timed::~Timed() {
+  Profile& p = Prof();
+  if (!p.on) return;
+  const double dt = Now() - t0;
+  std::lock_guard<std::mutex> lock(p.mu);
+  auto& r = p.rows[name];
+  r.first += dt;
+  r.second += 1;
+}
+
 Mat Continuous(const Mat& m) {
   m.sync();
   return m.isContinuous() ? m : m.clone();
@@ -48,6 +77,7 @@ Buffer::~Buffer() { std::free(base); }  // cv::dct calls still collected die wit
 // Executes the collected cv::dct calls of one allocation: one svc_hip_dct_tiles_host per tile shape (the reference
 // issues a single shape per plane).  The regular full grid -- what libs/encoder.cpp:330-337 produces -- needs no list.
 void Flush(Buffer& b) {
+  Timed timed("cv::dct (flush: GPU)");
   std::vector<DeferredDct> todo;
   todo.swap(b.pending);  // first: anything below that touches a Mat over this buffer must not recurse
   if (CV_MAT_DEPTH(b.type) != CV_32F || CV_MAT_CN(b.type) != 1) Fail("cv::dct", "only single-channel 32-bit float matrices");
@@ -94,6 +124,7 @@ Mat Mat::clone() const {
 }
 
 void Mat::copyTo(Mat& dst) const {
+  detail::Timed timed("Mat::copyTo / clone");
   sync();
   if (empty()) { dst.release(); return; }
   dst.create(rows, cols, type());
@@ -139,6 +170,7 @@ template <typename S> void ConvertFrom(const Mat& src, Mat& dst, double a, doubl
 // libs/encoder.cpp:638: 8-bit B,G,R -> 32-bit float, the transform's input.  A change of representation (exact), done
 // on the host where both matrices live.
 void Mat::convertTo(Mat& dst, int rtype, double alpha, double beta) const {
+  detail::Timed timed("Mat::convertTo");
   sync();
   if (empty()) { dst.release(); return; }
   const int dtype = CV_MAKETYPE(rtype < 0 ? depth() : CV_MAT_DEPTH(rtype), channels());
@@ -200,6 +232,7 @@ void swap(Mat& a, Mat& b) { std::swap(a, b); }
 
 // ---- core functions --------------------------------------------------------------------------------------------------
 void copyMakeBorder(const Mat& src, Mat& dst, int top, int bottom, int left, int right, int borderType, const Scalar& value) {
+  detail::Timed timed("cv::copyMakeBorder");
   if (borderType != BORDER_CONSTANT) detail::Fail("cv::copyMakeBorder", "only BORDER_CONSTANT (libs/encoder.cpp:447-448)");
   if (top < 0 || bottom < 0 || left < 0 || right < 0 || src.empty()) detail::Fail("cv::copyMakeBorder", "bad arguments");
   src.sync();
@@ -219,6 +252,7 @@ void copyMakeBorder(const Mat& src, Mat& dst, int top, int bottom, int left, int
 }
 
 void extractChannel(const Mat& src, Mat& dst, int coi) {
+  detail::Timed timed("cv::extractChannel");
   if (src.empty() || coi < 0 || coi >= src.channels()) detail::Fail("cv::extractChannel", "bad channel index");
   src.sync();
   const size_t e1 = src.elemSize1(), es = src.elemSize();
@@ -238,6 +272,7 @@ void extractChannel(const Mat& src, Mat& dst, int coi) {
 }
 
 void detail::SplitInto(const Mat& src, Mat* const* planes, int n) {
+  Timed timed("cv::split");
   if (src.empty() || n != src.channels()) Fail("cv::split", "plane count does not match the channel count");
   src.sync();
   const int cn = src.channels();
@@ -301,6 +336,7 @@ RNG& theRNG() {
 void setRNGSeed(int seed) { theRNG() = RNG((uint64_t)(unsigned)seed); }
 
 double kmeans(const Mat& data, int K, Mat& bestLabels, TermCriteria criteria, int attempts, int flags) {
+  detail::Timed timed("cv::kmeans (GPU)");
   if (flags != KMEANS_PP_CENTERS) detail::Fail("cv::kmeans", "only KMEANS_PP_CENTERS (libs/encoder.cpp:576)");
   if (data.empty() || data.depth() != CV_32F) detail::Fail("cv::kmeans", "data must be 32-bit float");
   const int dims = data.cols * data.channels();

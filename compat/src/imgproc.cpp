@@ -9,6 +9,7 @@
 namespace cv {
 
 void cvtColor(const Mat& src, Mat& dst, int code) {
+  detail::Timed timed("cv::cvtColor (GPU)");
   if (code != COLOR_BGR2YUV) detail::Fail("cv::cvtColor", "only COLOR_BGR2YUV (libs/encoder.cpp:449, :468)");
   if (src.empty() || src.type() != CV_8UC3) detail::Fail("cv::cvtColor", "COLOR_BGR2YUV takes an 8-bit 3-channel matrix");
   const Mat in = detail::Continuous(src);
@@ -26,6 +27,7 @@ void cvtColor(const Mat& src, Mat& dst, int code) {
 }
 
 void detail::BuildPyramidInto(const Mat& src, Mat* const* levels, int maxlevel) {
+  Timed timed("cv::buildPyramid (GPU)");
   if (src.empty() || src.type() != CV_8UC1) Fail("cv::buildPyramid", "only 8-bit single-channel matrices (libs/encoder.cpp:451)");
   if (maxlevel < 0 || maxlevel > 15) Fail("cv::buildPyramid", "maxlevel out of range");
   const uint32_t f = 1u << maxlevel;
@@ -74,6 +76,7 @@ Mat getStructuringElement(int shape, Size ksize, Point) {
 }
 
 static void Morph(const Mat& src, Mat& dst, uint32_t op, const Mat& kernel, const char* who) {
+  detail::Timed timed("cv::morphologyEx (GPU)");
   if (src.empty() || src.type() != CV_8UC1) detail::Fail(who, "only 8-bit single-channel matrices (libs/encoder.cpp:524-527)");
   if (kernel.empty() || kernel.type() != CV_8UC1) detail::Fail(who, "the structuring element must be an 8-bit matrix");
   kernel.sync();
@@ -99,6 +102,7 @@ void erode(const Mat& src, Mat& dst, const Mat& kernel) { Morph(src, dst, SVC_MO
 void dilate(const Mat& src, Mat& dst, const Mat& kernel) { Morph(src, dst, SVC_MORPH_DILATE, kernel, "cv::dilate"); }
 
 int connectedComponents(const Mat& image, Mat& labels, int connectivity, int ltype, int) {
+  detail::Timed timed("cv::connectedComponents (GPU)");
   if (image.empty() || image.type() != CV_8UC1) detail::Fail("cv::connectedComponents", "only 8-bit single-channel images");
   if (ltype != CV_32S) detail::Fail("cv::connectedComponents", "only CV_32S labels (libs/encoder.cpp:609)");
   const Mat in = detail::Continuous(image);

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <vector>
 
+#include "internal.hpp"
 #include "opencv2/videoio.hpp"
 
 namespace cv {
@@ -79,6 +80,7 @@ double VideoCapture::get(int propId) const {
 }
 
 bool VideoCapture::read(Mat& image) {
+  detail::Timed timed("VideoCapture::read");
   if (!f_) { image.release(); return false; }
   if (ppm_) {
     int w = 0, h = 0;

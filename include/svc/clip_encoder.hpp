@@ -64,10 +64,9 @@ struct ClipEncoderConfig {
   uint32_t clip_frames = 0;   // frames of the WHOLE clip
   uint32_t rank = 0, world = 1;
   Schedule schedule = Schedule::kPipelined;
-  bool graph = false;         // replay the steady-state iteration from a captured hipGraph
   // Tuning (the A/B switches of the measurements under profiles/; results never depend on them)
   uint32_t hbma_flags = SVC_HBMA_AUTO;  // kernel choice of the motion search, SVC_HBMA_*
-  uint32_t lat_depth = 0;               // pipelined: iterations RANSAC + segmentation get, 1..3; 0 = 2 (1 with graph)
+  uint32_t lat_depth = 0;               // pipelined: iterations RANSAC + segmentation get, 1..3; 0 = 2
   bool standalone_shapes = false;       // pipelined: keep the latency-bound stages' stand-alone launch shapes
   bool segment_fork = false;            // pipelined: let the segmentation fork its heavy attempts to a side stream
   bool inline_rmse = false;             // pipelined: keep RANSAC's in-order RMSE sum inside its kernel instead of beside the segmentation

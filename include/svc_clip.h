@@ -47,11 +47,12 @@ typedef struct svc_clip_config {
   uint32_t clip_frames; /* frames of the whole clip */
   uint32_t rank, world; /* this handle holds shard `rank` of `world` */
   uint32_t schedule;    /* SVC_CLIP_SERIAL / SVC_CLIP_PIPELINED */
-  uint32_t graph;       /* 1: replay the steady-state iteration from a captured hipGraph */
+  uint32_t reserved0;   /* 0 (was `graph` through round 3: replaying the iteration from a hipGraph measured slower than the eager
+                           pipelined schedule on every workload, profiles/r04_ab_graph.txt, and was removed) */
   /* Tuning; all zero = the defaults.  These are the A/B switches of the measurements under profiles/ -- they change
    * launch shapes and kernel choice, never results. */
   uint32_t hbma_flags;  /* SVC_HBMA_* passed to svc_hip_hbma_pairs (0 = SVC_HBMA_AUTO) */
-  uint32_t lat_depth;   /* pipelined: iterations RANSAC + segmentation get to finish, 1..3 (0 = 2; ignored with graph) */
+  uint32_t lat_depth;   /* pipelined: iterations RANSAC + segmentation get to finish, 1..3 (0 = 2) */
   uint32_t tuning;      /* SVC_CLIP_TUNE_* bits */
 } svc_clip_config;
 

@@ -32,7 +32,7 @@ class ClipConfig(C.Structure):
     _fields_ = [("struct_size", _u32), ("width", _u32), ("height", _u32), ("levels", _u32), ("mv_block", _u32), ("search_range", _u32),
                 ("dct_block_w", _u32), ("dct_block_h", _u32), ("fg_step", _u32), ("bg_step", _u32), ("wire", _u32),
                 ("segmentation", _u32), ("seed", _u64), ("ransac", RansacParams), ("segment", SegmentParams),
-                ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("graph", _u32),
+                ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("reserved0", _u32),
                 ("hbma_flags", _u32), ("lat_depth", _u32), ("tuning", _u32)]
 
 
@@ -141,7 +141,7 @@ class Clip:
     """One rank's shard of a clip, resident in HBM, driven by svc::ClipEncoder."""
 
     def __init__(self, cfg: CodecConfig, clip_frames: int, rank: int = 0, world: int = 1, schedule: int = PIPELINED,
-                 graph: bool = False, segmentation: bool = True, wire: bool = False, seed: Optional[int] = None,
+                 segmentation: bool = True, wire: bool = False, seed: Optional[int] = None,
                  ransac: Optional[dict] = None, segment: Optional[dict] = None, dct_block: Optional[Tuple[int, int]] = None,
                  hbma_flags: int = 0, lat_depth: int = 0, tuning: int = 0):
         self.cfg = cfg
@@ -153,7 +153,7 @@ class Clip:
         self.config = ClipConfig(C.sizeof(ClipConfig), cfg.width, cfg.height, cfg.levels, cfg.mv_block, cfg.search_range, bw, bh,
                                  cfg.fg_step, cfg.bg_step, int(wire), int(segmentation),
                                  cfg.seed if seed is None else seed, RansacParams(**r), SegmentParams(**s),
-                                 clip_frames, rank, world, schedule, int(graph), hbma_flags, lat_depth, tuning)
+                                 clip_frames, rank, world, schedule, 0, hbma_flags, lat_depth, tuning)
         self._h = _vp()
         self._cb = None  # keeps the ctypes callback alive
         _check(load().svc_clip_create(C.byref(self.config), C.byref(self._h)))

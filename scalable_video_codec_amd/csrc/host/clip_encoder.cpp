@@ -80,7 +80,7 @@ struct ClipEncoder::Impl {
   DevBuf<uint32_t> count[kSets], types[kSets], samples;
   hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {}, e_rfork = nullptr, e_rmse[kSets] = {};
   bool halo_recorded[2] = {false, false}, join_pending[kSets] = {}, rmse_pending[kSets] = {};
-  bool defer_rmse = false;  // pipelined, no graph, large fields: RANSAC leaves its in-order RMSE sum to a later kernel (nothing downstream
+  bool defer_rmse = false;  // pipelined, large fields: RANSAC leaves its in-order RMSE sum to a later kernel (nothing downstream
                             // needs it): on sC beside the segmentation at world 1, on the latency stream behind it on a multi-rank run
   uint64_t iter = 0, fork_iter[kSets] = {};
   void* comm = nullptr;
@@ -98,17 +98,10 @@ struct ClipEncoder::Impl {
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
   std::vector<hipEvent_t> event_pool;
-  // graph of the steady-state block, one per buffer parity
-  hipGraphExec_t gexec[kSets] = {};
-  hipGraph_t graph[kSets] = {};
 
   ~Impl() {
     for (hipStream_t s : {sM, sL[0], sL[1], sL[2], sC})
       if (s) (void)hipStreamSynchronize(s);
-    for (int b = 0; b < kSets; ++b) {
-      if (gexec[b]) (void)hipGraphExecDestroy(gexec[b]);
-      if (graph[b]) (void)hipGraphDestroy(graph[b]);
-    }
     for (auto& v : timed)
       for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
@@ -262,15 +255,6 @@ struct ClipEncoder::Impl {
     join_pending[Set(l)] = false;
   }
 
-  // The steady-state iteration as ONE fork/join block (what the hipGraph option captures; depth 1): motion search of
-  // step h on the main stream with the transform of step h - 2 behind it, RANSAC + segmentation of step h - 1 beside them.
-  void Block(uint64_t h, uint64_t l, uint64_t d) {
-    Hbma(h, sM, false);
-    ForkLat(l, false);
-    Transform(d, sM, false);
-    JoinLat(l);
-  }
-
   // One iteration of the software pipeline: luma + pyramid of step s, motion search of s - 1, fork of RANSAC +
   // segmentation of s - 2, transform of s - 2 - depth.  Buffer hazards (a step's small buffers are set s % (depth + 2)):
   //   lat(l) reads mv[l], writes mask / types[l] on stream l % depth, and must be done before transform(l) reads types[l]:
@@ -283,8 +267,7 @@ struct ClipEncoder::Impl {
     const uint64_t h = n_hbma, l = n_lat, d = n_dct;
     // draining (no new step) joins at once; otherwise the transform of step d waits until lat(d) has had its iterations
     const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Set(d)] >= (uint64_t)depth);
-    const bool replay = c.graph && do_hbma && do_lat && do_dct && !timing;
-    if (do_lat && !replay) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
+    if (do_lat) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
     if (new_step) {
       const uint64_t s = n_luma;
       const int b = Par(s);
@@ -296,31 +279,10 @@ struct ClipEncoder::Impl {
     }
     if (do_hbma && c.world > 1)  // the halo of step h has had a whole iteration to arrive
       Hip(hipStreamWaitEvent(sM, e_halo[Par(h)], 0), "hipStreamWaitEvent");
-    if (replay) {
-      JoinLat(d);  // a lat forked by an eager iteration (fill, timed step) is picked up outside the graph
-      const int b = Set(h);
-      if (!gexec[b]) {
-        Hip(hipStreamBeginCapture(sM, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-        try {
-          Block(h, l, d);
-        } catch (...) {
-          hipGraph_t dead = nullptr;
-          (void)hipStreamEndCapture(sM, &dead);
-          if (dead) (void)hipGraphDestroy(dead);
-          throw;
-        }
-        Hip(hipStreamEndCapture(sM, &graph[b]), "hipStreamEndCapture");
-        Hip(hipGraphInstantiate(&gexec[b], graph[b], nullptr, nullptr, 0), "hipGraphInstantiate");
-      } else {
-        fork_iter[Set(l)] = iter;  // what ForkLat records when the block is captured
-      }
-      Hip(hipGraphLaunch(gexec[b], sM), "hipGraphLaunch");
-    } else {
-      if (do_hbma) Hbma(h, sM, timing);
-      if (do_dct) {
-        JoinLat(d);
-        Transform(d, sM, timing);
-      }
+    if (do_hbma) Hbma(h, sM, timing);
+    if (do_dct) {
+      JoinLat(d);
+      Transform(d, sM, timing);
     }
     n_hbma += do_hbma; n_lat += do_lat; n_dct += do_dct;
     ++iter;
@@ -385,12 +347,11 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   // 0.373, C3 19 frames 0.236 / 0.208 / 0.207).  ClipEncoderConfig::lat_depth overrides (A/B runs).
   const bool pipelined = c.schedule == Schedule::kPipelined;
   m.depth = 1;
-  if (pipelined && !c.graph) m.depth = c.lat_depth ? (int)c.lat_depth : 2;
-  m.nsets = !pipelined ? 1 : c.graph ? 4 : m.depth + 2;  // hipGraph replay: the set must also fix the pyramid parity
-  // not while capturing: a fork out of a stream that is itself a fork of the capture's origin breaks hipStreamEndCapture
-  // and only where the chain is long enough to matter: 0.13 ms at 4K against 0.03 ms at 1080p, where it measures neutral
+  if (pipelined) m.depth = c.lat_depth ? (int)c.lat_depth : 2;
+  m.nsets = !pipelined ? 1 : m.depth + 2;
+  // only where the chain is long enough to matter: 0.13 ms at 4K against 0.03 ms at 1080p, where it measures neutral
   // (profiles/r03_ab_defer_rmse.txt)
-  m.defer_rmse = pipelined && !c.graph && !c.inline_rmse && m.blocks > 8192;
+  m.defer_rmse = pipelined && !c.inline_rmse && m.blocks > 8192;
   Hip(hipStreamCreateWithFlags(&m.sM, hipStreamNonBlocking), "hipStreamCreate");
   Hip(hipStreamCreateWithFlags(&m.sC, hipStreamNonBlocking), "hipStreamCreate");
   if (m.defer_rmse) {
@@ -581,7 +542,6 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.seed = k->seed; c.ransac = k->ransac; c.segment = k->segment; c.clip_frames = k->clip_frames;
     c.rank = k->rank; c.world = k->world;
     c.schedule = k->schedule == SVC_CLIP_SERIAL ? svc::Schedule::kSerial : svc::Schedule::kPipelined;
-    c.graph = k->graph != 0;
     c.hbma_flags = k->hbma_flags; c.lat_depth = k->lat_depth;
     c.standalone_shapes = (k->tuning & SVC_CLIP_TUNE_STANDALONE_SHAPES) != 0;
     c.segment_fork = (k->tuning & SVC_CLIP_TUNE_SEGMENT_FORK) != 0;

@@ -1,5 +1,5 @@
 """svc::ClipEncoder (include/svc/clip_encoder.hpp) through its C handle API: the C++ driver of one rank's
-shard.  Checked here: every schedule (serial, pipelined, pipelined + hipGraph) gives the bytes of the
+shard.  Checked here: every schedule (serial, pipelined at every depth) gives the bytes of the
 stage-by-stage C-ABI calls; a clip cut into shards -- the halo moved by the encoder's own transport hook --
 encodes to exactly the unsharded clip; the RCCL entry points bind and move bytes."""
 import ctypes as C
@@ -57,30 +57,28 @@ def _assert_same(out, ref, coeffs=None):
         assert torch.equal(coeffs.view(ref.coeffs.shape), ref.coeffs.cpu())
 
 
-@pytest.mark.parametrize("schedule,graph,steps", [(clipmod.SERIAL, False, 1), (clipmod.SERIAL, False, 3),
-                                                   (clipmod.PIPELINED, False, 1), (clipmod.PIPELINED, False, 5),
-                                                   (clipmod.PIPELINED, True, 7)])
-def test_schedules_equal_stagewise_calls(native, schedule, graph, steps):
+@pytest.mark.parametrize("schedule,steps", [(clipmod.SERIAL, 1), (clipmod.SERIAL, 3), (clipmod.PIPELINED, 1), (clipmod.PIPELINED, 5),
+                                            (clipmod.PIPELINED, 7)])
+def test_schedules_equal_stagewise_calls(native, schedule, steps):
     dev = torch.device("cuda")
     n = CFG.frames
     frames = _frames(CFG, n, dev)
     ref = _reference_outputs(native, CFG, frames)
-    enc = clipmod.Clip(CFG, n, schedule=schedule, graph=graph)
+    enc = clipmod.Clip(CFG, n, schedule=schedule)
     assert (enc.info.frames, enc.info.pairs, enc.info.first_encoded, enc.info.needs_halo) == (n, n - 1, 1, 0)
     enc.load_frames(frames)
     for s in range(steps):
-        enc.step(timed=not graph)
+        enc.step(timed=True)
     enc.sync()
     _assert_same(enc.outputs(), ref, enc.read("coeffs"))
-    if not graph:
-        t = enc.stage_times_ms()
-        assert set(t) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
-        assert all(ms > 0 and launches == steps for ms, launches in t.values())
+    t = enc.stage_times_ms()
+    assert set(t) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
+    assert all(ms > 0 and launches == steps for ms, launches in t.values())
     enc.close()
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_pipeline_state_machine_fuzz(native, graph):
+@pytest.mark.parametrize("lat_depth", [0, 1, 3])
+def test_pipeline_state_machine_fuzz(native, lat_depth):
     """Bursts of steps of random length, random timing flags, syncs and output reads at random points, a halo that
     arrives through the transport hook on every step: whatever the interleaving, the newest finished step's outputs are
     the clip's (the double-buffered sets, the deferred join of the second stream and the drain must never mix steps)."""
@@ -95,7 +93,7 @@ def test_pipeline_state_machine_fuzz(native, graph):
     want_coeffs = whole.read("coeffs")
     pyr = whole.read("pyramids", device=dev)
     first, cnt, pairs, first_encoded = clipmod.plan_shard(n, 2, 1)
-    enc = clipmod.Clip(CFG, n, rank=1, world=2, graph=graph)
+    enc = clipmod.Clip(CFG, n, rank=1, world=2, lat_depth=lat_depth)
     enc.load_frames(frames[first:first + cnt].contiguous())
     stride = enc.info.pyramid_stride
     enc.set_halo_transport(lambda send, recv, nbytes, stream: _hip_memcpy_async(recv, pyr.data_ptr() + first * stride, nbytes, stream))
@@ -104,7 +102,7 @@ def test_pipeline_state_machine_fuzz(native, graph):
     per = 3 * enc.info.padded_w * enc.info.padded_h
     for burst in range(12):
         for _ in range(int(rng.integers(1, 8))):
-            enc.step(timed=bool(rng.integers(0, 2)) and not graph)
+            enc.step(timed=bool(rng.integers(0, 2)))
         if rng.integers(0, 3) == 0:
             enc.flush()
         out = enc.outputs()  # syncs
@@ -116,9 +114,9 @@ def test_pipeline_state_machine_fuzz(native, graph):
     enc.close()
 
 
-@pytest.mark.parametrize("graph,lat_depth", [(False, 0), (False, 1), (False, 3), (True, 0)])
+@pytest.mark.parametrize("lat_depth", [0, 1, 3])
 @pytest.mark.parametrize("steps_after", [1, 2, 3, 4, 5, 6])
-def test_buffer_sets_never_serve_stale_steps(native, graph, lat_depth, steps_after):
+def test_buffer_sets_never_serve_stale_steps(native, lat_depth, steps_after):
     """The pipelined schedule keeps the small per-step buffers in depth + 2 sets and the pyramids in two; re-encoding the
     same clip leaves every set with identical bytes after a few steps, so a missing join (the transform of step d reading
     region ids before RANSAC + segmentation of d have run, the motion search of step h overwriting a field its reader has
@@ -139,7 +137,7 @@ def test_buffer_sets_never_serve_stale_steps(native, graph, lat_depth, steps_aft
         want[name] = (s.outputs(), s.read("coeffs"))
         s.close()
     assert not torch.equal(want["a"][0]["mv"], want["b"][0]["mv"]) and not torch.equal(want["a"][0]["block_types"], want["b"][0]["block_types"])
-    enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, graph=graph, lat_depth=lat_depth)
+    enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, lat_depth=lat_depth)
     enc.load_frames(fa)
     for _ in range(7):
         enc.step()

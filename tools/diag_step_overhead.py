@@ -16,7 +16,7 @@ pw, ph = cfg.padded
 for n in sizes:
     src = synth.SynthClip(cfg.width, cfg.height, n, cfg.seed, device=dev)
     frames = torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(n)]).contiguous()
-    for label, kw, timed in (("timed", {}, True), ("untimed", {}, False), ("graph", {"graph": True}, False),
+    for label, kw, timed in (("timed", {}, True), ("untimed", {}, False),
                              ("serial timed", {"schedule": clipmod.SERIAL}, True), ("serial untimed", {"schedule": clipmod.SERIAL}, False)):
         enc = clipmod.Clip(cfg, n, **kw)
         enc.load_frames(frames)

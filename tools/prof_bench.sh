@@ -5,7 +5,7 @@ set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$(dirname "$out")"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "${out}_raw" -- python3 bench.py --no-cpu-baseline --no-hbm-probe "$@" > "${out}_bench.json" 2> "${out}_bench.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "${out}_raw" -- python3 bench.py --no-cpu-baseline --no-hbm-probe --no-end-to-end "$@" > "${out}_bench.json" 2> "${out}_bench.err"
 rc=$?
 echo "rocprofv3 exit $rc"
 python3 tools/summarize_rocprof.py "${out}_raw" "${out}_kernel_stats.csv" "bench.py $*" > /dev/null
