@@ -65,14 +65,58 @@ static size_t ElemSize(int type) {
   return sz[CV_MAT_DEPTH(type)] * (size_t)CV_MAT_CN(type);
 }
 
+// Large matrices come and go once per frame in the reference's loop (three 8 MB clones, a 6 MB frame per read, the
+// k-means inputs): malloc hands such sizes to mmap / munmap, and a fresh mapping costs a page fault per 4 KB on first
+// touch (2.2 ms per 8 MB clone measured, profiles/r04_ref_encoder_profile_before_pool.txt).  Freed blocks of 1 MB and
+// more are therefore kept, by exact size, for the next matrix of that size (at most 8 per size, 512 MB in all).
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::map<size_t, std::vector<uchar*>> free_by_size;
+  size_t held = 0;
+  static constexpr size_t kMinBytes = 1u << 20, kMaxHeld = 512u << 20, kPerSize = 8;
+  uchar* Take(size_t bytes) {
+    if (bytes >= kMinBytes) {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = free_by_size.find(bytes);
+      if (it != free_by_size.end() && !it->second.empty()) {
+        uchar* p = it->second.back();
+        it->second.pop_back();
+        held -= bytes;
+        return p;
+      }
+    }
+    return static_cast<uchar*>(std::aligned_alloc(64, bytes));
+  }
+  void Give(uchar* p, size_t bytes) {
+    if (bytes >= kMinBytes) {
+      std::lock_guard<std::mutex> lock(mu);
+      auto& v = free_by_size[bytes];
+      if (v.size() < kPerSize && held + bytes <= kMaxHeld) {
+        v.push_back(p);
+        held += bytes;
+        return;
+      }
+    }
+    std::free(p);
+  }
+  ~Pool() {
+    for (auto& kv : free_by_size)
+      for (uchar* p : kv.second) std::free(p);
+  }
+};
+Pool& ThePool() { static Pool* p = new Pool; return *p; }  // never destroyed: matrices with static storage may outlive it
+size_t Rounded(size_t bytes) { return (bytes + 63) / 64 * 64 + 64; }
+}  // namespace
+
 Buffer::Buffer(int rows_, int cols_, int type_) : rows(rows_), cols(cols_), type(type_) {
   step = (size_t)cols_ * ElemSize(type_);
   bytes = step * (size_t)rows_;
-  base = static_cast<uchar*>(std::aligned_alloc(64, (bytes + 63) / 64 * 64 + 64));
+  base = ThePool().Take(Rounded(bytes));
   if (!base) Fail("cv::Mat::create", "out of memory");
 }
 
-Buffer::~Buffer() { std::free(base); }  // cv::dct calls still collected die with the data nobody looked at
+Buffer::~Buffer() { ThePool().Give(base, Rounded(bytes)); }  // cv::dct calls still collected die with the data nobody looked at
 
 // Executes the collected cv::dct calls of one allocation: one svc_hip_dct_tiles_host per tile shape (the reference
 // issues a single shape per plane).  The regular full grid -- what libs/encoder.cpp:330-337 produces -- needs no list.

@@ -152,18 +152,27 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int kRowPitch = 144;                  // 16 f64 + 16 B pad
 constexpr int kSlab8 = 8 * kRowPitch;           // 1152 B  (= 128 mod 256)
 constexpr int kSlab16 = 16 * kRowPitch + 128;   // 2432 B  (= 128 mod 256)
+// WIRE: once the last channel has left it, a wave's slabs (adjacent in LDS) become ONE linear staging buffer for the
+// records of the wave's 64 / N segment columns (8 x 2 x 772 = 12 352 B for N = 8, 4 x 3076 = 12 304 B for N = 16) plus up
+// to 12 bytes of alignment slack -- so the slab pitch grows to cover its share of that, still = 128 mod 256
+constexpr int kSlabWire8 = 1664, kSlabWire16 = 3200;
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-// WIRE: instead of three coefficient planes the kernel emits the reference's serialised
-// records (libs/encoder.cpp:222-269: u32 block type, then per channel N rows of N floats) --
-// the column-pass results take one more trip through the (now free) LDS slab as f32 so that
-// every lane stores 16-byte runs that are contiguous across lanes (128 B per segment column
-// and instruction for N = 8, 256 B for N = 16).  No extra HBM traffic versus planar output.
+// WIRE: instead of three coefficient planes the kernel emits the reference's serialised records (libs/encoder.cpp:222-269:
+// u32 block type, then per channel N rows of N floats).  A record is 4 + 12 N^2 bytes -- 772 or 3076: no run of it is aligned
+// to a cache line, and stores that leave as pieces of lines cost the transform a third of its time (2.20 ms against 1.6 ms
+// with line-aligned 768-byte pseudo-records at C3, profiles/r04_ab_wire_aligned_experiment.txt; aligning only the 16-byte
+// stores is slower still, r04_ab_wire_aligned_chunks.txt).  So a lane keeps the f32 results of all three channels in
+// registers; when the last channel is through, the wave lays the COMPLETE records of its 64 / N segment columns -- one
+// contiguous 12 KB stretch of the stream -- into its slabs in stream order and writes them out as 16-byte chunks at
+// consecutive aligned addresses, 1 KiB per instruction: whole lines except at the stretch's two ends.  A wave whose segment
+// columns do not form such a stretch (the clip's last wave, a frame boundary inside it, rows SerializeEncodedFrame does not
+// visit) stores from the registers directly.  No extra HBM traffic versus planar output.
 template <int N, bool QUANT, bool WIRE>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   constexpr int kSegPerWg = 256 / N;  // 512- and 1024-lane workgroups (longer runs per row) measured level or worse: profiles/r03_ab_dct_lanes.txt
-  constexpr int kSlab = N == 8 ? kSlab8 : kSlab16;
+  constexpr int kSlab = WIRE ? (N == 8 ? kSlabWire8 : kSlabWire16) : (N == 8 ? kSlab8 : kSlab16);
   __shared__ __attribute__((aligned(16))) uint8_t lds[kSegPerWg * kSlab];
 
   const uint32_t tid = threadIdx.x;
@@ -210,9 +219,8 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   if (WIRE) {
     const uint32_t tiles_x = a.w / N, tile0 = band * tiles_x + (N == 8 ? 2 * seg : seg);
     rec0 = a.records + (size_t)frame * a.records_stride + (size_t)tile0 * kRec;
-    if (emit && (N == 8 ? (j & 3) == 0 : j == 0))
-      *reinterpret_cast<uint32_t*>(rec0 + (N == 8 ? (j >> 2) * kRec : 0)) = t;
   }
+  float keep[WIRE ? 3 : 1][16];  // WIRE: this lane's f32 results, all channels (N = 8: row v, columns 2j, 2j + 1 at [2v], [2v + 1])
 
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -244,7 +252,6 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
       dct1d<8, double>(ca, ya);
       dct1d<8, double>(cb, yb);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + 2 * j;
-      if (WIRE) wave_lds_sync();  // every lane has read its columns: the slab becomes the f32 tile
 #pragma unroll
       for (int v = 0; v < 8; ++v) {
         float fa = (float)ya[v], fb = (float)yb[v];
@@ -252,20 +259,8 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
           const f32x2 qq = quant2_fast(f32x2{fa, fb}, step, inv_step);
           fa = qq.x; fb = qq.y;
         }
-        if (WIRE) *reinterpret_cast<float2*>(slab + v * 64 + j * 8) = make_float2(fa, fb);
+        if (WIRE) { keep[WIRE ? c : 0][2 * v] = fa; keep[WIRE ? c : 0][2 * v + 1] = fb; }
         else *reinterpret_cast<float2*>(dst + (size_t)v * a.w) = make_float2(fa, fb);
-      }
-      if (WIRE) {
-        wave_lds_sync();
-        // 32 chunks of 16 B (2 tiles x 8 rows x 2 halves), 4 per lane, lane-contiguous in the record
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = i * 8 + (int)j, q = m >> 4, tt = m & 15;
-          const float4 v4 = *reinterpret_cast<const float4*>(slab + (tt >> 1) * 64 + q * 32 + (tt & 1) * 16);
-          if (emit)
-            *reinterpret_cast<u32x4_a4*>(rec0 + q * kRec + 4 + c * 256 + tt * 16) =
-                u32x4_a4{__float_as_uint(v4.x), __float_as_uint(v4.y), __float_as_uint(v4.z), __float_as_uint(v4.w)};
-        }
       }
     } else {
       double cc[16], yy[16];
@@ -274,32 +269,77 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
         cc[y] = *reinterpret_cast<const double*>(slab + y * kRowPitch + j * 8);
       dct1d<16, double>(cc, yy);
       float* dst = plane + (size_t)y_pix * a.w + x_pix + j;
-      if (WIRE) wave_lds_sync();
 #pragma unroll
       for (int v = 0; v < 16; v += 2) {
         f32x2 f = {(float)yy[v], (float)yy[v + 1]};
         if (QUANT) f = quant2_fast(f, step, inv_step);
         if (WIRE) {
-          *reinterpret_cast<float*>(slab + v * 64 + j * 4) = f.x;
-          *reinterpret_cast<float*>(slab + (v + 1) * 64 + j * 4) = f.y;
+          keep[WIRE ? c : 0][v] = f.x;
+          keep[WIRE ? c : 0][v + 1] = f.y;
         } else {
           dst[(size_t)v * a.w] = f.x;
           dst[(size_t)(v + 1) * a.w] = f.y;
         }
       }
-      if (WIRE) {
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // 64 chunks of 16 B per tile-channel, 4 per lane
-          const int m = i * 16 + (int)j;
-          const float4 v4 = *reinterpret_cast<const float4*>(slab + m * 16);
-          if (emit)
-            *reinterpret_cast<u32x4_a4*>(rec0 + 4 + c * 1024 + m * 16) =
-                u32x4_a4{__float_as_uint(v4.x), __float_as_uint(v4.y), __float_as_uint(v4.z), __float_as_uint(v4.w)};
-        }
-      }
     }
-    wave_lds_sync();  // the slab is rewritten by the next channel
+    wave_lds_sync();  // the slab is rewritten by the next channel (WIRE: by the record staging below)
+  }
+
+  if constexpr (WIRE) {
+    constexpr uint32_t kGroupBytes = N == 8 ? 2 * kRec : kRec;  // the records of one segment column
+    constexpr uint32_t kGroups = 64 / N;                         // segment columns per wave
+    constexpr uint32_t kWaveBytes = kGroups * kGroupBytes;
+    static_assert(kGroups * (uint32_t)kSlab >= kWaveBytes + 16, "a wave's slabs hold its stretch of the stream plus alignment slack");
+    const uint32_t lane = tid & 63u, g = lane / N;
+    // the records of consecutive segment columns are consecutive in the stream (across bands as well: tile index = band *
+    // tiles_x + tile column), as long as they are in one frame and SerializeEncodedFrame visits their rows
+    const uint32_t gsc_last = gsc - g + kGroups - 1;
+    bool stretch = gsc_last < a.total_segcols;
+    if (stretch) {
+      const uint32_t bg_last = gsc_last / a.segs_per_band, bg_first = (gsc - g) / a.segs_per_band;
+      const uint32_t f_last = bg_last / a.bands_per_frame;
+      stretch = f_last == bg_first / a.bands_per_frame && bg_last - f_last * a.bands_per_frame < a.emit_bands;
+    }
+    const uint32_t q = N == 8 ? j >> 2 : 0u;        // tile of the segment column this lane's columns belong to
+    const uint32_t col_off = N == 8 ? (j & 3u) * 8u : j * 4u;  // byte offset of the lane's column(s) inside a record row
+    if (stretch) {  // wave-uniform
+      uint8_t* wave_rec = rec0 - (size_t)g * kGroupBytes;                      // the same address in every lane
+      const uint32_t delta = (uint32_t)(reinterpret_cast<uintptr_t>(wave_rec) & 15u);
+      uint8_t* wbase = lds + (sc_local - g) * kSlab + delta;                   // LDS image of the stretch: same 16-byte phase as global
+      uint8_t* mine = wbase + g * kGroupBytes + q * kRec;
+      if (N == 8 ? (j & 3u) == 0 : j == 0) *reinterpret_cast<uint32_t*>(mine) = t;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int v = 0; v < N; ++v) {
+          uint32_t* d = reinterpret_cast<uint32_t*>(mine + 4 + c * (4 * N * N) + v * (4 * N) + col_off);
+          if (N == 8) { d[0] = __float_as_uint(keep[c][2 * v]); d[1] = __float_as_uint(keep[c][2 * v + 1]); }
+          else d[0] = __float_as_uint(keep[c][v]);
+        }
+      wave_lds_sync();
+      const uint32_t head = (16u - delta) & 15u;                  // bytes up to the first 16-byte boundary (a multiple of 4)
+      const uint32_t nfull = (kWaveBytes - head) / 16u, tail = (kWaveBytes - head) % 16u;
+      for (uint32_t k = lane; k < nfull; k += 64u) {               // 1 KiB of consecutive aligned chunks per wave instruction
+        const uint32_t o = head + 16u * k;
+        *reinterpret_cast<uint4*>(wave_rec + o) = *reinterpret_cast<const uint4*>(wbase + o);
+      }
+      const uint32_t hd = head / 4u, ne = hd + tail / 4u;          // the dwords in front of the first and behind the last chunk
+      if (lane < ne) {
+        const uint32_t o = lane < hd ? 4u * lane : head + 16u * nfull + 4u * (lane - hd);
+        *reinterpret_cast<uint32_t*>(wave_rec + o) = *reinterpret_cast<const uint32_t*>(wbase + o);
+      }
+    } else if (emit) {  // no stretch: this lane's values straight from its registers
+      uint8_t* mine = rec0 + q * kRec;
+      if (N == 8 ? (j & 3u) == 0 : j == 0) *reinterpret_cast<uint32_t*>(mine) = t;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int v = 0; v < N; ++v) {
+          uint32_t* d = reinterpret_cast<uint32_t*>(mine + 4 + c * (4 * N * N) + v * (4 * N) + col_off);
+          if (N == 8) { d[0] = __float_as_uint(keep[c][2 * v]); d[1] = __float_as_uint(keep[c][2 * v + 1]); }
+          else d[0] = __float_as_uint(keep[c][v]);
+        }
+    }
   }
 }
 
