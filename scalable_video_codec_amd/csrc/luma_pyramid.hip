@@ -146,7 +146,13 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
-constexpr int kTWBgr = 128, kTHBgr = 32, kTWPlane = 512, kTHPlane = 32 /* 128 x 64 ... 512 x 32 measured: profiles/r02_ab_pyr_tile.txt */, kOff = 16;  // LDS column c <-> x = x0 - kOff + c
+#ifndef SVC_LUMA_TW
+#define SVC_LUMA_TW 128
+#endif
+#ifndef SVC_LUMA_TH
+#define SVC_LUMA_TH 32
+#endif
+constexpr int kTWBgr = SVC_LUMA_TW, kTHBgr = SVC_LUMA_TH, kTWPlane = 512, kTHPlane = 32 /* 128 x 64 ... 512 x 32 measured: profiles/r02_ab_pyr_tile.txt */, kOff = 16;  // LDS column c <-> x = x0 - kOff + c
 
 struct LumaPyr1Args {
   const uint8_t* bgr;      // FROM_BGR: interleaved frames
