@@ -72,4 +72,8 @@ C5 = CodecConfig("C5-4k-4L-dct16", 5, 3840, 2160, 64, levels=4, dct_block=16)
 # the reference's default build (SSE2 path): 4 levels, 16x16 (libs/motion.hpp:143-147)
 C3_L4 = CodecConfig("C3b-1080p-4L-dct8-quant", 6, 1920, 1080, 300, levels=4, dct_block=8)
 
-ALL = {c.name: c for c in (C1, C2, C3, C5, C3_L4)}
+# not a BASELINE configuration: PAL with the reference's default build -- a frame 16 mod 32 pixels wide, whose level-3 plane (90 wide) is
+# not a whole number of dwords: the shape the fast motion-search kernels do not take (the general per-level kernel serves it)
+X_PAL = CodecConfig("X1-pal-720x576-4L-dct8", 7, 720, 576, 300, levels=4, dct_block=8)
+
+ALL = {c.name: c for c in (C1, C2, C3, C5, C3_L4, X_PAL)}

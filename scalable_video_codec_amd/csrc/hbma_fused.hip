@@ -28,10 +28,11 @@ bool fused_supported(uint32_t levels, uint32_t w, uint32_t h, uint32_t range, ui
   const uint32_t rt = range >> (levels - 1);
   if (rt < 1 || rt > (bw == 32 ? 2u : 4u)) return false;  // 32 x 32 blocks at R_top 3 - 4 would spill (hbma_fused_kernel.hpp)
   const uint32_t tw = w >> (levels - 1), th = h >> (levels - 1), tb = bw >> (levels - 1);
-  // the top plane must hold a whole candidate grid, and its rows must be dword-aligned: the
-  // clamped top-level loads (load_row<.., true>) only leave needed bytes alone when the row
-  // width is a multiple of 4 (found by tests/test_gpu_hbma_property.py: 112 x 32, 4 levels)
-  return tw >= tb + 8 && tw >= 12 && tw % 4 == 0 && th >= tb + 2 * rt && (w % bw == 0) && (h % bh == 0);
+  // the top plane must hold a whole candidate grid.  Its rows need not be whole dwords when the top block is 2 x 2
+  // (load_top_b2 reads them where they lie: 720 -> 90, 176 -> 22 at 4 levels of 16 x 16); the larger top blocks go through
+  // load_row<.., true>, whose in-row clamp only leaves the needed bytes alone when the row width is a multiple of 4 (found
+  // by tests/test_gpu_hbma_property.py: 112 x 32, 4 levels) -- and their top widths always are (w is a multiple of the block)
+  return tw >= tb + 8 && tw >= 12 && (tw % 4 == 0 || tb == 2) && th >= tb + 2 * rt && (w % bw == 0) && (h % bh == 0);
 }
 
 int launch_hbma_tiled(const FusedArgs& a, uint32_t n_pairs, hipStream_t stream);

@@ -324,8 +324,26 @@ __device__ __forceinline__ void load_top_b2(const uint8_t* __restrict__ trk, con
   for (int r = 0; r < B; ++r)
     s.a[r] = *reinterpret_cast<const uint16_t*>(anc + (uint32_t)((ay + r) * fw + ax));
   const uint32_t to = (uint32_t)(s.w.wy * fw);
+  if ((fw & 3) == 0) {  // wave-uniform
 #pragma unroll
-  for (int t = 0; t < NT; ++t) load_row<TopB2<RT>::ND, true>(trk, to + (uint32_t)(t * fw), a0, fw, s.m[t]);
+    for (int t = 0; t < NT; ++t) load_row<TopB2<RT>::ND, true>(trk, to + (uint32_t)(t * fw), a0, fw, s.m[t]);
+  } else {
+    // Rows that are not whole dwords (a frame 16 mod 32 pixels wide at 4 levels: PAL's 720 -> 90, QCIF's 176 -> 22): row
+    // starts are not dword-aligned in memory and the in-row clamp above would shift the bytes it is meant to protect.  The
+    // dwords are read where they lie (unaligned loads; a dword past the row's end simply continues into the next row), and
+    // only the PLANE's end is guarded: a load that would cross it re-reads the plane's last four bytes and shifts them down
+    // -- the bytes that fall off are past the plane and belong to no window.
+    const uint32_t last = (uint32_t)(fw * fh) - 4u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int k = 0; k < TopB2<RT>::ND; ++k) {
+        const uint32_t off = to + (uint32_t)(t * fw) + (uint32_t)(a0 + 4 * k), c = min(off, last), sh = off - c;
+        typedef uint32_t u32_a1 __attribute__((aligned(1)));
+        const uint32_t raw = *reinterpret_cast<const u32_a1*>(trk + c);
+        s.m[t][k] = sh >= 4u ? 0u : raw >> (8u * sh);
+      }
+  }
 }
 
 template <int RT, int SHIFT>

@@ -355,8 +355,6 @@ int svc_hip_build_pyramid_host(const uint8_t* level0, uint32_t w, uint32_t h, ui
               "(libs/encoder.cpp:164-168 pads to that)", w, h, f);
   for (uint32_t l = 1; l < level_count; ++l) SVC_REQUIRE(out_levels[l], "build_pyramid: null plane at level %u", l);
   if (level_count == 1) return SVC_OK;
-  if ((w >> (level_count - 1)) % 4 != 0)
-    return fail(SVC_ERR_UNSUPPORTED, "build_pyramid: top-level width %u must be a multiple of 4", w >> (level_count - 1));
   int rc = require_device();
   if (rc) return rc;
   Staging& st = host_stage();

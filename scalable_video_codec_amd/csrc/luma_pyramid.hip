@@ -62,8 +62,11 @@ struct PyrDownArgs {
   uint64_t src_off, dst_off;  // plane offsets inside a packed pyramid
   uint32_t sw, sh;            // source plane size
   uint32_t dw, dh;            // destination plane size (sw/2, sh/2)
-  uint32_t quads_per_row;     // dw / 4
-  uint32_t total;             // frames * dh * quads_per_row
+  uint32_t quads_per_row;     // ceil(dw / 4)
+  uint32_t total;             // frames * ceil(dh / 2) * quads_per_row
+  uint32_t bytewise;          // source or destination rows are not whole dwords (sw % 4 or dw % 4): every quad gathers and
+                              // stores byte by byte -- the top level of a 4-level pyramid of a frame 16 mod 32 pixels wide
+                              // (PAL's 720 -> 90, 1360 -> 170, QCIF's 176 -> 22), which the reference's default build produces
 };
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
   const uint32_t dy = 2 * dp;
   const uint8_t* src = a.pyr + (size_t)frame * a.pyr_stride + a.src_off;
   const int sx0 = (int)dq * 8;  // source column of the first output's centre
-  const bool border = dq == 0 || dq + 1 == a.quads_per_row;
+  const bool border = dq == 0 || dq + 1 == a.quads_per_row || a.bytewise != 0;
 
   uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
   const uint32_t taps[5] = {1, 4, 6, 4, 1};
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
     for (int r = 0; r < 7; ++r) {
       uint32_t px[11];
 #pragma unroll
-      for (int i = 0; i < 11; ++i) px[i] = rows[r][reflect101(sx0 - 2 + i, (int)a.sw)];
+      for (int i = 0; i < 11; ++i)  // (clamped: columns past a partial last quad only feed outputs that are not stored)
+        px[i] = rows[r][min(max(reflect101(sx0 - 2 + i, (int)a.sw), 0), (int)a.sw - 1)];
 #pragma unroll
       for (int o = 0; o < 4; ++o) h[r][o] = px[2 * o] + 4 * px[2 * o + 1] + 6 * px[2 * o + 2] + 4 * px[2 * o + 3] + px[2 * o + 4];
     }
@@ -134,6 +138,14 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
     out1 |= ((acc1[o] + 128u) >> 8) << (8 * o);
   }
   uint8_t* dst = a.pyr + (size_t)frame * a.pyr_stride + a.dst_off;
+  if (a.bytewise) {  // rows are not whole dwords: the row's last quad may be partial, and no store is dword-aligned
+    const uint32_t n = min(4u, a.dw - dq * 4);
+    for (uint32_t o = 0; o < n; ++o) {
+      dst[(size_t)dy * a.dw + dq * 4 + o] = (uint8_t)(out0 >> (8 * o));
+      if (dy + 1 < a.dh) dst[(size_t)(dy + 1) * a.dw + dq * 4 + o] = (uint8_t)(out1 >> (8 * o));
+    }
+    return;
+  }
   *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dw + dq * 4) = out0;
   if (dy + 1 < a.dh) *reinterpret_cast<uint32_t*>(dst + (size_t)(dy + 1) * a.dw + dq * 4) = out1;
 }
@@ -272,8 +284,6 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
   if (n_frames == 0) return SVC_OK;
   if (w % 16 != 0 || ((uint64_t)w * h) % 16 != 0)
     return fail(SVC_ERR_UNSUPPORTED, "luma: frame width %u must be a multiple of 16", w);
-  if ((w >> (levels - 1)) % 4 != 0)
-    return fail(SVC_ERR_UNSUPPORTED, "pyramid: top-level width %u must be a multiple of 4", w >> (levels - 1));
   LumaArgs la;
   la.bgr = d_bgr;
   la.frame_stride = frame_stride;
@@ -325,7 +335,8 @@ int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frame
     pa.src_off = off;
     off += (uint64_t)pa.sw * pa.sh;
     pa.dst_off = off;
-    pa.quads_per_row = pa.dw / 4;
+    pa.quads_per_row = div_up(pa.dw, 4);
+    pa.bytewise = (pa.sw % 4 != 0 || pa.dw % 4 != 0) ? 1u : 0u;
     if (l < first_plain_level) continue;  // produced by luma_pyr1_kernel
     // the LDS-tiled pass: source rows are read as aligned 16-byte segments
     if (pa.sw % 16 == 0 && pa.sh % 2 == 0 && pa.dw % 4 == 0 && pa.src_off % 16 == 0 && pyr_stride % 16 == 0 &&
@@ -345,7 +356,8 @@ int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frame
       if ((rc = check_launch("luma_pyr1_kernel<false>"))) return rc;
       continue;
     }
-    if (pa.quads_per_row < 2) return fail(SVC_ERR_UNSUPPORTED, "pyramid: level %u is narrower than 16 pixels", l);
+    if (pa.dw < 1 || pa.dh < 1 || pa.sw < 3 || pa.sh < 3)  // reflect-101 folds once: a source side below 3 cannot be mirrored
+      return fail(SVC_ERR_UNSUPPORTED, "pyramid: level %u (%u x %u) is too small to reduce", l, pa.sw, pa.sh);
     const uint64_t tot = (uint64_t)n_frames * ((pa.dh + 1) / 2) * pa.quads_per_row;
     if (tot > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many pixels for one launch");
     pa.total = (uint32_t)tot;

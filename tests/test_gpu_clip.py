@@ -285,3 +285,35 @@ def test_invalid_configurations(native):
         clipmod.Clip(CFG, 3, rank=0, world=4)  # fewer frames than ranks
     with pytest.raises(clipmod.ClipError):
         clipmod.Clip(CFG, 8, rank=2, world=2)
+
+
+@pytest.mark.parametrize("w,h", [(720, 576), (176, 144)])
+def test_default_four_level_build_on_widths_16_mod_32(native, oracle, w, h):
+    """PAL (720 x 576) and QCIF (176 x 144) with the reference's DEFAULT configuration (4 levels, 16 x 16, range 8): the level-3
+    plane is 90 / 22 pixels wide, not a whole number of dwords -- the pyramid kernels refused that until round 4.  The C++ driver's
+    pyramids and motion field (the general per-level kernel serves this shape) against the oracle, pipelined schedule."""
+    cfg = configs.CodecConfig(f"t-{w}x{h}-4L-dct8", 5, w, h, 5, levels=4, dct_block=8)
+    dev = torch.device("cuda")
+    frames = _frames(cfg, cfg.frames, dev)
+    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED)
+    enc.load_frames(frames)
+    for _ in range(4):
+        enc.step()
+    enc.sync()
+    out = enc.outputs()
+    pw, ph = cfg.padded
+    pyrs = [oracle.luma_pyramid(frames[t].cpu().numpy(), 4) for t in range(cfg.frames)]
+    pyr = enc.read("pyramids")
+    stride = enc.info.pyramid_stride
+    for t in (0, cfg.frames - 1):  # slot = frame + 1 (slot 0 is the halo)
+        off = 0
+        for l, p in enumerate(pyrs[t]):
+            got = pyr[(t + 1) * stride + off:(t + 1) * stride + off + p.size].numpy().reshape(p.shape)
+            assert np.array_equal(got, p), (t, l)
+            off += p.size
+    for p in range(cfg.frames - 1):
+        mv, mad = oracle.hbma16_sse2(pyrs[p], pyrs[p + 1], 8)
+        assert np.array_equal(out["mv"][p].numpy(), mv) and np.array_equal(out["min_mad"][p].numpy(), mad), p
+    ref = _reference_outputs(native, cfg, frames)
+    _assert_same(out, ref, enc.read("coeffs"))
+    enc.close()

@@ -256,3 +256,30 @@ def test_tiny_frames_fall_back_to_the_general_kernel(native, oracle):
         exp_mv, exp_mad = oracle.hbma(t, a, 8, 16, 16)
         mv, mad = native.hbma_host(t, a, 8, 16, 16)
         _assert_same(mv, mad, exp_mv, exp_mad, f"{w}x{h} L={levels}")
+
+
+@pytest.mark.parametrize("w,h,mb,levels", [(720, 576, 16, 4), (176, 144, 16, 4), (336, 272, 16, 4), (1360, 768, 16, 4), (112, 32, 16, 4),
+                                           (120, 72, 8, 3), (224, 96, 32, 5)])
+def test_top_level_rows_that_are_not_whole_dwords(native, oracle, w, h, mb, levels):
+    """Frames 16 mod 32 pixels wide at 4 levels of 16 x 16 (PAL, QCIF, 1360 x 768 ...; likewise 8 mod 16 at 3 levels of 8 x 8, 32 mod 64 at
+    5 of 32 x 32): the top plane's rows are 2 mod 4 bytes, so its row starts are not dword-aligned.  The lane-per-block kernel takes
+    them since round 4 (top-level dwords read where they lie, only the plane's end guarded) -- against the oracle and the general kernel,
+    with the pyramids packed at their exact size so that the last pair's top planes end where the buffer's data ends."""
+    rng = np.random.default_rng(w + levels)
+    n = 3
+    pyrs = [util.random_planes(rng, w, h, levels) for _ in range(n + 1)]
+    # a few flat / periodic rows at the bottom right: ties and clamped windows next to the plane's end
+    for p in pyrs:
+        p[levels - 1][-3:, -6:] = 77
+    exact = sum(p.size for p in pyrs[0])
+    stride = (exact + 15) & ~15
+    buf = util.pack_clip(pyrs, stride, torch.device("cuda"))[: n * stride + exact].clone()
+    assert native.hbma_kernel_name(levels, w, h, 8 if mb <= 16 else 16, mb, mb) == "hbma_fused_kernel"
+    r = 8 if mb <= 16 else 16
+    mv, mad = native.hbma_pairs(buf, buf[stride:], stride, n, levels, w, h, r, mb, mb)
+    mvw, madw = native.hbma_pairs(buf, buf[stride:], stride, n, levels, w, h, r, mb, mb, flags=native.HBMA_FORCE_WAVE_PER_BLOCK)
+    torch.cuda.synchronize()
+    assert torch.equal(mv, mvw) and torch.equal(mad, madw)
+    for p in range(n):
+        exp_mv, exp_mad = oracle.hbma(pyrs[p], pyrs[p + 1], r, mb, mb)
+        _assert_same(mv[p].cpu().numpy(), mad[p].cpu().numpy(), exp_mv, exp_mad, f"{w}x{h} pair {p}")

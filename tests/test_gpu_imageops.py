@@ -19,7 +19,8 @@ def test_bgr2yuv(native, oracle, w, h):
     assert np.array_equal(got[..., 0], oracle.luma(bgr))  # channel 0 is the luma the fused pyramid kernel computes
 
 
-@pytest.mark.parametrize("w,h,levels", [(1920, 1088, 3), (1920, 1088, 4), (3840, 2160, 4), (352, 288, 1), (64, 32, 2), (128, 64, 4)])
+@pytest.mark.parametrize("w,h,levels", [(1920, 1088, 3), (1920, 1088, 4), (3840, 2160, 4), (352, 288, 1), (64, 32, 2), (128, 64, 4),
+                                        (720, 576, 4), (176, 144, 4), (48, 16, 4)])  # the last three: level planes 90 / 22 / 6 pixels wide
 def test_build_pyramid(native, oracle, w, h, levels):
     rng = np.random.default_rng(levels * 7 + w)
     y = rng.integers(0, 256, (h, w), dtype=np.uint8)

@@ -154,6 +154,19 @@ def test_reference_encoder_odd_size_and_options(native, oracle, tmp_path):
     assert got2 == got
 
 
+def test_reference_encoder_pal_default_build(native, oracle, tmp_path):
+    """720 x 576 through the reference's DEFAULT build (4 levels): the level-3 plane is 90 pixels wide -- not a whole number of
+    dwords -- which the pyramid kernels refused until round 4, and the motion search takes the general per-level kernel there."""
+    n = 4
+    clip = synth.SynthClip(720, 576, n, seed=2024)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "pal.svcbgr"
+    _write_clip(path, frames)
+    got, _, _ = _encode("ref_encoder_sse2", path, "--verbose", "0")
+    header, expected = _expected_stream(oracle, frames, 4, True, 8)
+    _check(got, header, expected, 8)
+
+
 def test_reference_encoder_rejects_what_the_reference_rejects(native, tmp_path):
     """Validate() (libs/encoder.cpp:62-142) and the capture check (apps/encoder.cpp:192-196) are the reference's own code."""
     exe = os.path.join(BIN, "ref_encoder_generic")
