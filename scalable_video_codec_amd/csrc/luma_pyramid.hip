@@ -278,12 +278,31 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)gy * (w >> 1) + gx) = out;
   }
 }
+// any frame width: one pixel per lane
+__global__ __launch_bounds__(256) void luma_any_kernel(const uint8_t* bgr, uint64_t frame_stride, uint8_t* pyr, uint64_t pyr_stride,
+                                                        uint32_t px_per_frame, uint32_t total) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t frame = i / px_per_frame, p = i - frame * px_per_frame;
+  const uint8_t* s = bgr + (size_t)frame * frame_stride + (size_t)p * 3;
+  pyr[(size_t)frame * pyr_stride + p] = (uint8_t)luma_of(s[0], s[1], s[2]);
+}
+
 int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                         uint32_t h, uint32_t levels, uint8_t* d_pyr, uint64_t pyr_stride,
                         hipStream_t stream) {
   if (n_frames == 0) return SVC_OK;
-  if (w % 16 != 0 || ((uint64_t)w * h) % 16 != 0)
-    return fail(SVC_ERR_UNSUPPORTED, "luma: frame width %u must be a multiple of 16", w);
+  if (w % 16 != 0) {
+    // Frames that are not whole 16-pixel segments wide (8 x 8 MV blocks pad to multiples of 8: --mv-block-w 8 on a 360-pixel
+    // frame): a pixel per lane for the luma plane, then the plane-to-plane kernels.  Not the roofline path.
+    const uint64_t px = (uint64_t)w * h, tot = px * n_frames;
+    if (tot > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many pixels for one launch");
+    hipLaunchKernelGGL(luma_any_kernel, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, stream, d_bgr, frame_stride, d_pyr,
+                       pyr_stride, (uint32_t)px, (uint32_t)tot);
+    int rc0 = check_launch("luma_any_kernel");
+    if (rc0) return rc0;
+    return launch_pyr_down_levels(d_pyr, pyr_stride, n_frames, w, h, levels, 0, stream);
+  }
   LumaArgs la;
   la.bgr = d_bgr;
   la.frame_stride = frame_stride;

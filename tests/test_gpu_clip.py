@@ -317,3 +317,30 @@ def test_default_four_level_build_on_widths_16_mod_32(native, oracle, w, h):
     ref = _reference_outputs(native, cfg, frames)
     _assert_same(out, ref, enc.read("coeffs"))
     enc.close()
+
+
+def test_eight_pixel_mv_blocks_on_a_frame_not_16_wide(native, oracle):
+    """--mv-block-w 8 --mv-block-h 8 pads a 360 x 200 frame to itself (multiples of 8 and of 2^(L-1) = 4): not a whole number of the
+    luma kernel's 16-pixel segments wide.  The C++ driver end to end (general-width luma, bytewise level 2, lane-per-block search of
+    8 x 8 blocks at 3 levels, general transform kernel for 4 x 4 blocks) against the stage-by-stage calls and the oracle."""
+    cfg = configs.CodecConfig("t-360x200-8x8-3L-dct4", 9, 360, 200, 5, levels=3, mv_block=8, dct_block=4)
+    assert cfg.padded == (360, 200)
+    dev = torch.device("cuda")
+    frames = _frames(cfg, cfg.frames, dev)
+    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED)
+    enc.load_frames(frames)
+    for _ in range(4):
+        enc.step()
+    enc.sync()
+    out = enc.outputs()
+    pyrs = [oracle.luma_pyramid(frames[t].cpu().numpy(), 3) for t in range(cfg.frames)]
+    for p in range(cfg.frames - 1):
+        mv, mad = oracle.hbma(pyrs[p], pyrs[p + 1], cfg.search_range, 8, 8)
+        assert np.array_equal(out["mv"][p].numpy(), mv) and np.array_equal(out["min_mad"][p].numpy(), mad), p
+    ref = _reference_outputs(native, cfg, frames)
+    _assert_same(out, ref, enc.read("coeffs"))
+    want = oracle.dct_frame_f64(frames[2].cpu().numpy(), 4, 4)
+    got = oracle.quant_frame(want.astype(np.float32), 8, 8, out["block_types"][1].numpy().astype(np.uint32), cfg.fg_step, cfg.bg_step)
+    c = enc.read("coeffs").view(cfg.frames - 1, 3, 200, 360)[1].numpy()
+    assert np.mean(c == got) > 0.999  # away from rounding boundaries the quantised values agree exactly
+    enc.close()

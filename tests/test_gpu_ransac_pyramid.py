@@ -150,7 +150,8 @@ def test_ransac_device_draw_past_the_field_stays_inside(native, oracle, frames, 
 # 720 x 576 (PAL), 1360 x 768, 176 x 144 (QCIF), 336 x 272: frames 16 mod 32 pixels wide, whose level-3 plane is not a whole number
 # of dwords wide (90, 170, 22, 42) -- what the reference's DEFAULT 4-level build makes of them (refused until round 4); 5 levels too
 @pytest.mark.parametrize("w,h,levels", [(352, 288, 1), (320, 208, 3), (640, 368, 4), (64, 16, 2), (32, 8, 3), (128, 2, 2),
-                                        (720, 576, 4), (1360, 768, 4), (176, 144, 4), (336, 272, 4), (720, 576, 5), (48, 16, 4), (96, 48, 5)])
+                                        (720, 576, 4), (1360, 768, 4), (176, 144, 4), (336, 272, 4), (720, 576, 5), (48, 16, 4), (96, 48, 5),
+                                        (360, 200, 3), (40, 24, 4), (8, 8, 1), (24, 12, 2)])  # the last four: not a multiple of 16 wide (8 x 8 MV blocks pad to 8)
 def test_luma_pyramid(native, oracle, w, h, levels):
     """svc_hip_luma_pyramid_frames against the oracle's restatement of cvtColor + buildPyramid (libs/encoder.cpp:468-470)."""
     rng = np.random.default_rng(w * 31 + h)

@@ -66,47 +66,53 @@ class _TheRng:  # cv::theRNG() of compat/opencv2/core.hpp: OpenCV's multiply-wit
         self.state = ((self.state & 0xffffffff) * 4164903690 + (self.state >> 32)) & 0xffffffffffffffff
 
 
-def _expected_stream(oracle, frames, levels, sse2_entry, tb, search_range=8):
-    """Header bytes + per encoded frame (tile types u32, tile coefficients f32 [tiles, 3 * tb * tb])."""
+def _expected_stream(oracle, frames, levels, sse2_entry, tb, search_range=8, mvb=(16, 16), seg=None, ransac=None):
+    """Header bytes + per encoded frame (tile types u32, tile coefficients f32 [tiles, 3 * tbw * tbh]).  tb: the transform block, one
+    side or (w, h); mvb: the MV block (w, h); seg: non-default segmentation options as oracle.segment takes them."""
+    tbw, tbh = (tb, tb) if isinstance(tb, int) else tb
+    bw, bh = mvb
     h, w, _ = frames[0].shape
-    pw, ph = synth.padded_dims(w, h, 16, 16, levels)
-    mfw, mfh = pw // 16, ph // 16
-    header = struct.pack("<8I", len(frames) - 1, w, h, pw - w, ph - h, tb, tb, 3)
+    pw, ph = synth.padded_dims(w, h, bw, bh, levels)
+    mfw, mfh = pw // bw, ph // bh
+    header = struct.pack("<8I", len(frames) - 1, w, h, pw - w, ph - h, tbw, tbh, 3)
     padded = []
     for fr in frames:
         p = np.zeros((ph, pw, 3), np.uint8)  # cv::copyMakeBorder(..., BORDER_CONSTANT, 0), libs/encoder.cpp:447, :459
         p[:h, :w] = fr
         padded.append(p)
     pyrs = [oracle.luma_pyramid(p, levels) for p in padded]
-    iters = oracle.ransac_iter_count(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
-    draws = _draws(mfw * mfh, iters, 1, len(frames) - 1)
+    rp = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+    rp.update(ransac or {})
+    iters = oracle.ransac_iter_count(**rp)
+    draws = _draws(mfw * mfh, iters, rp["subset_sz"], len(frames) - 1)
     rng = _TheRng()
     out = []
     for t in range(1, len(frames)):
         if sse2_entry:
             mv, _ = oracle.hbma16_sse2(pyrs[t - 1], pyrs[t], search_range)
         else:
-            mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, 16, 16)
-        _, _, inliers = oracle.ransac(mv, draws[t - 1], subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+            mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, bw, bh)
+        _, _, inliers = oracle.ransac(mv, draws[t - 1], **rp)
         mask = np.zeros(mfw * mfh, np.uint8)
         mask[inliers] = 1
-        types = oracle.segment(mask, mv, mfw, mfh, seed=rng.state)
+        types = oracle.segment(mask, mv, mfw, mfh, bw, bh, seed=rng.state, **(seg or {}))
         if types.any():  # libs/encoder.cpp:553: cv::kmeans runs (and theRNG advances) only with a non-empty foreground
             rng.next()
-        planes = oracle.dct_frame_f32(padded[t], tb, tb)
-        rec = oracle.serialize_frame(planes, types, w, h, tb, tb, mfw)  # the UNPADDED size, as libs/encoder.cpp:647-650 passes it
-        rec = rec.view(np.uint32).reshape(-1, 1 + 3 * tb * tb)
+        planes = oracle.dct_frame_f32(padded[t], tbw, tbh)
+        rec = oracle.serialize_frame(planes, types, w, h, tbw, tbh, mfw, bw, bh)  # the UNPADDED size, as libs/encoder.cpp:647-650 passes it
+        rec = rec.view(np.uint32).reshape(-1, 1 + 3 * tbw * tbh)
         out.append((rec[:, 0].copy(), rec[:, 1:].copy().view(np.float32)))
     return header, out
 
 
 def _check(got, header, expected, tb):
+    area = tb * tb if isinstance(tb, int) else tb[0] * tb[1]
     assert got[:32] == header
-    per = expected[0][0].size * (4 + 12 * tb * tb)
+    per = expected[0][0].size * (4 + 12 * area)
     assert len(got) == 32 + per * len(expected), (len(got), per, len(expected))
     fg_tiles = 0
     for i, (types, coefs) in enumerate(expected):
-        rec = np.frombuffer(got, np.uint32, per // 4, 32 + i * per).reshape(-1, 1 + 3 * tb * tb)
+        rec = np.frombuffer(got, np.uint32, per // 4, 32 + i * per).reshape(-1, 1 + 3 * area)
         assert np.array_equal(rec[:, 0], types), f"frame {i + 1}: {(rec[:, 0] != types).sum()} tile types differ"
         c = rec[:, 1:].view(np.float32)
         assert (np.abs(c - coefs) <= 1e-4 * np.maximum(1.0, np.abs(coefs))).all(), f"frame {i + 1}: coefficients"
@@ -165,6 +171,41 @@ def test_reference_encoder_pal_default_build(native, oracle, tmp_path):
     got, _, _ = _encode("ref_encoder_sse2", path, "--verbose", "0")
     header, expected = _expected_stream(oracle, frames, 4, True, 8)
     _check(got, header, expected, 8)
+
+
+@pytest.mark.parametrize("size,levels,mvb,tb,opts,seg", [
+    ((360, 200), 3, (8, 8), (4, 4), ["--kmeans-cluster-count", "4", "--connected-components-connectivity", "8"],
+     dict(cluster_count=4, connectivity=8)),
+    ((330, 250), 2, (32, 16), (16, 8), ["--morph-rect-w", "5", "--morph-rect-h", "1", "--kmeans-attempt-count", "2"],
+     dict(morph_w=5, morph_h=1, attempts=2)),
+    ((352, 288), 1, (16, 16), (2, 2), ["--mv-search-range", "5", "--ransac-subset-sz", "3", "--ransac-inlier-thresh", "2.5"], None),
+], ids=["8x8-blocks-3L-360x200", "32x16-blocks-2L-16x8-transform", "1-level-ebma-2x2-transform-subset3"])
+def test_reference_encoder_every_option_of_its_command_line(native, oracle, tmp_path, size, levels, mvb, tb, opts, seg):
+    """The build without -DSVC_MOTION_SSE2 takes MV block sizes and level counts from the command line (apps/encoder.cpp:75-104):
+    8 x 8 blocks on a frame that is not a multiple of 16 wide (360: the general-width luma path, the general motion search and
+    transform kernels), NON-SQUARE MV and transform blocks -- where the reference's serialiser swaps width and height
+    (libs/encoder.cpp:230-262; the oracle restates it argument for argument) --, a 1-level search (= EBMA) with another search range,
+    RANSAC with 3-vector subsets, and the segmentation's options."""
+    w, h = size
+    n = 4
+    clip = synth.SynthClip(w, h, n, seed=w + h)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.svcbgr"
+    _write_clip(path, frames)
+    args = ["--verbose", "0", "--pyr-lvl-count", str(levels), "--mv-block-w", str(mvb[0]), "--mv-block-h", str(mvb[1]),
+            "--transform-block-w", str(tb[0]), "--transform-block-h", str(tb[1]), *opts]
+    got, _, _ = _encode("ref_encoder_generic", path, *args)
+    rp = {}
+    sr = 8
+    for k, v in zip(opts[::2], opts[1::2]):
+        if k == "--mv-search-range":
+            sr = int(v)
+        if k == "--ransac-subset-sz":
+            rp["subset_sz"] = int(v)
+        if k == "--ransac-inlier-thresh":
+            rp["inlier_thresh"] = float(v)
+    header, expected = _expected_stream(oracle, frames, levels, False, tb, search_range=sr, mvb=mvb, seg=seg, ransac=rp)
+    _check(got, header, expected, tb)
 
 
 def test_reference_encoder_rejects_what_the_reference_rejects(native, tmp_path):
