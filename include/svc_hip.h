@@ -464,7 +464,7 @@ int svc_hip_morph_rect_host(const uint8_t* src, uint32_t w, uint32_t h, uint32_t
  * Lloyd iterations with integer sums / counts and f64 distances in coordinate order, the attempt with the smallest
  * fixed-point compactness wins (ties: the earlier one).  labels: n cluster ids in [0, k); *compactness (may be NULL):
  * sum over the points of the squared distance to their centre, as cv::kmeans returns it (here in 1/256 steps).
- * n >= k >= 1, k <= 64, attempts <= 16. */
+ * n >= k >= 1, k <= 255, attempts <= 64. */
 int svc_hip_kmeans_host(const float* features, uint32_t n, uint32_t dims, uint32_t k, uint32_t attempts,
                         uint32_t max_iter, float epsilon, uint64_t seed, int32_t* labels, double* compactness);
 

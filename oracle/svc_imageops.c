@@ -6,7 +6,7 @@
  * Reference call sites: cv::cvtColor(BGR2YUV) libs/encoder.cpp:449, :468; cv::morphologyEx :524-527; cv::kmeans :575-576;
  * cv::connectedComponents :607-610.  All of them live in OpenCV 3.4.x, which is neither vendored nor installed:
  * PARITY UNPINNED, as for the fused forms.  The definitions are the ones oracle/svc_segment.c already states for the
- * fused segmentation (tests/test_oracle_golden.py checks that composing these functions the way the reference composes
+ * fused segmentation (tests/test_cpu_baseline.py checks that composing these functions the way the reference composes
  * the cv:: calls gives svc_oracle_segment's region ids), written a second time here for ANY point dimension up to 4,
  * any 8-bit image and any labelling image -- the generality the per-call C ABI has.
  */
@@ -98,8 +98,8 @@ static double d2_dbl(const pt4* p, const double* c, uint32_t dims) {
 
 static uint64_t attempt(const pt4* pts, uint32_t n, uint32_t dims, uint32_t k, uint32_t max_iter, double eps2, uint64_t seed,
                         uint32_t att, int32_t* labels) {
-  double c[64][4];
-  uint32_t chosen[64];
+  double c[256][4];
+  uint32_t chosen[256];
   const uint64_t aseed = seed ^ ((uint64_t)att << 32);
   chosen[0] = (uint32_t)(io_hash(aseed) % n);
   for (uint32_t j = 1; j < k; ++j) { /* k-means++ with exact integer weights */
@@ -134,8 +134,8 @@ static uint64_t attempt(const pt4* pts, uint32_t n, uint32_t dims, uint32_t k, u
     for (uint32_t d = 0; d < dims; ++d) c[j][d] = (double)pts[chosen[j]].f[d];
   uint64_t compact = 0;
   for (uint32_t it = 0;; ++it) {
-    int64_t sum[64][4];
-    uint32_t cnt[64];
+    int64_t sum[256][4];
+    uint32_t cnt[256];
     memset(sum, 0, sizeof(sum));
     memset(cnt, 0, sizeof(cnt));
     compact = 0;
@@ -173,7 +173,7 @@ static uint64_t attempt(const pt4* pts, uint32_t n, uint32_t dims, uint32_t k, u
  * coordinates.  Returns 0, or 1 for parameters outside the definition (non-integral features included). */
 int svc_oracle_kmeans(const float* features, uint32_t n, uint32_t dims, uint32_t k, uint32_t attempts, uint32_t max_iter,
                       float epsilon, uint64_t seed, int32_t* labels, double* compactness) {
-  if (!n || !k || k > 64 || k > n || dims < 1 || dims > 4 || !attempts || !max_iter || !(epsilon > 0)) return 1;
+  if (!n || !k || k > 255 || k > n || dims < 1 || dims > 4 || !attempts || !max_iter || !(epsilon > 0)) return 1;
   pt4* pts = (pt4*)malloc(sizeof(pt4) * n);
   for (uint32_t i = 0; i < n; ++i)
     for (uint32_t d = 0; d < 4; ++d) {

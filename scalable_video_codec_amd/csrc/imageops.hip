@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void morph_rect_kernel(const uint8_t* src, uin
 }
 
 // ---- k-means (oracle/svc_segment.c's definition, up to 4 integer coordinates) --------------------------------------
-constexpr uint32_t kKmT = 1024, kKmMaxK = 64, kKmMaxAttempts = 16;
+constexpr uint32_t kKmT = 1024, kKmMaxK = 255, kKmMaxAttempts = 64;  // labels are bytes; the compactness table is 512 B
 
 struct KmArgs {
   const float* feat;            // [n][dims]
@@ -422,7 +422,7 @@ int svc_hip_kmeans_host(const float* features, uint32_t n, uint32_t dims, uint32
   if (rc) return rc;
   Staging& st = host_stage();
   const size_t feat_b = up256((size_t)n * dims * 4), pts_b = up256((size_t)n * 16), dmin_b = up256((size_t)attempts * n * 8);
-  const size_t lab_b = up256((size_t)attempts * n), misc_b = 256, out_b = up256((size_t)n * 4);
+  const size_t lab_b = up256((size_t)attempts * n), misc_b = 768, out_b = up256((size_t)n * 4);
   if ((rc = st.ensure(feat_b + pts_b + dmin_b + lab_b + misc_b + out_b))) return rc;
   std::memcpy(st.pin, features, (size_t)n * dims * 4);
   SVC_HIP_TRY(hipMemcpyAsync(st.dev, st.pin, (size_t)n * dims * 4, hipMemcpyHostToDevice, st.stream));
@@ -432,10 +432,10 @@ int svc_hip_kmeans_host(const float* features, uint32_t n, uint32_t dims, uint32
   a.pts = reinterpret_cast<int*>(d + feat_b);
   a.dmin = reinterpret_cast<unsigned long long*>(d + feat_b + pts_b);
   a.lab = d + feat_b + pts_b + dmin_b;
-  uint8_t* misc = d + feat_b + pts_b + dmin_b + lab_b;  // [0, 128): compactness per attempt; 128: bad flag; 136: result
+  uint8_t* misc = d + feat_b + pts_b + dmin_b + lab_b;  // [0, 512): compactness per attempt; 512: bad flag; 520: result
   a.compact = reinterpret_cast<unsigned long long*>(misc);
-  a.bad = reinterpret_cast<uint32_t*>(misc + 128);
-  a.out_compact = reinterpret_cast<double*>(misc + 136);
+  a.bad = reinterpret_cast<uint32_t*>(misc + 512);
+  a.out_compact = reinterpret_cast<double*>(misc + 520);
   a.out = reinterpret_cast<int32_t*>(misc + misc_b);
   a.n = n; a.dims = dims; a.k = k; a.attempts = attempts; a.max_iter = max_iter;
   a.eps2 = (double)epsilon * (double)epsilon;
@@ -449,12 +449,12 @@ int svc_hip_kmeans_host(const float* features, uint32_t n, uint32_t dims, uint32
   SVC_HIP_TRY(hipMemcpyAsync(st.pin + pin_off, misc, back, hipMemcpyDeviceToHost, st.stream));
   SVC_HIP_TRY(hipStreamSynchronize(st.stream));
   uint32_t bad;
-  std::memcpy(&bad, st.pin + pin_off + 128, 4);
+  std::memcpy(&bad, st.pin + pin_off + 512, 4);
   if (bad)
     return fail(SVC_ERR_UNSUPPORTED, "kmeans: a feature is not an integer of magnitude below 32768 (this definition of "
                                      "cv::kmeans takes block-matching output and pixel positions)");
   std::memcpy(labels, st.pin + pin_off + misc_b, (size_t)n * 4);
-  if (compactness) std::memcpy(compactness, st.pin + pin_off + 136, 8);
+  if (compactness) std::memcpy(compactness, st.pin + pin_off + 520, 8);
   return SVC_OK;
 }
 

@@ -47,7 +47,8 @@ def test_morph_rect(native, oracle, w, h, kw, kh):
 
 @pytest.mark.parametrize("n,dims,k,kw", [(600, 4, 10, {}), (8160, 4, 10, {}), (30000, 4, 10, {}), (5, 4, 5, {}), (64, 1, 3, {}),
                                           (2000, 2, 64, dict(attempts=1, max_iter=30)), (900, 3, 7, dict(epsilon=40.0)),
-                                          (1500, 4, 1, {}), (777, 4, 12, dict(max_iter=1, attempts=16))])
+                                          (1500, 4, 1, {}), (777, 4, 12, dict(max_iter=1, attempts=16)),
+                                          (3000, 4, 200, dict(attempts=2)), (400, 2, 5, dict(attempts=40, max_iter=3))])  # more clusters / attempts than the fused path takes
 def test_kmeans(native, oracle, n, dims, k, kw):
     rng = np.random.default_rng(n + dims)
     f = np.zeros((n, dims), np.float32)
