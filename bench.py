@@ -175,7 +175,9 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
                                  _dct_quant_host, what libsvc_motion.so's wrappers call), synchronous, one host thread;
       stream_encoder_fps         svc::StreamEncoder (C++, tests/dropin/stream_main): batches, H2D / kernels / D2H on three streams;
       reference_application_fps  the reference's UNCHANGED apps/encoder.cpp + libs/encoder.cpp on compat/opencv2
-                                 (tests/dropin/ref_encoder_*), two clip lengths so that process start-up cancels.
+                                 (tests/dropin/ref_encoder_*), two clip lengths so that process start-up cancels;
+      reference_application_batched_encoder_fps  the same unchanged apps/encoder.cpp with this repo's class Encoder
+                                 (the reference's encoder.hpp on svc::StreamEncoder, tests/dropin/ref_app_svc_encoder*).
     `value` of the line never includes any of this."""
     import subprocess
     import tempfile
@@ -253,6 +255,35 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
         except Exception as e:  # noqa: BLE001
             out["reference_application_fps"] = None
             out["reference_application_note"] = f"not measured: {e}"
+        # (d) the same unchanged application with THIS repo's implementation of the reference's class Encoder (svc::StreamEncoder
+        # behind libs/encoder.hpp: csrc/host/encoder_hip.cpp) in place of the reference's libs/encoder.cpp
+        exe = os.path.join(bin_dir, "ref_app_svc_encoder" if sse2 else "ref_app_svc_encoder_generic")
+        try:
+            if not os.path.exists(exe):
+                raise RuntimeError("tests/dropin/ref_app_svc_encoder* not built (needs /root/reference at build time)")
+            if cfg.dct_block == 0:
+                raise RuntimeError("this configuration has no transform")
+            times = {}
+            for n in (9, min(len(src), 65)):
+                path = os.path.join(d, f"clip{n}.svcbgr")
+                with open(path, "wb") as f:
+                    f.write(b"SVCBGR1\0" + np.array([cfg.width, cfg.height, n, 0], np.uint32).tobytes())
+                    src[:n].tofile(f)
+                t0 = time.perf_counter()
+                with open(os.devnull, "wb") as sink:
+                    r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600)
+                times[n] = time.perf_counter() - t0
+                os.remove(path)
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr.decode()[-300:])
+            (n1, t1), (n2, t2) = sorted(times.items())
+            out["reference_application_batched_encoder_fps"] = (n2 - n1) / max(t2 - t1, 1e-9)
+            out["reference_application_batched_encoder_sample"] = (
+                f"{os.path.basename(exe)} (the reference's unchanged apps/encoder.cpp + libs/cli.cpp, class Encoder = csrc/host/encoder_hip.cpp on "
+                f"svc::StreamEncoder): {n1} and {n2} frame clips, stdout to /dev/null; ({n2} - {n1}) frames / ({t2:.2f} - {t1:.2f}) s")
+        except Exception as e:  # noqa: BLE001
+            out["reference_application_batched_encoder_fps"] = None
+            out["reference_application_batched_encoder_note"] = f"not measured: {e}"
     return out
 
 

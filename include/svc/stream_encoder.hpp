@@ -34,6 +34,10 @@ struct StreamEncoderConfig {
                                    // coefficients, as the reference's encoder emits them (the decoder picks the
                                    // quant step per tile, libs/decoder.cpp:130-135), over the PADDED tile grid its
                                    // decoder parses (libs/decoder.cpp:185-186); fg_step / bg_step apply to planes only
+  bool reference_stream = false;   // with `wire`: the records EXACTLY as the reference's ENCODER serialises them
+                                   // (libs/encoder.cpp:647-650 hands SerializeEncodedFrame the UNPADDED size: tile loops over it,
+                                   // and the unpadded width as the row stride of the padded planes) -- the stream
+                                   // apps/encoder.cpp writes to stdout; record_bytes then counts the unpadded tile grid
   uint32_t batch = 16;             // encoded frames per batch
   uint32_t depth = 3;              // batches in flight, >= 3 (H2D, kernels and D2H of three batches overlap)
   uint64_t seed = 0;
@@ -61,6 +65,9 @@ struct EncodedBatch {
 class StreamEncoder {
  public:
   using Sink = std::function<void(const EncodedBatch&)>;
+  // Hands out the clip's next source frame (unpadded B,G,R u8, height x width x 3, tightly packed, anywhere in host memory),
+  // or nullptr when the clip has ended; the pointer must stay valid until the next call.  May block (a capture queue).
+  using Source = std::function<const uint8_t*()>;
 
   // Allocates every buffer; throws std::runtime_error with the C ABI's message on failure.
   explicit StreamEncoder(const StreamEncoderConfig& config);
@@ -71,6 +78,11 @@ class StreamEncoder {
   // Encodes a clip of n_frames >= 2 unpadded B,G,R u8 frames (height x width x 3, tightly packed,
   // anywhere in host memory); sink is called once per batch, in clip order, from this thread.
   void Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& sink);
+
+  // The same for a clip that ARRIVES frame by frame (the reference's reader thread -> queue -> Encoder::operator(),
+  // apps/encoder.cpp:125-148): frames are pulled from `next` as the batches need them.  header_frame_count is what the
+  // stream's header announces (the reference takes it from the container, libs/encoder.cpp:361-367), not a limit.
+  void Encode(const Source& next, uint32_t header_frame_count, const Sink& sink);
 
   uint32_t padded_width() const;
   uint32_t padded_height() const;

@@ -168,6 +168,18 @@ def reference_encoder_command(exe: str, sse2: bool, extra_sources: List[str] = (
             f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd"]
 
 
+def svc_encoder_app_command(exe: str, sse2: bool = True, extra_sources: List[str] = ()) -> List[str]:
+    """INTEGRATION.md section 3, second build line: the reference's unchanged apps/encoder.cpp + libs/cli.cpp with THIS repo's
+    implementation of the reference's class Encoder (csrc/host/encoder_hip.cpp, compiled against the reference's own encoder.hpp)
+    in place of libs/encoder.cpp -- the batched GPU form of the same application."""
+    cxx = shutil.which("g++") or "g++"
+    return [cxx, "-std=c++17", "-O2", "-DNDEBUG", "-msse2", *(["-DSVC_MOTION_SSE2"] if sse2 else []), f"-I{COMPAT}", f"-I{REFERENCE_LIBS}",
+            f"-I{INCLUDE}", "-o", exe, os.path.join(REFERENCE_APPS, "encoder.cpp"), os.path.join(REFERENCE_LIBS, "cli.cpp"),
+            os.path.join(CSRC, "host", "encoder_hip.cpp"), os.path.join(COMPAT, "src", "thread_guard.cpp"), *extra_sources,
+            f"-L{PKG}", "-lsvc_opencv_compat", "-lsvc_motion", "-lsvc_hip", "-pthread",
+            f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd"]
+
+
 def build_reference_encoder(force: bool = False) -> List[str]:
     """tests/dropin/ref_encoder_{sse2,generic}: the reference's unchanged encoder application on the HIP path,
     built where /root/reference exists; the binaries travel to the GPU box like the other drop-in callers.  The only extra
@@ -184,6 +196,15 @@ def build_reference_encoder(force: bool = False) -> List[str]:
         exe = os.path.join(here, name)
         if force or not _newer(exe, deps):
             _run(reference_encoder_command(exe, sse2, [seed_src]))
+        out.append(exe)
+    # the reference's unchanged apps/encoder.cpp on the BATCHED Encoder (csrc/host/encoder_hip.cpp: class Encoder of the reference's own
+    # encoder.hpp implemented on svc::StreamEncoder) instead of the reference's libs/encoder.cpp
+    enc_src = os.path.join(CSRC, "host", "encoder_hip.cpp")
+    seed2 = os.path.join(here, "encoder_seed.cpp")
+    for name, sse2 in (("ref_app_svc_encoder", True), ("ref_app_svc_encoder_generic", False)):
+        exe = os.path.join(here, name)
+        if force or not _newer(exe, [enc_src, seed2, LIB_COMPAT, LIB_MOTION, os.path.join(INCLUDE, "svc", "stream_encoder.hpp")]):
+            _run(svc_encoder_app_command(exe, sse2, [seed2]))
         out.append(exe)
     # the libstdc++ engine + distribution the C++ RANSAC wrapper draws with, for tests that mirror its draws
     exe = os.path.join(here, "ransac_draws")

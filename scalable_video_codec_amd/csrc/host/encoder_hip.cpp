@@ -1,0 +1,160 @@
+// encoder_hip.cpp -- the reference's `class Encoder` and its three Validate functions (libs/encoder.hpp:14, :23, :38, :52-95)
+// implemented on svc::StreamEncoder: the drop-in one level above libsvc_motion.so.  Compiled against the REFERENCE'S OWN
+// header (-I<reference>/libs; never copied) so that apps/encoder.cpp -- unchanged -- constructs this Encoder, starts its reader
+// and writer threads and calls operator() exactly as it does with the reference's libs/encoder.cpp (apps/encoder.cpp:213-228).
+//
+// What operator() does is the reference's per-frame loop (libs/encoder.cpp:341-664) batched: frames are pulled from the
+// reader's queue sixteen at a time, go to the GPU once as 8-bit B,G,R, and come back as the serialised records themselves --
+// Header first (libs/codec.hpp:8-17), then one byte vector per encoded frame, bit-compatible with what
+// SerializeEncodedFrame emits for the reference's own arguments (the unpadded tile loops and row stride of
+// libs/encoder.cpp:647-650 included).  No cv:: arithmetic is called: the adapter under compat/ only supplies the matrix TYPE
+// the two queues carry.  RANSAC draws and k-means seeds come from one seed (std::random_device unless SvcEncoderSeed() was
+// called), as the reference's come from its own generators: two runs of the reference differ in region ids the same way.
+//
+// Scope: square MV blocks and square transform blocks (what svc::StreamEncoder batches); the general case -- non-square
+// blocks -- runs through the reference's own libs/encoder.cpp over compat/opencv2.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "codec.hpp"    // the reference's (Header)
+#include "encoder.hpp"  // the reference's (class Encoder, EncoderConfig, Validate)
+#include "svc/stream_encoder.hpp"
+
+namespace {
+bool g_seeded = false;
+uint64_t g_seed = 0;
+
+// A fatal error inside operator(): the reader and writer threads of apps/encoder.cpp are alive and may be blocked on the two
+// queues, which are objects of static storage -- std::exit would destroy them under the waiters.  Leave without destructors.
+[[noreturn]] void Die() {
+  std::fflush(stderr);
+  std::_Exit(EXIT_FAILURE);
+}
+
+Error Invalid(std::string what) { return Error{ErrorCode::kInvalidParameter, std::move(what)}; }
+}  // namespace
+
+// Reproducible runs (tests): fixes the seed of RANSAC's draws and of the k-means seeding for every Encoder of the process.
+extern "C" void SvcEncoderSeed(unsigned long long seed) {
+  g_seed = seed;
+  g_seeded = true;
+}
+
+// ---- the configuration rules of libs/encoder.cpp:20-142, rule for rule ------------------------------------------------
+Error Validate(const RansacParams& p) {
+  if (p.inlier_thresh < 0) return Invalid("RANSAC inlier threshold below 0");
+  if (p.success_prob < 0) return Invalid("RANSAC success probability below 0");
+  if (p.inlier_ratio < 0) return Invalid("RANSAC inlier ratio below 0");
+  return Error{ErrorCode::kOk};
+}
+
+Error Validate(const KMeansParams& p) {
+  if (p.cluster_count == 0) return Invalid("k-means cluster count must be positive");
+  if (p.attempt_count == 0) return Invalid("k-means attempt count must be positive");
+  if (p.max_iter_count == 0) return Invalid("k-means iteration limit must be positive");
+  if (p.epsilon <= 0) return Invalid("k-means epsilon must be positive");
+  return Error{ErrorCode::kOk};
+}
+
+Error Validate(const EncoderConfig& c) {
+  if (c.mv_block_w < 1 || c.mv_block_h < 1) return Invalid("MV block sides must be positive");
+  if (c.pyr_lvl_count < 1) return Invalid("pyramid level count must be positive");
+  if (c.mv_search_range / Pow2(c.pyr_lvl_count - 1) == 0)
+    return Invalid("MV search range divided by 2^(levels - 1) must be positive");
+  Error e = Validate(c.ransac);
+  if (e.code != ErrorCode::kOk) return Error{e.code, "RANSAC parameters: " + e.message};
+  e = Validate(c.kmeans);
+  if (e.code != ErrorCode::kOk) return Error{e.code, "k-means parameters: " + e.message};
+  if (c.connected_components_connectivity != 4 && c.connected_components_connectivity != 8)
+    return Invalid("connected-components connectivity must be 4 or 8");
+  if (c.transform_block_w < 1 || c.transform_block_h < 1) return Invalid("transform block sides must be positive");
+  if (c.transform_block_w > c.mv_block_w || c.transform_block_h > c.mv_block_h)
+    return Invalid("the transform block must not exceed the MV block");
+  if (c.mv_block_w % c.transform_block_w != 0 || c.mv_block_h % c.transform_block_h != 0)
+    return Invalid("the MV block must be a whole number of transform blocks");
+  return Error{ErrorCode::kOk};
+}
+
+Encoder::Encoder(const EncoderConfig& cfg, const VideoProperties& vidprops, CircularQueue<cv::Mat3b>& in_queue,
+                 std::future<void> attempted_first_frame_read, CircularQueue<std::vector<uchar>>& out_queue)
+    : cfg_{cfg},
+      vidprops_{vidprops},
+      in_queue_{in_queue},
+      attempted_first_frame_read_{std::move(attempted_first_frame_read)},
+      out_queue_{out_queue} {
+  const uint f = Pow2(cfg_.pyr_lvl_count - 1);
+  padded_frame_w_ = ClosestLargerDivisible(vidprops_.frame_w, cfg_.mv_block_w, f);  // libs/encoder.cpp:164-168
+  padded_frame_h_ = ClosestLargerDivisible(vidprops_.frame_h, cfg_.mv_block_h, f);
+  frame_excess_w_ = padded_frame_w_ - vidprops_.frame_w;
+  frame_excess_h_ = padded_frame_h_ - vidprops_.frame_h;
+  mv_field_w_ = padded_frame_w_ / cfg_.mv_block_w;
+  mv_field_h_ = padded_frame_h_ / cfg_.mv_block_h;
+}
+
+void Encoder::operator()() {
+  attempted_first_frame_read_.wait();
+  if (in_queue_.IsEmpty()) return;  // the reader found no frame: no output at all (libs/encoder.cpp:344-348)
+
+  if (cfg_.mv_block_w != cfg_.mv_block_h || cfg_.transform_block_w != cfg_.transform_block_h) {
+    std::fprintf(stderr, "svc Encoder (batched GPU form): square MV and transform blocks only (got %ux%u / %ux%u); the general case runs "
+                         "through the reference's libs/encoder.cpp over compat/opencv2\n",
+                 cfg_.mv_block_w, cfg_.mv_block_h, cfg_.transform_block_w, cfg_.transform_block_h);
+    Die();
+  }
+  svc::StreamEncoderConfig c;
+  c.width = vidprops_.frame_w; c.height = vidprops_.frame_h;
+  c.levels = cfg_.pyr_lvl_count;
+  c.mv_block = cfg_.mv_block_w;
+  c.search_range = cfg_.mv_search_range;
+  c.dct_block = cfg_.transform_block_w;
+  c.wire = true;
+  c.reference_stream = true;  // the bytes SerializeEncodedFrame emits for the reference's arguments (libs/encoder.cpp:647-650)
+  c.ransac = svc_ransac_params{cfg_.ransac.subset_sz, cfg_.ransac.inlier_thresh, cfg_.ransac.success_prob, cfg_.ransac.inlier_ratio};
+  c.segment = svc_segment_params{cfg_.morph_rect_w, cfg_.morph_rect_h, cfg_.kmeans.cluster_count, cfg_.kmeans.attempt_count,
+                                 cfg_.kmeans.max_iter_count, cfg_.kmeans.epsilon, cfg_.connected_components_connectivity};
+  if (g_seeded) {
+    c.seed = g_seed;
+  } else {
+    std::random_device rd;  // the reference's own source of randomness (libs/motion.cpp:186)
+    c.seed = ((uint64_t)rd() << 32) | rd();
+  }
+
+  {  // the stream's header goes out as soon as the first frame has arrived, before anything is encoded (libs/encoder.cpp:360-381)
+    uint frame_count = vidprops_.frame_count;
+    if (frame_count > 0) --frame_count;  // the first frame is tracked only
+    Header h{frame_count, vidprops_.frame_w, vidprops_.frame_h, frame_excess_w_, frame_excess_h_,
+             cfg_.transform_block_w, cfg_.transform_block_h, 3u};
+    const uchar* p = reinterpret_cast<const uchar*>(&h);
+    out_queue_.Push(std::vector<uchar>(p, p + sizeof(h)));
+  }
+
+  try {
+    svc::StreamEncoder enc(c);
+    cv::Mat3b frame;  // keeps the frame handed to the encoder alive until it asks for the next one
+    const size_t want = (size_t)vidprops_.frame_w * vidprops_.frame_h * 3;
+    auto next = [&]() -> const uint8_t* {
+      if (!in_queue_.Pop(frame)) return nullptr;  // queue empty and the reader is done
+      if (frame.empty() || (size_t)frame.rows * frame.cols * 3 != want || !frame.isContinuous()) {
+        std::fprintf(stderr, "svc Encoder: a frame of %d x %d does not match the capture's %u x %u\n", frame.cols, frame.rows,
+                     vidprops_.frame_w, vidprops_.frame_h);
+        Die();
+      }
+      return frame.data;
+    };
+    auto sink = [&](const svc::EncodedBatch& b) {
+      for (uint32_t i = 0; i < b.count; ++i) {
+        const uint8_t* r = b.records + (size_t)i * b.record_bytes;
+        out_queue_.Push(std::vector<uchar>(r, r + b.record_bytes));  // one vector per frame, as the reference pushes them (:652)
+      }
+    };
+    enc.Encode(next, vidprops_.frame_count, sink);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "svc Encoder: %s\n", e.what());
+    Die();
+  }
+  out_queue_.SignalProducerIsDone();
+}

@@ -48,7 +48,8 @@ template <typename T> struct PinBuf {
 struct Slot {
   DevBuf<uint8_t> bgr, pyr, mask, seg_ws, records;
   DevBuf<float> mv, mad, gm, rmse, coeffs;
-  DevBuf<uint32_t> count, types;
+  DevBuf<uint32_t> count, types, samples;
+  PinBuf<uint32_t> pin_samples;
   PinBuf<uint8_t> pin_in, pin_records;
   PinBuf<float> pin_mv, pin_gm, pin_coeffs;
   PinBuf<uint32_t> pin_types;
@@ -70,8 +71,7 @@ struct StreamEncoder::Impl {
   uint64_t pyr_stride = 0, frame_bytes = 0, plane_elems = 0, record_bytes = 0, seg_ws_bytes = 0;
   std::vector<std::unique_ptr<Slot>> slots;
   hipStream_t s_in = nullptr, s_compute = nullptr, s_out = nullptr;
-  DevBuf<uint32_t> samples;
-  size_t samples_cap = 0;
+  bool fused_records = false;  // wire: the transform kernel emits the records itself
 
   ~Impl() {
     for (hipStream_t s : {s_in, s_compute, s_out})
@@ -89,10 +89,15 @@ StreamEncoder::StreamEncoder(const StreamEncoderConfig& config) : p_(new Impl) {
   m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
   m.ph = ClosestLargerDivisible(c.height, c.mv_block, f);
   m.mfw = m.pw / c.mv_block; m.mfh = m.ph / c.mv_block; m.blocks = m.mfw * m.mfh;
-  m.pyr_stride = svc_hip_pyramid_bytes(m.pw, m.ph, c.levels);
+  m.pyr_stride = (svc_hip_pyramid_bytes(m.pw, m.ph, c.levels) + 255) / 256 * 256;  // the kernels ask for 16-byte aligned pyramids
   m.frame_bytes = (uint64_t)m.pw * m.ph * 3;
   m.plane_elems = (uint64_t)m.pw * m.ph;
-  m.record_bytes = c.wire ? svc_hip_serialized_frame_bytes(m.pw, m.ph, c.dct_block, c.dct_block) : 0;
+  // reference_stream: SerializeEncodedFrame over the UNPADDED size (libs/encoder.cpp:647-650); the transform kernel emits that
+  // directly when the padded width IS the frame's width (emit height = the unpadded one); with a padded width the row
+  // stride quirk needs the planes first and svc_hip_serialize_frames behind them
+  m.record_bytes = !c.wire ? 0 : c.reference_stream ? svc_hip_serialized_frame_bytes(c.width, c.height, c.dct_block, c.dct_block)
+                                                    : svc_hip_serialized_frame_bytes(m.pw, m.ph, c.dct_block, c.dct_block);
+  m.fused_records = c.wire && (!c.reference_stream || m.pw == c.width);
   m.iters = svc_hip_ransac_iter_count(c.ransac);
   m.seg_ws_bytes = svc_hip_segment_workspace_bytes(m.mfw, m.mfh, c.batch, c.segment.attempt_count);
   Hip(hipStreamCreateWithFlags(&m.s_in, hipStreamNonBlocking), "hipStreamCreate");
@@ -111,8 +116,11 @@ StreamEncoder::StreamEncoder(const StreamEncoderConfig& config) : p_(new Impl) {
     s->pin_in.Alloc((B + 1) * m.frame_bytes);
     std::memset(s->pin_in.p, 0, (B + 1) * m.frame_bytes);  // the padding border stays zero (encoder.cpp:459-461)
     s->pin_mv.Alloc(B * m.blocks * 2); s->pin_gm.Alloc(B * 2); s->pin_types.Alloc(B * m.blocks);
+    s->samples.Alloc(B * m.iters * c.ransac.subset_sz); s->pin_samples.Alloc(B * m.iters * c.ransac.subset_sz);
+    Hip(hipMemset(s->samples.p, 0, std::max<size_t>(B * m.iters * c.ransac.subset_sz, 1) * sizeof(uint32_t)), "hipMemset");
     if (c.wire) { s->records.Alloc(B * m.record_bytes); s->pin_records.Alloc(B * m.record_bytes); }
-    else { s->coeffs.Alloc(B * 3 * m.plane_elems); s->pin_coeffs.Alloc(B * 3 * m.plane_elems); }
+    if (!c.wire || !m.fused_records) s->coeffs.Alloc(B * 3 * m.plane_elems);
+    if (!c.wire) s->pin_coeffs.Alloc(B * 3 * m.plane_elems);
     Hip(hipEventCreateWithFlags(&s->h2d_done, hipEventDisableTiming), "hipEventCreate");
     Hip(hipEventCreateWithFlags(&s->compute_done, hipEventDisableTiming), "hipEventCreate");
     Hip(hipEventCreateWithFlags(&s->d2h_done, hipEventDisableTiming), "hipEventCreate");
@@ -125,36 +133,22 @@ uint32_t StreamEncoder::padded_width() const { return p_->pw; }
 uint32_t StreamEncoder::padded_height() const { return p_->ph; }
 
 void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& sink) {
+  if (!bgr || n_frames < 2) throw std::runtime_error("svc::StreamEncoder: a clip needs at least two frames");
+  const size_t frame = (size_t)p_->c.width * p_->c.height * 3;
+  uint32_t i = 0;
+  Encode([&]() -> const uint8_t* { return i < n_frames ? bgr + (size_t)(i++) * frame : nullptr; }, n_frames, sink);
+}
+
+void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, const Sink& sink) {
   Impl& m = *p_;
   const StreamEncoderConfig& c = m.c;
-  if (!bgr || n_frames < 2) throw std::runtime_error("svc::StreamEncoder: a clip needs at least two frames");
-  const uint32_t pairs_total = n_frames - 1, B = c.batch;
-
-  // RANSAC draws for every encoded frame of the clip: distinct within an iteration, a function of
-  // (seed, frame, iteration) only (same generator as the harness: pipeline.ransac_samples)
-  {
-    const size_t n = (size_t)pairs_total * m.iters * c.ransac.subset_sz;
-    std::vector<uint32_t> h(n);
-    const uint32_t div = std::max<uint32_t>(1, (m.blocks - 1) / std::max<uint32_t>(1, c.ransac.subset_sz));
-    for (size_t idx = 0; idx < (size_t)pairs_total * m.iters; ++idx) {
-      const uint32_t first = Hash32(idx * 0x9E3779B1ull + c.seed) % m.blocks;
-      const uint32_t step = 1 + Hash32(idx * 0x85EBCA6Bull + c.seed + 1) % div;
-      for (uint32_t k = 0; k < c.ransac.subset_sz; ++k)
-        h[idx * c.ransac.subset_sz + k] = (uint32_t)(((uint64_t)first + (uint64_t)step * k) % m.blocks);
-    }
-    if (n + (size_t)B * m.iters * c.ransac.subset_sz > m.samples_cap) {  // slack: a short last batch still runs B pairs
-      if (m.samples.p) { Hip(hipFree(m.samples.p), "hipFree"); m.samples.p = nullptr; }
-      m.samples_cap = n + (size_t)B * m.iters * c.ransac.subset_sz;
-      m.samples.Alloc(m.samples_cap);
-      Hip(hipMemset(m.samples.p, 0, m.samples_cap * sizeof(uint32_t)), "hipMemset");
-    }
-    Hip(hipMemcpy(m.samples.p, h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy");
-  }
+  if (!next) throw std::runtime_error("svc::StreamEncoder: no frame source");
+  const uint32_t B = c.batch;
 
   svc_wire_header header{};
   if (c.wire)
-    Abi(svc_hip_wire_header(n_frames, c.width, c.height, c.mv_block, c.mv_block, c.levels, c.dct_block, c.dct_block, &header),
-        "svc_hip_wire_header");
+    Abi(svc_hip_wire_header(std::max<uint32_t>(header_frame_count, 1), c.width, c.height, c.mv_block, c.mv_block, c.levels, c.dct_block,
+                            c.dct_block, &header), "svc_hip_wire_header");
 
   auto deliver = [&](Slot& s) {
     Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize");
@@ -171,21 +165,24 @@ void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& si
 
   std::vector<Slot*> pending;
   Slot* prev = nullptr;
-  uint32_t lo = 0, first = 1, k = 0;
-  while (lo < n_frames) {
+  uint32_t first = 1, k = 0;
+  bool ended = false;
+  while (!ended) {
     Slot& s = *m.slots[k % c.depth];
     if (s.busy) { Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize"); s.busy = false; }
     const bool carry = prev != nullptr;
-    const uint32_t hi = std::min<uint32_t>(n_frames, lo + (carry ? B : B + 1));
-    const uint32_t n_new = hi - lo, off = carry ? 1 : 0;
-    const uint32_t encoded = carry ? n_new : n_new - 1;
-    // pageable -> pinned, padding each row out to the padded width
-    for (uint32_t f = 0; f < n_new; ++f) {
-      const uint8_t* src = bgr + (size_t)(lo + f) * c.width * c.height * 3;
-      uint8_t* dst = s.pin_in.p + (size_t)(off + f) * m.frame_bytes;
+    const uint32_t want = carry ? B : B + 1, off = carry ? 1 : 0;
+    // source -> pinned, padding each row out to the padded width
+    uint32_t n_new = 0;
+    for (; n_new < want; ++n_new) {
+      const uint8_t* src = next();
+      if (!src) { ended = true; break; }
+      uint8_t* dst = s.pin_in.p + (size_t)(off + n_new) * m.frame_bytes;
       if (m.pw == c.width) std::memcpy(dst, src, (size_t)c.width * c.height * 3);
       else for (uint32_t y = 0; y < c.height; ++y) std::memcpy(dst + (size_t)y * m.pw * 3, src + (size_t)y * c.width * 3, (size_t)c.width * 3);
     }
+    const uint32_t encoded = carry ? n_new : (n_new ? n_new - 1 : 0);
+    if (encoded == 0) break;  // the clip ended on a batch boundary (or had a single frame): nothing left to encode
     Hip(hipMemcpyAsync(s.bgr.p + (size_t)off * m.frame_bytes, s.pin_in.p + (size_t)off * m.frame_bytes,
                        (size_t)n_new * m.frame_bytes, hipMemcpyHostToDevice, m.s_in), "hipMemcpyAsync H2D");
     if (carry) {
@@ -193,30 +190,49 @@ void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& si
       Hip(hipMemcpyAsync(s.bgr.p, prev->bgr.p + (size_t)(prev->frames - 1) * m.frame_bytes, m.frame_bytes,
                          hipMemcpyDeviceToDevice, m.s_in), "hipMemcpyAsync D2D");
     }
+    // RANSAC draws of the batch's pairs: distinct within an iteration, a function of (seed, clip-wide pair, iteration) only
+    // (same generator as the harness: pipeline.ransac_samples), so the clip encodes the same whatever the batch size
+    const uint32_t g0 = first - 1;  // clip-wide index of the batch's first pair
+    {
+      const uint32_t div = std::max<uint32_t>(1, (m.blocks - 1) / std::max<uint32_t>(1, c.ransac.subset_sz));
+      for (size_t q = 0; q < (size_t)encoded * m.iters; ++q) {
+        const uint64_t idx = (uint64_t)g0 * m.iters + q;
+        const uint32_t f0 = Hash32(idx * 0x9E3779B1ull + c.seed) % m.blocks;
+        const uint32_t step = 1 + Hash32(idx * 0x85EBCA6Bull + c.seed + 1) % div;
+        for (uint32_t j = 0; j < c.ransac.subset_sz; ++j)
+          s.pin_samples.p[q * c.ransac.subset_sz + j] = (uint32_t)(((uint64_t)f0 + (uint64_t)step * j) % m.blocks);
+      }
+      Hip(hipMemcpyAsync(s.samples.p, s.pin_samples.p, (size_t)encoded * m.iters * c.ransac.subset_sz * sizeof(uint32_t),
+                         hipMemcpyHostToDevice, m.s_in), "hipMemcpyAsync samples");
+    }
     Hip(hipEventRecord(s.h2d_done, m.s_in), "hipEventRecord");
     s.frames = off + n_new;
 
     // the kernels: always B pairs (a short last batch re-encodes stale frames past its end and drops them)
-    const uint32_t g0 = first - 1;  // clip-wide index of the batch's first pair
     Hip(hipStreamWaitEvent(m.s_compute, s.h2d_done, 0), "hipStreamWaitEvent");
     Abi(svc_hip_luma_pyramid_frames(s.bgr.p, m.frame_bytes, B + 1, m.pw, m.ph, c.levels, s.pyr.p, m.pyr_stride, m.s_compute),
         "svc_hip_luma_pyramid_frames");
     Abi(svc_hip_hbma_pairs(s.pyr.p, s.pyr.p + m.pyr_stride, m.pyr_stride, B, c.levels, m.pw, m.ph, c.search_range,
                            c.mv_block, c.mv_block, s.mv.p, s.mad.p, SVC_HBMA_AUTO, m.s_compute), "svc_hip_hbma_pairs");
     Hip(hipMemsetAsync(s.gm.p, 0, (size_t)B * 2 * sizeof(float), m.s_compute), "hipMemsetAsync");
-    Abi(svc_hip_ransac_frames(s.mv.p, m.blocks, B, c.ransac, m.samples.p + (size_t)g0 * m.iters * c.ransac.subset_sz, m.iters,
+    Abi(svc_hip_ransac_frames(s.mv.p, m.blocks, B, c.ransac, s.samples.p, m.iters,
                               s.gm.p, s.rmse.p, s.mask.p, s.count.p, m.s_compute), "svc_hip_ransac_frames");
     Abi(svc_hip_segment_frames(s.mask.p, s.mv.p, m.mfw, m.mfh, B, c.mv_block, c.mv_block, c.segment,
                                c.seed * 1000003ull + g0, s.seg_ws.p, m.seg_ws_bytes, s.types.p, m.s_compute),
         "svc_hip_segment_frames");
     const uint8_t* enc_bgr = s.bgr.p + m.frame_bytes;  // encoded frame of pair p is source frame p + 1
-    if (c.wire)
+    if (c.wire && m.fused_records) {
       Abi(svc_hip_dct_records_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, s.types.p, c.mv_block, c.mv_block,
-                                     0, 0, m.ph, s.records.p, m.record_bytes, m.s_compute),  // raw: see the header
+                                     0, 0, c.reference_stream ? c.height : m.ph, s.records.p, m.record_bytes, m.s_compute),  // raw: see the header
           "svc_hip_dct_records_frames");
-    else
+    } else if (c.wire) {  // the reference encoder's stream on a padded width: planes, then the serialiser with the reference's own arguments
+      Abi(svc_hip_dct_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, c.dct_block, s.coeffs.p, m.s_compute), "svc_hip_dct_frames");
+      Abi(svc_hip_serialize_frames(s.coeffs.p, m.plane_elems, B, s.types.p, c.width, c.height, c.dct_block, c.dct_block, m.mfw, m.mfh,
+                                   c.mv_block, c.mv_block, s.records.p, m.record_bytes, m.s_compute), "svc_hip_serialize_frames");
+    } else {
       Abi(svc_hip_dct_quant_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, c.dct_block, s.types.p, c.mv_block,
                                    c.mv_block, c.fg_step, c.bg_step, s.coeffs.p, m.s_compute), "svc_hip_dct_quant_frames");
+    }
     Hip(hipEventRecord(s.compute_done, m.s_compute), "hipEventRecord");
 
     Hip(hipStreamWaitEvent(m.s_out, s.compute_done, 0), "hipStreamWaitEvent");
@@ -231,7 +247,7 @@ void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& si
 
     s.busy = true; s.encoded = encoded; s.first = first;
     pending.push_back(&s);
-    prev = &s; lo = hi; first += encoded; ++k;
+    prev = &s; first += encoded; ++k;
     if (pending.size() >= c.depth - 1) { deliver(*pending.front()); pending.erase(pending.begin()); }
   }
   for (Slot* s : pending) deliver(*s);

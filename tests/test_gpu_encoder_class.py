@@ -1,0 +1,116 @@
+"""The drop-in one level above libs/motion.hpp: the reference's `class Encoder` (libs/encoder.hpp:52-95) implemented on
+svc::StreamEncoder (scalable_video_codec_amd/csrc/host/encoder_hip.cpp, compiled against the reference's OWN encoder.hpp) and driven by
+the reference's UNCHANGED apps/encoder.cpp + libs/cli.cpp (tests/dropin/ref_app_svc_encoder[_generic], built by build.py where
+/root/reference exists).  Same command line, same reader / writer threads and queues, same stdout format -- but the per-frame loop is
+the batched GPU pipeline instead of the reference's libs/encoder.cpp.
+
+Checked: the stream (Header + one record block per frame, the reference's unpadded tile loops and row stride included) against the
+oracle run stage by stage with the draws and seeds this Encoder uses (a function of one seed and the frame index, like the harness);
+and that it is the same stream whatever the frame count does to the batching."""
+import os
+import struct
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from scalable_video_codec_amd import pipeline, synth
+from tests.test_gpu_ref_encoder import _check, _write_clip, _write_ppm_stream
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+SEED = 9001
+
+
+def _encode(exe, clip, *args):
+    path = os.path.join(BIN, exe)
+    if not os.path.exists(path):
+        pytest.skip(f"{exe} not built (needs /root/reference at build time)")
+    t0 = time.time()
+    r = subprocess.run([path, *args, str(clip)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, SVC_TEST_ENCODER_SEED=str(SEED)))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout, time.time() - t0
+
+
+def _expected(oracle, frames, levels, tb, mv_block=16, search_range=8, seg=None):
+    """Header + per frame (tile types, tile coefficients): the oracle's stages with THIS Encoder's draws (pipeline.ransac_samples) and
+    segmentation seeds (seed * 1000003 + clip-wide pair index), serialised with the reference's own arguments."""
+    h, w, _ = frames[0].shape
+    pw, ph = synth.padded_dims(w, h, mv_block, mv_block, levels)
+    mfw, mfh = pw // mv_block, ph // mv_block
+    header = struct.pack("<8I", len(frames) - 1, w, h, pw - w, ph - h, tb, tb, 3)
+    padded = []
+    for fr in frames:
+        p = np.zeros((ph, pw, 3), np.uint8)
+        p[:h, :w] = fr
+        padded.append(p)
+    pyrs = [oracle.luma_pyramid(p, levels) for p in padded]
+    rp = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+    iters = oracle.ransac_iter_count(**rp)
+    samples = pipeline.ransac_samples(len(frames) - 1, iters, 1, mfw * mfh, SEED, "cpu").numpy().astype(np.uint32)
+    out = []
+    for t in range(1, len(frames)):
+        mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, mv_block, mv_block)
+        _, _, inliers = oracle.ransac(mv, samples[t - 1].ravel(), **rp)
+        mask = np.zeros(mfw * mfh, np.uint8)
+        mask[inliers] = 1
+        types = oracle.segment(mask, mv, mfw, mfh, mv_block, mv_block, seed=SEED * 1000003 + (t - 1), **(seg or {}))
+        planes = oracle.dct_frame_f32(padded[t], tb, tb)
+        rec = oracle.serialize_frame(planes, types, w, h, tb, tb, mfw, mv_block, mv_block)
+        rec = rec.view(np.uint32).reshape(-1, 1 + 3 * tb * tb)
+        out.append((rec[:, 0].copy(), rec[:, 1:].copy().view(np.float32)))
+    return header, out
+
+
+def test_batched_encoder_class_1080p(native, oracle, tmp_path):
+    """1080p through the reference's unchanged main() with the batched Encoder: 21 frames = one full batch of 16 + a short one."""
+    n = 21
+    clip = synth.SynthClip(1920, 1080, n, seed=0x5C0DEC02)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.svcbgr"
+    _write_clip(path, frames)
+    got, secs = _encode("ref_app_svc_encoder", path, "--verbose", "0")
+    header, expected = _expected(oracle, frames, 4, 8)
+    fg = _check(got, header, expected, 8)
+    assert fg > 0
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "ref_app_svc_encoder.txt"), "w") as f:
+        f.write(f"ref_app_svc_encoder: {n - 1} encoded 1080p frames in {secs:.2f} s (process start to exit), {len(got)} bytes\n")
+
+
+@pytest.mark.parametrize("n", [2, 3, 17, 18, 34])
+def test_batched_encoder_class_any_clip_length(native, oracle, tmp_path, n):
+    """Clip lengths around the batch size (16 encoded frames per batch: 17 frames = exactly one batch, 18 = one frame into the second,
+    2 = a single pair) on a 344 x 280 clip (pads to 352 x 288: the serialiser's unpadded-stride quirk, so the planes + serialiser route)
+    from a PPM stream, with 16 x 16 transform blocks."""
+    clip = synth.SynthClip(344, 280, n, seed=5)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.ppm"
+    _write_ppm_stream(path, frames)
+    got, _ = _encode("ref_app_svc_encoder", path, "--verbose", "0", "--transform-block-w", "16", "--transform-block-h", "16")
+    header, expected = _expected(oracle, frames, 4, 16)
+    _check(got, header, expected, 16)
+
+
+def test_batched_encoder_class_generic_build_and_limits(native, oracle, tmp_path):
+    """The build without -DSVC_MOTION_SSE2: --pyr-lvl-count 3 and 8 x 8 MV blocks from the command line; a single-frame clip is a header
+    and nothing else; non-square blocks are refused with a message that names the route that takes them."""
+    n = 6
+    clip = synth.SynthClip(360, 200, n, seed=11)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.svcbgr"
+    _write_clip(path, frames)
+    args = ["--verbose", "0", "--pyr-lvl-count", "3", "--mv-block-w", "8", "--mv-block-h", "8", "--transform-block-w", "4",
+            "--transform-block-h", "4", "--kmeans-cluster-count", "4"]
+    got, _ = _encode("ref_app_svc_encoder_generic", path, *args)
+    header, expected = _expected(oracle, frames, 3, 4, mv_block=8, seg=dict(cluster_count=4))
+    _check(got, header, expected, 4)
+    one = tmp_path / "one.svcbgr"
+    _write_clip(one, frames[:1])
+    got, _ = _encode("ref_app_svc_encoder_generic", one, "--verbose", "0")
+    assert len(got) == 32 and struct.unpack("<3I", got[:12]) == (0, 360, 200)
+    exe = os.path.join(BIN, "ref_app_svc_encoder_generic")
+    r = subprocess.run([exe, "--verbose", "0", "--mv-block-w", "32", "--mv-block-h", "16", str(path)], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"square" in r.stderr and b"compat/opencv2" in r.stderr

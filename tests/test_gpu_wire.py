@@ -123,3 +123,11 @@ def test_fused_records_full_clip_c3(native):
     got = native.dct_records_frames(enc.bgr[1:], 8, enc.types, 16, cfg.fg_step, cfg.bg_step, emit_h=cfg.height)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_frame_not_divisible_by_the_transform_block(native, oracle):
+    """What the reference's Release build emits for a 344 x 280 frame (padded to 352 x 288) with 16 x 16 transform blocks: its assert
+    on divisibility (libs/encoder.cpp:230-231) is compiled out, the loops run over ceil(344 / 16) x ceil(280 / 16) tiles and the last
+    tile column reads through the unpadded-stride quirk.  Bug-compatible bytes against the literal restatement."""
+    _case(native, oracle, 352, 288, 344, 280, 16, 16, frames=2, seed=8)
+    _case(native, oracle, 352, 288, 346, 282, 8, 8, frames=1, seed=9)
