@@ -264,11 +264,12 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
             if cfg.dct_block == 0:
                 raise RuntimeError("this configuration has no transform")
             times = {}
-            for n in (9, min(len(src), 65)):
+            for n in (33, 225):  # long enough for the difference to stand above the ~1 s of start-up (1.6 GB of pinned buffers)
                 path = os.path.join(d, f"clip{n}.svcbgr")
                 with open(path, "wb") as f:
                     f.write(b"SVCBGR1\0" + np.array([cfg.width, cfg.height, n, 0], np.uint32).tobytes())
-                    src[:n].tofile(f)
+                    for lo in range(0, n, len(src)):  # the sample frames, repeated
+                        src[:min(len(src), n - lo)].tofile(f)
                 t0 = time.perf_counter()
                 with open(os.devnull, "wb") as sink:
                     r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600)
@@ -280,7 +281,7 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
             out["reference_application_batched_encoder_fps"] = (n2 - n1) / max(t2 - t1, 1e-9)
             out["reference_application_batched_encoder_sample"] = (
                 f"{os.path.basename(exe)} (the reference's unchanged apps/encoder.cpp + libs/cli.cpp, class Encoder = csrc/host/encoder_hip.cpp on "
-                f"svc::StreamEncoder): {n1} and {n2} frame clips, stdout to /dev/null; ({n2} - {n1}) frames / ({t2:.2f} - {t1:.2f}) s")
+                f"svc::StreamEncoder): {n1} and {n2} frame clips (the sample frames repeated), stdout to /dev/null; ({n2} - {n1}) frames / ({t2:.2f} - {t1:.2f}) s")
         except Exception as e:  # noqa: BLE001
             out["reference_application_batched_encoder_fps"] = None
             out["reference_application_batched_encoder_note"] = f"not measured: {e}"
@@ -404,7 +405,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     for j in range(info.frames):
         enc.load_frames(synth.pad_frame(src.frame_bgr(info.first_frame + j), pw, ph).unsqueeze(0).contiguous(), j)
     sample_frames = [synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(min(info.frames, 129))] \
-        if (rank == 0 and mode == "strong" and world == 1 and not args.no_cpu_baseline) else None
+        if (rank == 0 and mode == "strong" and world == 1 and not (args.no_cpu_baseline and args.no_end_to_end)) else None
     del src
     halo = None
     halo_check = None
@@ -734,7 +735,7 @@ def main() -> None:
                                              "note": "svc_hip_probe_stream on this GPU, context only; roofline fractions are against the 8 TB/s peak"}
         if r["sample_frames"] is not None and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_rates(cfg, r["sample_frames"])
-        if r["sample_frames"] is not None:
+        if r["sample_frames"] is not None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, r["sample_frames"])
             cb = out["cpu_baseline"]
             if cb.get("hbma_ms_per_frame") and "hbma" in kt:
