@@ -13,6 +13,7 @@
 //
 // Scope: square MV blocks and square transform blocks (what svc::StreamEncoder batches); the general case -- non-square
 // blocks -- runs through the reference's own libs/encoder.cpp over compat/opencv2.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -111,6 +112,9 @@ void Encoder::operator()() {
   c.mv_block = cfg_.mv_block_w;
   c.search_range = cfg_.mv_search_range;
   c.dct_block = cfg_.transform_block_w;
+  // sixteen frames per batch; fewer when the container says the clip is shorter (the pinned buffers of a batch are 31 MB per frame at
+  // 1080p, and page-locking them is most of a short run's start-up)
+  c.batch = vidprops_.frame_count > 1 ? std::min<uint32_t>(16u, vidprops_.frame_count - 1) : 16u;
   c.wire = true;
   c.reference_stream = true;  // the bytes SerializeEncodedFrame emits for the reference's arguments (libs/encoder.cpp:647-650)
   c.ransac = svc_ransac_params{cfg_.ransac.subset_sz, cfg_.ransac.inlier_thresh, cfg_.ransac.success_prob, cfg_.ransac.inlier_ratio};

@@ -123,6 +123,29 @@ void OraclePart() {
     std::vector<float> c(1001);
     for (auto& v : c) v = (float)(Rnd() % 4000) - 2000.0f;
     svc_oracle_quant(c.data(), c.size(), 640);
+    // the per-call statements (oracle/svc_imageops.c) and the CPU baseline's transform (oracle/svc_cpu_dct.c), exactly-sized buffers
+    std::vector<uint8_t> yuv(bgr.size());
+    svc_oracle_bgr2yuv(bgr.data(), w, h, yuv.data());
+    std::vector<uint8_t> img(n), out8(n);
+    for (auto& v : img) v = (Rnd() % 3) ? 255 : 0;
+    for (uint32_t op = 0; op < 4; ++op) svc_oracle_morph_rect(img.data(), mfw, mfh, 3, 2, op, out8.data());
+    svc_oracle_morph_rect(img.data(), mfw, mfh, 9, 9, 3, img.data());  // in place, element larger than the image
+    std::vector<int32_t> lab(n);
+    for (uint32_t conn : {4u, 8u}) CHECK(svc_oracle_connected_components(img.data(), mfw, mfh, conn, lab.data()) >= 1);
+    std::vector<float> feats((size_t)n * 4, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) { feats[4 * i + 1] = (float)(Rnd() % 17) - 8; feats[4 * i + 2] = (float)((i % mfw) * 16); feats[4 * i + 3] = (float)((i / mfw) * 16); }
+    double compact = 0;
+    CHECK(svc_oracle_kmeans(feats.data(), n, 4, 10, 3, 10, 1.0f, 7, lab.data(), &compact) == 0 && compact >= 0);
+    CHECK(svc_oracle_kmeans(feats.data(), n, 4, n, 1, 2, 1.0f, 7, lab.data(), nullptr) == (n <= 255 ? 0 : 1));  // as many clusters as points
+    feats[5] = 0.5f;
+    CHECK(svc_oracle_kmeans(feats.data(), n, 4, 3, 1, 2, 1.0f, 7, lab.data(), nullptr) == 1);  // not an integer: outside the definition
+    for (uint32_t blk : {8u, 16u}) {
+      std::vector<float> p32((size_t)3 * w * h);
+      CHECK(svc_cpu_dct_frame_f32(bgr.data(), w, h, blk, p32.data()) == 0);
+      svc_cpu_quant_frame_f32(p32.data(), w, h, 16, 16, types.data(), 3, 640);
+    }
+    std::vector<float> p32((size_t)3 * w * h);
+    CHECK(svc_cpu_dct_frame_f32(bgr.data(), w, h, 4, p32.data()) == 1 && svc_cpu_dct_isa() >= 0);
   }
 }
 

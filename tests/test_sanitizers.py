@@ -33,6 +33,31 @@ def test_host_side_is_clean_under_asan_and_ubsan():
     assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-4000:]
 
 
+@pytest.mark.timeout(1200)
+def test_compat_adapter_host_side_is_clean(tmp_path):
+    """compat/opencv2 under the same sanitizers: the matrix semantics program of tests/test_compat_host.py (sharing, views, create()
+    reuse, the buffer pool, copyMakeBorder / split / convertTo / extractChannel, both clip containers)."""
+    import struct
+    import numpy as np
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc: the sanitized host build needs the ROCm clang")
+    _make("compat")
+    frames = [((np.arange(4 * 6 * 3) + 50 * t) & 255).astype(np.uint8).reshape(4, 6, 3) for t in range(3)]
+    raw, ppm = tmp_path / "c.svcbgr", tmp_path / "c.ppm"
+    with open(raw, "wb") as f:
+        f.write(b"SVCBGR1\0" + struct.pack("<4I", 6, 4, 3, 0))
+        for fr in frames:
+            f.write(fr.tobytes())
+    with open(ppm, "wb") as f:
+        for fr in frames:
+            f.write(b"P6\n6 4\n255\n" + np.ascontiguousarray(fr[..., ::-1]).tobytes())
+    r = subprocess.run([os.path.join(SAN, "_build", "compat_host_asan"), str(raw), str(ppm)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "compat host semantics ok" in r.stdout, out[-4000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-4000:]
+
+
 @pytest.mark.timeout(600)
 def test_reference_ransac_reads_past_its_field():
     if not os.path.exists("/root/reference/libs/motion.cpp") or not os.path.exists(HIPCC):
