@@ -103,7 +103,8 @@ def test_hbma_kernel_choice_is_queryable():
     assert name(4, 1920, 1088, 8) == "hbma_tiled16_kernel"       # C3b
     assert name(3, 1920, 1088, 8) == "hbma_fused_kernel"         # C3 (headline): lane per block
     assert name(4, 1920, 1088, 16) == "hbma_fused_kernel"        # r_top 2
-    assert name(4, 1936, 1088, 8) == "hbma_wave_level_kernel"    # top plane width not a multiple of 4
+    assert name(4, 1936, 1088, 8) == "hbma_fused_kernel"         # top plane 242 wide, not whole dwords: taken since round 4 (2 x 2 top blocks)
+    assert name(4, 720, 576, 8) == "hbma_fused_kernel"           # PAL with the reference's default build
     assert name(1, 352, 288, 8) == "hbma_wave_level_kernel"      # C1: one level is EBMA-shaped
     assert name(3, 1920, 1088, 8, 8, 8) == "hbma_fused_kernel"
     assert name(3, 1920, 1088, 8, 16, 8) == "hbma_wave_level_kernel"   # non-square blocks
@@ -111,7 +112,7 @@ def test_hbma_kernel_choice_is_queryable():
     assert name(4, 3840, 2160, 8, flags=native.HBMA_FORCE_WAVE_PER_BLOCK) == "hbma_wave_level_kernel"
     assert name(4, 3840, 2160, 8, flags=native.HBMA_FORCE_TILED) == "hbma_tiled16_kernel"
     for args, flags, status in (((3, 1920, 1088, 8), native.HBMA_FORCE_TILED, native.SVC_ERR_UNSUPPORTED),
-                                ((4, 1936, 1088, 8), native.HBMA_FORCE_LANE, native.SVC_ERR_UNSUPPORTED),
+                                ((3, 1920, 1088, 8, 16, 8), native.HBMA_FORCE_LANE, native.SVC_ERR_UNSUPPORTED),   # non-square blocks
                                 ((4, 1920, 1080, 8), native.HBMA_AUTO, native.SVC_ERR_INVALID_ARG),     # 1080 % 16
                                 ((5, 1920, 1088, 8), native.HBMA_AUTO, native.SVC_ERR_INVALID_ARG)):    # range < 2^(L-1)
         with pytest.raises(native.SvcError) as e:
