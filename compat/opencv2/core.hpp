@@ -37,10 +37,6 @@ template <typename T> void split(const Mat& src, std::vector<Mat_<T>>& mv) {
 // with every other pending one in a single GPU launch (svc_hip_dct_tiles_host) when the data is next looked at; see
 // detail::Buffer in core/mat.hpp.  A matrix over caller-owned memory is transformed at once.
 void dct(const Mat& src, Mat& dst, int flags = 0);
-template <typename T> void dct(const Mat_<T>& src, const Mat_<T>& dst, int flags = 0) {  // `cv::dct(block, block)` on views
-  Mat d = dst;  // OutputArray semantics: the header is a handle, the storage is what is written
-  dct(static_cast<const Mat&>(src), d, flags);
-}
 
 // cv::theRNG(): OpenCV's per-thread multiply-with-carry generator.  cv::kmeans takes its seed from it.
 struct RNG {

@@ -128,7 +128,9 @@ struct Buffer {
   uchar* base = nullptr;
   size_t bytes = 0, step = 0;  // step: row pitch of the allocation this buffer was created for
   int rows = 0, cols = 0, type = 0;
-  std::vector<DeferredDct> pending;
+  std::vector<DeferredDct> pending;  // invariant: one tile shape, origins on that shape's grid, in strictly increasing raster order
+                                     // -- so no two collected calls overlap and running them together equals running them in turn
+  uint64_t last_key = 0;             // (y << 32 | x) + 1 of the newest collected tile
   Buffer(int rows_, int cols_, int type_);
   ~Buffer();
   Buffer(const Buffer&) = delete;

@@ -124,6 +124,7 @@ void Flush(Buffer& b) {
   Timed timed("cv::dct (flush: GPU)");
   std::vector<DeferredDct> todo;
   todo.swap(b.pending);  // first: anything below that touches a Mat over this buffer must not recurse
+  b.last_key = 0;
   if (CV_MAT_DEPTH(b.type) != CV_32F || CV_MAT_CN(b.type) != 1) Fail("cv::dct", "only single-channel 32-bit float matrices");
   std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> by_shape;
   for (const DeferredDct& t : todo) {
@@ -361,7 +362,17 @@ void dct(const Mat& src, Mat& dst, int flags) {
   detail::Buffer* b = dst.compat_buffer();
   if (b && dst.step == b->step && CV_MAT_DEPTH(b->type) == CV_32F && CV_MAT_CN(b->type) == 1) {
     const size_t off = (size_t)(dst.data - b->base);
-    b->pending.push_back({(uint32_t)((off % b->step) / sizeof(float)), (uint32_t)(off / b->step), (uint32_t)dst.cols, (uint32_t)dst.rows});
+    const detail::DeferredDct t{(uint32_t)((off % b->step) / sizeof(float)), (uint32_t)(off / b->step), (uint32_t)dst.cols, (uint32_t)dst.rows};
+    // Collected calls run TOGETHER, so they must not depend on each other: a call is only added to a list of tiles of its own
+    // shape, on that shape's grid, and further on in raster order than every tile already there (the reference's loops,
+    // libs/encoder.cpp:330-337, issue exactly that) -- anything else (another shape, an off-grid tile, a tile issued twice
+    // or out of order) first runs what has been collected, so that it sees those results as OpenCV's eager cv::dct would.
+    const uint64_t key = (((uint64_t)t.y << 32) | t.x) + 1;
+    const bool on_grid = t.x % t.w == 0 && t.y % t.h == 0;
+    if (!b->pending.empty() && (b->pending[0].w != t.w || b->pending[0].h != t.h || !on_grid || key <= b->last_key)) detail::Flush(*b);
+    b->pending.push_back(t);
+    b->last_key = key;
+    if (!on_grid) detail::Flush(*b);  // runs alone
     return;
   }
   // caller-owned memory (or a view of a multi-channel allocation): nothing to hang the call on -- run it now
