@@ -14,6 +14,7 @@
 // Scope: square MV blocks and square transform blocks (what svc::StreamEncoder batches); the general case -- non-square
 // blocks -- runs through the reference's own libs/encoder.cpp over compat/opencv2.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -137,7 +138,10 @@ void Encoder::operator()() {
   }
 
   try {
-    svc::StreamEncoder enc(c);
+    const auto t_begin = std::chrono::steady_clock::now();
+    svc::StreamEncoder enc(c);  // page-locks the batch buffers: most of a short run's time
+    const auto t_ready = std::chrono::steady_clock::now();
+    uint64_t encoded_frames = 0;
     cv::Mat3b frame;  // keeps the frame handed to the encoder alive until it asks for the next one
     const size_t want = (size_t)vidprops_.frame_w * vidprops_.frame_h * 3;
     auto next = [&]() -> const uint8_t* {
@@ -154,8 +158,15 @@ void Encoder::operator()() {
         const uint8_t* r = b.records + (size_t)i * b.record_bytes;
         out_queue_.Push(std::vector<uchar>(r, r + b.record_bytes));  // one vector per frame, as the reference pushes them (:652)
       }
+      encoded_frames += b.count;
     };
     enc.Encode(next, vidprops_.frame_count, sink);
+    if (std::getenv("SVC_ENCODER_REPORT")) {  // what bench.py's end_to_end object reads: the loop's own clock, start-up apart
+      const double setup = std::chrono::duration<double>(t_ready - t_begin).count();
+      const double loop = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count();
+      std::fprintf(stderr, "svc Encoder: %llu frames encoded in %.4f s (%.1f frames/s) after %.3f s of set-up; batch %u\n",
+                   (unsigned long long)encoded_frames, loop, loop > 0 ? encoded_frames / loop : 0.0, setup, c.batch);
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "svc Encoder: %s\n", e.what());
     Die();
