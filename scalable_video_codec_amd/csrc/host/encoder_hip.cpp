@@ -13,6 +13,8 @@
 //
 // Scope: square MV blocks and square transform blocks (what svc::StreamEncoder batches); the general case -- non-square
 // blocks -- runs through the reference's own libs/encoder.cpp over compat/opencv2.
+#include <malloc.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -137,6 +139,11 @@ void Encoder::operator()() {
     out_queue_.Push(std::vector<uchar>(p, p + sizeof(h)));
   }
 
+  // Every encoded frame leaves as a fresh 25 MB std::vector (the queue's element type, libs/encoder.hpp:57) that the writer thread frees
+  // a moment later.  glibc serves such sizes with mmap / munmap -- a page fault per 4 KB on every frame; keeping them on the heap
+  // lets the next frame reuse the block the writer just returned.
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
   try {
     const auto t_begin = std::chrono::steady_clock::now();
     svc::StreamEncoder enc(c);  // page-locks the batch buffers: most of a short run's time
