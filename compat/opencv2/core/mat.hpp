@@ -131,7 +131,9 @@ struct Buffer {
   std::vector<DeferredDct> pending;  // invariant: one tile shape, origins on that shape's grid, in strictly increasing raster order
                                      // -- so no two collected calls overlap and running them together equals running them in turn
   uint64_t last_key = 0;             // (y << 32 | x) + 1 of the newest collected tile
+  std::shared_ptr<void> keeps;        // set for storage this buffer does not own (a mapped clip file): what keeps it alive
   Buffer(int rows_, int cols_, int type_);
+  Buffer(uchar* memory, int rows_, int cols_, int type_, std::shared_ptr<void> keeps_);  // videoio.cpp: a frame where the file is mapped
   ~Buffer();
   Buffer(const Buffer&) = delete;
   Buffer& operator=(const Buffer&) = delete;
@@ -201,6 +203,7 @@ class Mat {
 
   void sync() const { if (buf_ && !buf_->pending.empty()) detail::Flush(*buf_); }
   detail::Buffer* compat_buffer() const { return buf_.get(); }  // adapter-internal (core.cpp / imgproc.cpp)
+  static Mat compat_over(std::shared_ptr<detail::Buffer> b);    // adapter-internal (videoio.cpp): a header over a ready buffer
 
   // OpenCV's public fields
   int flags = 0;  // the type code (OpenCV keeps more bits here; only the type is modelled)

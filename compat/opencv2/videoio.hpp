@@ -8,6 +8,7 @@
 #define SVC_COMPAT_OPENCV2_VIDEOIO_HPP
 
 #include <cstdio>
+#include <memory>
 #include <string>
 
 #include "opencv2/core/mat.hpp"
@@ -29,8 +30,11 @@ class VideoCapture {
   bool isOpened() const { return f_ != nullptr; }
   void release();
   double get(int propId) const;
-  // Every frame lands in a FRESH allocation: apps/encoder.cpp:139-145 pushes the same cv::Mat3b header into its queue
-  // after each read, and a header shares its storage -- reusing the allocation would overwrite frames still queued.
+  // Every frame is storage of its own: apps/encoder.cpp:139-145 pushes the same cv::Mat3b header into its queue after
+  // each read, and a header shares its storage -- reusing an allocation would overwrite frames still queued.  A frame of
+  // an SVCBGR1 file is a header over the file where it is MAPPED (private, copy-on-write: writable like any matrix, the
+  // file never changes): no copy at all on the reader's thread, and the mapping lives as long as any frame does.  PPM
+  // frames (channel order swapped) are read into a fresh allocation.
   bool read(Mat& image);
   VideoCapture& operator>>(Mat& image) { read(image); return *this; }
 
@@ -38,6 +42,8 @@ class VideoCapture {
   std::FILE* f_ = nullptr;
   int w_ = 0, h_ = 0, count_ = 0, pos_ = 0;
   bool ppm_ = false;
+  std::shared_ptr<void> map_;  // the whole SVCBGR1 file; null for PPM streams or where mapping failed (then: fread)
+  size_t map_bytes_ = 0;
 };
 
 }  // namespace cv

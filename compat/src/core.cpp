@@ -116,7 +116,15 @@ Buffer::Buffer(int rows_, int cols_, int type_) : rows(rows_), cols(cols_), type
   if (!base) Fail("cv::Mat::create", "out of memory");
 }
 
-Buffer::~Buffer() { ThePool().Give(base, Rounded(bytes)); }  // cv::dct calls still collected die with the data nobody looked at
+Buffer::Buffer(uchar* memory, int rows_, int cols_, int type_, std::shared_ptr<void> keeps_)
+    : base(memory), rows(rows_), cols(cols_), type(type_), keeps(std::move(keeps_)) {
+  step = (size_t)cols_ * ElemSize(type_);
+  bytes = step * (size_t)rows_;
+}
+
+Buffer::~Buffer() {
+  if (!keeps) ThePool().Give(base, Rounded(bytes));
+}  // cv::dct calls still collected die with the data nobody looked at
 
 // Executes the collected cv::dct calls of one allocation: one svc_hip_dct_tiles_host per tile shape (the reference
 // issues a single shape per plane).  The regular full grid -- what libs/encoder.cpp:330-337 produces -- needs no list.
@@ -147,6 +155,18 @@ void Flush(Buffer& b) {
 }  // namespace detail
 
 // ---- Mat -------------------------------------------------------------------------------------------------------------
+Mat Mat::compat_over(std::shared_ptr<detail::Buffer> b) {
+  Mat m;
+  m.flags = b->type;
+  m.dims = 2;
+  m.rows = b->rows;
+  m.cols = b->cols;
+  m.step = b->step;
+  m.data = b->base;
+  m.buf_ = std::move(b);
+  return m;
+}
+
 void Mat::create(int rows_, int cols_, int type_) {
   type_ &= 4095;
   if (rows_ < 0 || cols_ < 0) detail::Fail("cv::Mat::create", "negative size");

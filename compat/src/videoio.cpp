@@ -1,5 +1,8 @@
 // compat/src/videoio.cpp -- cv::VideoCapture over uncompressed clips (see compat/opencv2/videoio.hpp).
 // PRODUCT-SIDE ADAPTER, NOT AN ORACLE (see compat/opencv2/core/mat.hpp).
+#include <sys/mman.h>
+#include <sys/stat.h>
+
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -10,6 +13,8 @@
 namespace cv {
 
 namespace {
+
+constexpr size_t kRawHeader = 24;  // "SVCBGR1\0" + four u32
 
 // one PPM header token (whitespace- and '#'-comment-separated); false at end of file
 bool PpmToken(std::FILE* f, long* out) {
@@ -48,6 +53,16 @@ bool VideoCapture::open(const String& filename) {
     if (std::fread(hdr, 4, 4, f) != 4 || hdr[0] == 0 || hdr[1] == 0 || hdr[0] > 65535 || hdr[1] > 65535) { std::fclose(f); return false; }
     w_ = (int)hdr[0]; h_ = (int)hdr[1]; count_ = (int)hdr[2];
     ppm_ = false;
+    struct stat st;
+    if (fstat(fileno(f), &st) == 0 && st.st_size > (off_t)kRawHeader) {
+      const size_t n = (size_t)st.st_size;
+      void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE, fileno(f), 0);
+      if (m != MAP_FAILED) {
+        madvise(m, n, MADV_SEQUENTIAL);
+        map_ = std::shared_ptr<void>(m, [n](void* p) { munmap(p, n); });
+        map_bytes_ = n;
+      }
+    }
   } else {
     std::rewind(f);
     if (!PpmHeader(f, &w_, &h_)) { std::fclose(f); return false; }
@@ -66,6 +81,8 @@ bool VideoCapture::open(const String& filename) {
 void VideoCapture::release() {
   if (f_) std::fclose(f_);
   f_ = nullptr;
+  map_.reset();  // frames still alive keep the mapping
+  map_bytes_ = 0;
   w_ = h_ = count_ = pos_ = 0;
 }
 
@@ -86,8 +103,21 @@ bool VideoCapture::read(Mat& image) {
     int w = 0, h = 0;
     if (!PpmHeader(f_, &w, &h) || w != w_ || h != h_) { image.release(); return false; }
   }
-  Mat frame(h_, w_, CV_8UC3);  // a fresh allocation per frame: queued headers keep theirs
   const size_t bytes = (size_t)w_ * h_ * 3;
+  if (map_) {
+    const size_t at = kRawHeader + (size_t)pos_ * bytes;
+    if (at + bytes > map_bytes_) { image.release(); return false; }  // the end of the file (whatever the header's count says)
+#ifdef MADV_POPULATE_READ
+    {  // map the frame's pages here, on the reader's thread, rather than by page faults under whoever reads the frame first
+      const uintptr_t lo = (reinterpret_cast<uintptr_t>(map_.get()) + at) & ~(uintptr_t)4095;
+      madvise(reinterpret_cast<void*>(lo), reinterpret_cast<uintptr_t>(map_.get()) + at + bytes - lo, MADV_POPULATE_READ);  // best effort
+    }
+#endif
+    image = Mat::compat_over(std::make_shared<detail::Buffer>(static_cast<uchar*>(map_.get()) + at, h_, w_, CV_8UC3, map_));
+    ++pos_;
+    return true;
+  }
+  Mat frame(h_, w_, CV_8UC3);  // a fresh allocation per frame: queued headers keep theirs
   if (std::fread(frame.data, 1, bytes, f_) != bytes) { image.release(); return false; }
   if (ppm_)
     for (size_t i = 0; i < bytes; i += 3) { const uchar t = frame.data[i]; frame.data[i] = frame.data[i + 2]; frame.data[i + 2] = t; }

@@ -3,6 +3,7 @@
 // Built and run by tests/test_compat_host.py.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -116,6 +117,35 @@ int main(int argc, char** argv) {
       ++n;
     }
     CHECK(n == 3 && !b.read(fb));
+    {  // SVCBGR1 frames are headers over the file where it is mapped: writable (copy-on-write, the file never changes), alive after the
+       // capture has gone, and the file's real length -- not the header's count -- ends the clip
+      Mat3b kept;
+      {
+        VideoCapture c(argv[1]);
+        CHECK(c.read(kept));
+        kept(0, 0)[0] = 77;
+        Mat3b again;
+        VideoCapture d(argv[1]);
+        CHECK(d.read(again) && again(0, 0)[0] == 0 && again.data != kept.data);  // neither the file nor another mapping saw the write
+      }
+      CHECK(kept(0, 0)[0] == 77 && kept(1, 2)[0] == (uchar)(1 * 6 * 3 + 2 * 3));
+      Mat3b copy = kept.clone();
+      CHECK(copy.data != kept.data && std::memcmp(copy.data, kept.data, 72) == 0);
+      const std::string cut = std::string(argv[1]) + ".cut";
+      std::FILE* in = std::fopen(argv[1], "rb");
+      std::FILE* out = std::fopen(cut.c_str(), "wb");
+      CHECK(in && out);
+      if (in && out) {
+        char bytes[24 + 72 + 40];  // the header (which still says 3 frames), one whole frame and a piece of the second
+        CHECK(std::fread(bytes, 1, sizeof(bytes), in) == sizeof(bytes) && std::fwrite(bytes, 1, sizeof(bytes), out) == sizeof(bytes));
+        std::fclose(in);
+        std::fclose(out);
+        VideoCapture e(cut);
+        Mat3b f;
+        CHECK(e.isOpened() && e.get(CAP_PROP_FRAME_COUNT) == 3 && e.read(f) && f(0, 0)[0] == 0 && !e.read(f) && f.empty());
+        std::remove(cut.c_str());
+      }
+    }
     VideoCapture none("/nonexistent/clip");
     CHECK(!none.isOpened());
   }
