@@ -40,6 +40,7 @@ struct StreamEncoderConfig {
                                    // apps/encoder.cpp writes to stdout; record_bytes then counts the unpadded tile grid
   uint32_t batch = 16;             // encoded frames per batch
   uint32_t depth = 3;              // batches in flight, >= 3 (H2D, kernels and D2H of three batches overlap)
+  uint32_t copy_threads = 4;       // threads that move a source frame into the pinned batch buffer (the caller's included; 1 = the caller alone)
   uint64_t seed = 0;
   svc_ransac_params ransac{1, 7.5f, 0.99f, 0.5f};
   svc_segment_params segment{3, 3, 10, 3, 10, 1.0f, 4};

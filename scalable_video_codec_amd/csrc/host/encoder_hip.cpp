@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <random>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -144,6 +145,7 @@ void Encoder::operator()() {
   // lets the next frame reuse the block the writer just returned.
   mallopt(M_MMAP_THRESHOLD, 1 << 30);
   mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_ARENA_MAX, 1);  // ... whichever thread fills it: one heap for the copy helpers below, this thread and the writer
   try {
     const auto t_begin = std::chrono::steady_clock::now();
     svc::StreamEncoder enc(c);  // page-locks the batch buffers: most of a short run's time
@@ -151,8 +153,14 @@ void Encoder::operator()() {
     uint64_t encoded_frames = 0;
     cv::Mat3b frame;  // keeps the frame handed to the encoder alive until it asks for the next one
     const size_t want = (size_t)vidprops_.frame_w * vidprops_.frame_h * 3;
+    double wait_reader = 0, wait_helpers = 0, wait_writer = 0;  // seconds this thread spent blocked on each neighbour (SVC_ENCODER_REPORT)
+    auto clock = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(clock() - t).count(); };
     auto next = [&]() -> const uint8_t* {
-      if (!in_queue_.Pop(frame)) return nullptr;  // queue empty and the reader is done
+      const auto t0 = clock();
+      const bool more = in_queue_.Pop(frame);
+      wait_reader += since(t0);
+      if (!more) return nullptr;  // queue empty and the reader is done
       if (frame.empty() || (size_t)frame.rows * frame.cols * 3 != want || !frame.isContinuous()) {
         std::fprintf(stderr, "svc Encoder: a frame of %d x %d does not match the capture's %u x %u\n", frame.cols, frame.rows,
                      vidprops_.frame_w, vidprops_.frame_h);
@@ -160,19 +168,48 @@ void Encoder::operator()() {
       }
       return frame.data;
     };
+    // One vector per frame, as the reference pushes them (:652).  Filling a 25 MB vector from the pinned batch buffer is 1.2 ms of one
+    // core -- more than a frame's share of everything else this thread does -- so a batch's vectors are filled by a few helper threads
+    // while this thread goes on staging the next batch's source frames; they are pushed, in clip order, when the next batch is
+    // delivered (a delivered batch's buffers stay valid until the following delivery returns, include/svc/stream_encoder.hpp).
+    const uint32_t copiers = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    std::vector<std::vector<uchar>> filled;
+    std::vector<std::thread> helpers;
+    struct JoinAll {  // an exception on its way out of Encode must not meet a running thread
+      std::vector<std::thread>& threads;
+      ~JoinAll() { for (auto& t : threads) if (t.joinable()) t.join(); }
+    } join_all{helpers};
+    auto push_filled = [&]() {
+      auto t0 = clock();
+      for (auto& h : helpers) h.join();
+      wait_helpers += since(t0);
+      helpers.clear();
+      t0 = clock();
+      for (auto& v : filled) out_queue_.Push(std::move(v));
+      wait_writer += since(t0);
+      encoded_frames += filled.size();
+      filled.clear();
+    };
     auto sink = [&](const svc::EncodedBatch& b) {
-      for (uint32_t i = 0; i < b.count; ++i) {
-        const uint8_t* r = b.records + (size_t)i * b.record_bytes;
-        out_queue_.Push(std::vector<uchar>(r, r + b.record_bytes));  // one vector per frame, as the reference pushes them (:652)
-      }
-      encoded_frames += b.count;
+      push_filled();  // the previous batch
+      filled.resize(b.count);
+      const uint8_t* records = b.records;
+      const uint64_t bytes = b.record_bytes;
+      const uint32_t count = b.count;
+      for (uint32_t t = 0; t < copiers && t < count; ++t)
+        helpers.emplace_back([&filled, records, bytes, count, copiers, t]() {
+          for (uint32_t i = t; i < count; i += copiers) filled[i] = std::vector<uchar>(records + (size_t)i * bytes, records + (size_t)(i + 1) * bytes);
+        });
     };
     enc.Encode(next, vidprops_.frame_count, sink);
+    push_filled();  // the last batch
     if (std::getenv("SVC_ENCODER_REPORT")) {  // what bench.py's end_to_end object reads: the loop's own clock, start-up apart
       const double setup = std::chrono::duration<double>(t_ready - t_begin).count();
       const double loop = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count();
-      std::fprintf(stderr, "svc Encoder: %llu frames encoded in %.4f s (%.1f frames/s) after %.3f s of set-up; batch %u\n",
-                   (unsigned long long)encoded_frames, loop, loop > 0 ? encoded_frames / loop : 0.0, setup, c.batch);
+      std::fprintf(stderr, "svc Encoder: %llu frames encoded in %.4f s (%.1f frames/s) after %.3f s of set-up; batch %u; this thread waited "
+                   "%.3f s for the reader, %.3f s for its copy helpers, %.3f s for the writer's queue\n",
+                   (unsigned long long)encoded_frames, loop, loop > 0 ? encoded_frames / loop : 0.0, setup, c.batch, wait_reader, wait_helpers,
+                   wait_writer);
     }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "svc Encoder: %s\n", e.what());
