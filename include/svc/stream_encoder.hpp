@@ -26,9 +26,11 @@ namespace svc {
 struct StreamEncoderConfig {
   uint32_t width = 0, height = 0;  // source frame size; padded as libs/encoder.cpp:164-168 does
   uint32_t levels = 3;             // pyr-lvl-count
-  uint32_t mv_block = 16;          // apps/encoder.cpp:28-58 defaults from here on
+  uint32_t mv_block = 16;          // MV block width (and height, unless mv_block_h is set); apps/encoder.cpp:28-58 defaults from here on
   uint32_t search_range = 8;
-  uint32_t dct_block = 8;          // transform block, 8 or 16
+  uint32_t dct_block = 8;          // transform block width (and height, unless dct_block_h is set): anything the C ABI's Dct takes
+  uint32_t mv_block_h = 0;         // non-square blocks (--mv-block-h / --transform-block-h differing from the widths): 0 = square.
+  uint32_t dct_block_h = 0;        // Non-square transform blocks with `wire` take the planes + serialiser route (the fused record kernel is square)
   uint32_t fg_step = 1, bg_step = 640;  // apps/decoder.cpp:22-23
   bool wire = false;               // serialised records (libs/encoder.cpp:222-269) instead of planes: RAW
                                    // coefficients, as the reference's encoder emits them (the decoder picks the

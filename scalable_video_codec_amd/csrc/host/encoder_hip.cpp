@@ -11,8 +11,8 @@
 // the two queues carry.  RANSAC draws and k-means seeds come from one seed (std::random_device unless SvcEncoderSeed() was
 // called), as the reference's come from its own generators: two runs of the reference differ in region ids the same way.
 //
-// Scope: square MV blocks and square transform blocks (what svc::StreamEncoder batches); the general case -- non-square
-// blocks -- runs through the reference's own libs/encoder.cpp over compat/opencv2.
+// Scope: every configuration the reference's Validate admits -- non-square MV and transform blocks included (those take the per-level
+// search kernel and the planes + serialiser route instead of the tuned ones).
 #include <malloc.h>
 
 #include <algorithm>
@@ -104,18 +104,12 @@ void Encoder::operator()() {
   attempted_first_frame_read_.wait();
   if (in_queue_.IsEmpty()) return;  // the reader found no frame: no output at all (libs/encoder.cpp:344-348)
 
-  if (cfg_.mv_block_w != cfg_.mv_block_h || cfg_.transform_block_w != cfg_.transform_block_h) {
-    std::fprintf(stderr, "svc Encoder (batched GPU form): square MV and transform blocks only (got %ux%u / %ux%u); the general case runs "
-                         "through the reference's libs/encoder.cpp over compat/opencv2\n",
-                 cfg_.mv_block_w, cfg_.mv_block_h, cfg_.transform_block_w, cfg_.transform_block_h);
-    Die();
-  }
   svc::StreamEncoderConfig c;
   c.width = vidprops_.frame_w; c.height = vidprops_.frame_h;
   c.levels = cfg_.pyr_lvl_count;
-  c.mv_block = cfg_.mv_block_w;
+  c.mv_block = cfg_.mv_block_w; c.mv_block_h = cfg_.mv_block_h;
   c.search_range = cfg_.mv_search_range;
-  c.dct_block = cfg_.transform_block_w;
+  c.dct_block = cfg_.transform_block_w; c.dct_block_h = cfg_.transform_block_h;
   // sixteen frames per batch; fewer when the container says the clip is shorter (the pinned buffers of a batch are 31 MB per frame at
   // 1080p, and page-locking them is most of a short run's start-up)
   c.batch = vidprops_.frame_count > 1 ? std::min<uint32_t>(16u, vidprops_.frame_count - 1) : 16u;

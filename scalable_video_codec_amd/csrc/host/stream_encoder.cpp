@@ -132,6 +132,7 @@ class CopyCrew {
 struct StreamEncoder::Impl {
   StreamEncoderConfig c;
   uint32_t pw = 0, ph = 0, mfw = 0, mfh = 0, blocks = 0, iters = 0;
+  uint32_t bw = 0, bh = 0, tw = 0, th = 0;  // MV block and transform block sides
   uint64_t pyr_stride = 0, frame_bytes = 0, plane_elems = 0, record_bytes = 0, seg_ws_bytes = 0;
   std::vector<std::unique_ptr<Slot>> slots;
   hipStream_t s_in = nullptr, s_compute = nullptr, s_out = nullptr;
@@ -151,18 +152,21 @@ StreamEncoder::StreamEncoder(const StreamEncoderConfig& config) : p_(new Impl) {
   if (!c.width || !c.height || !c.levels || !c.mv_block || c.batch == 0 || c.depth < 3)
     throw std::runtime_error("svc::StreamEncoder: invalid configuration");
   const uint32_t f = 1u << (c.levels - 1);
-  m.pw = ClosestLargerDivisible(c.width, c.mv_block, f);   // libs/encoder.cpp:164-168
-  m.ph = ClosestLargerDivisible(c.height, c.mv_block, f);
-  m.mfw = m.pw / c.mv_block; m.mfh = m.ph / c.mv_block; m.blocks = m.mfw * m.mfh;
+  m.bw = c.mv_block; m.bh = c.mv_block_h ? c.mv_block_h : c.mv_block;
+  m.tw = c.dct_block; m.th = c.dct_block_h ? c.dct_block_h : c.dct_block;
+  if (!m.tw || !m.th) throw std::runtime_error("svc::StreamEncoder: invalid configuration");
+  m.pw = ClosestLargerDivisible(c.width, m.bw, f);   // libs/encoder.cpp:164-168
+  m.ph = ClosestLargerDivisible(c.height, m.bh, f);
+  m.mfw = m.pw / m.bw; m.mfh = m.ph / m.bh; m.blocks = m.mfw * m.mfh;
   m.pyr_stride = (svc_hip_pyramid_bytes(m.pw, m.ph, c.levels) + 255) / 256 * 256;  // the kernels ask for 16-byte aligned pyramids
   m.frame_bytes = (uint64_t)m.pw * m.ph * 3;
   m.plane_elems = (uint64_t)m.pw * m.ph;
   // reference_stream: SerializeEncodedFrame over the UNPADDED size (libs/encoder.cpp:647-650); the transform kernel emits that
   // directly when the padded width IS the frame's width (emit height = the unpadded one); with a padded width the row
   // stride quirk needs the planes first and svc_hip_serialize_frames behind them
-  m.record_bytes = !c.wire ? 0 : c.reference_stream ? svc_hip_serialized_frame_bytes(c.width, c.height, c.dct_block, c.dct_block)
-                                                    : svc_hip_serialized_frame_bytes(m.pw, m.ph, c.dct_block, c.dct_block);
-  m.fused_records = c.wire && (!c.reference_stream || m.pw == c.width);
+  m.record_bytes = !c.wire ? 0 : c.reference_stream ? svc_hip_serialized_frame_bytes(c.width, c.height, m.tw, m.th)
+                                                    : svc_hip_serialized_frame_bytes(m.pw, m.ph, m.tw, m.th);
+  m.fused_records = c.wire && m.tw == m.th && (!c.reference_stream || m.pw == c.width);
   m.iters = svc_hip_ransac_iter_count(c.ransac);
   m.seg_ws_bytes = svc_hip_segment_workspace_bytes(m.mfw, m.mfh, c.batch, c.segment.attempt_count);
   m.crew.reset(new CopyCrew(std::min<uint32_t>(c.copy_threads ? c.copy_threads - 1 : 0, 15)));
@@ -213,8 +217,8 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
 
   svc_wire_header header{};
   if (c.wire)
-    Abi(svc_hip_wire_header(std::max<uint32_t>(header_frame_count, 1), c.width, c.height, c.mv_block, c.mv_block, c.levels, c.dct_block,
-                            c.dct_block, &header), "svc_hip_wire_header");
+    Abi(svc_hip_wire_header(std::max<uint32_t>(header_frame_count, 1), c.width, c.height, m.bw, m.bh, c.levels, m.tw,
+                            m.th, &header), "svc_hip_wire_header");
 
   auto deliver = [&](Slot& s) {
     Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize");
@@ -278,25 +282,26 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
     Abi(svc_hip_luma_pyramid_frames(s.bgr.p, m.frame_bytes, B + 1, m.pw, m.ph, c.levels, s.pyr.p, m.pyr_stride, m.s_compute),
         "svc_hip_luma_pyramid_frames");
     Abi(svc_hip_hbma_pairs(s.pyr.p, s.pyr.p + m.pyr_stride, m.pyr_stride, B, c.levels, m.pw, m.ph, c.search_range,
-                           c.mv_block, c.mv_block, s.mv.p, s.mad.p, SVC_HBMA_AUTO, m.s_compute), "svc_hip_hbma_pairs");
+                           m.bw, m.bh, s.mv.p, s.mad.p, SVC_HBMA_AUTO, m.s_compute), "svc_hip_hbma_pairs");
     Hip(hipMemsetAsync(s.gm.p, 0, (size_t)B * 2 * sizeof(float), m.s_compute), "hipMemsetAsync");
     Abi(svc_hip_ransac_frames(s.mv.p, m.blocks, B, c.ransac, s.samples.p, m.iters,
                               s.gm.p, s.rmse.p, s.mask.p, s.count.p, m.s_compute), "svc_hip_ransac_frames");
-    Abi(svc_hip_segment_frames(s.mask.p, s.mv.p, m.mfw, m.mfh, B, c.mv_block, c.mv_block, c.segment,
+    Abi(svc_hip_segment_frames(s.mask.p, s.mv.p, m.mfw, m.mfh, B, m.bw, m.bh, c.segment,
                                c.seed * 1000003ull + g0, s.seg_ws.p, m.seg_ws_bytes, s.types.p, m.s_compute),
         "svc_hip_segment_frames");
     const uint8_t* enc_bgr = s.bgr.p + m.frame_bytes;  // encoded frame of pair p is source frame p + 1
     if (c.wire && m.fused_records) {
-      Abi(svc_hip_dct_records_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, s.types.p, c.mv_block, c.mv_block,
+      Abi(svc_hip_dct_records_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, m.tw, s.types.p, m.bw, m.bh,
                                      0, 0, c.reference_stream ? c.height : m.ph, s.records.p, m.record_bytes, m.s_compute),  // raw: see the header
           "svc_hip_dct_records_frames");
-    } else if (c.wire) {  // the reference encoder's stream on a padded width: planes, then the serialiser with the reference's own arguments
-      Abi(svc_hip_dct_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, c.dct_block, s.coeffs.p, m.s_compute), "svc_hip_dct_frames");
-      Abi(svc_hip_serialize_frames(s.coeffs.p, m.plane_elems, B, s.types.p, c.width, c.height, c.dct_block, c.dct_block, m.mfw, m.mfh,
-                                   c.mv_block, c.mv_block, s.records.p, m.record_bytes, m.s_compute), "svc_hip_serialize_frames");
+    } else if (c.wire) {  // the reference encoder's stream on a padded width, or non-square tiles: planes, then the serialiser with the reference's own arguments
+      Abi(svc_hip_dct_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, m.tw, m.th, s.coeffs.p, m.s_compute), "svc_hip_dct_frames");
+      const uint32_t sw = c.reference_stream ? c.width : m.pw, sh = c.reference_stream ? c.height : m.ph;
+      Abi(svc_hip_serialize_frames(s.coeffs.p, m.plane_elems, B, s.types.p, sw, sh, m.tw, m.th, m.mfw, m.mfh,
+                                   m.bw, m.bh, s.records.p, m.record_bytes, m.s_compute), "svc_hip_serialize_frames");
     } else {
-      Abi(svc_hip_dct_quant_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, c.dct_block, c.dct_block, s.types.p, c.mv_block,
-                                   c.mv_block, c.fg_step, c.bg_step, s.coeffs.p, m.s_compute), "svc_hip_dct_quant_frames");
+      Abi(svc_hip_dct_quant_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, m.tw, m.th, s.types.p, m.bw,
+                                   m.bh, c.fg_step, c.bg_step, s.coeffs.p, m.s_compute), "svc_hip_dct_quant_frames");
     }
     Hip(hipEventRecord(s.compute_done, m.s_compute), "hipEventRecord");
 

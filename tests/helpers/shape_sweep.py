@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Discovery tool: random configurations the reference's Validate admits (libs/encoder.cpp:62-142) -- odd frame sizes, every
+level count, 8 / 16 / 32-pixel MV blocks, any transform block that divides them, any search range -- through svc::ClipEncoder
+(pipelined schedule), every output against the oracle (oracle/ is the checker here, as in tests/): pyramids, motion field,
+RANSAC, region ids bit for bit, coefficients within the parity tolerance.  Prints one line per configuration and a summary;
+anything it finds becomes a fix plus a named test.
+
+usage (GPU box): python tests/helpers/shape_sweep.py [--count 60] [--seed 1] [--max-side 420]
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import binding  # noqa: E402
+from scalable_video_codec_amd import clip as clipmod  # noqa: E402
+from scalable_video_codec_amd import configs, native, pipeline, synth  # noqa: E402
+
+DEFAULT_RANSAC = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+
+
+def random_config(rng, i, max_side):
+    levels = int(rng.integers(1, 5))
+    f = 1 << (levels - 1)
+    mv_block = int(rng.choice([8, 16, 16, 16, 32]))
+    if mv_block < 2 * f:  # the top level's block is mv_block / f >= 2 in every build the reference's CLI produces
+        mv_block = max(mv_block, 2 * f)
+    dct_choices = [b for b in (2, 4, 8, 16, 32) if mv_block % b == 0]
+    dct_block = int(rng.choice(dct_choices))
+    search = int(rng.choice([r for r in (8, 8, 16, 4, 2, 32) if r >= f]))
+    w = int(rng.integers(2 * mv_block + 1, max_side))
+    h = int(rng.integers(2 * mv_block + 1, max_side))
+    if rng.random() < 0.3:
+        w = w // 16 * 16 + 16  # common widths too
+    return configs.CodecConfig(f"sweep{i}-{w}x{h}-{levels}L-mv{mv_block}-r{search}-dct{dct_block}", 100 + i, w, h, 4, levels=levels,
+                               mv_block=mv_block, search_range=search, dct_block=dct_block)
+
+
+def check(cfg, oracle, dev):
+    pw, ph = cfg.padded
+    src = synth.SynthClip(cfg.width, cfg.height, cfg.frames, cfg.seed, device=dev)
+    frames = torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(cfg.frames)]).contiguous()
+    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED)
+    try:
+        enc.load_frames(frames)
+        for _ in range(3):
+            enc.step()
+        enc.sync()
+        out = enc.outputs()
+        info = enc.info
+        host = frames.cpu().numpy()
+        pyrs = [oracle.luma_pyramid(host[t], cfg.levels) for t in range(cfg.frames)]
+        pyr = enc.read("pyramids")
+        stride = info.pyramid_stride
+        for t in range(cfg.frames):
+            off = 0
+            for l, p in enumerate(pyrs[t]):
+                got = pyr[(t + 1) * stride + off:(t + 1) * stride + off + p.size].numpy().reshape(p.shape)
+                if not np.array_equal(got, p):
+                    return f"pyramid frame {t} level {l}"
+                off += p.size
+        mfw, mfh = cfg.mv_field
+        samples = pipeline.ransac_samples(info.pairs, info.ransac_iters, 1, info.blocks, cfg.seed, "cpu").numpy().astype(np.uint32)
+        coeffs = enc.read("coeffs").view(info.pairs, 3, ph, pw).numpy()
+        for p in range(cfg.frames - 1):
+            mv, mad = oracle.hbma(pyrs[p], pyrs[p + 1], cfg.search_range, cfg.mv_block, cfg.mv_block)
+            if not (np.array_equal(out["mv"][p].numpy(), mv) and np.array_equal(out["min_mad"][p].numpy(), mad)):
+                return f"motion field pair {p} ({native.hbma_kernel_name(cfg.levels, pw, ph, cfg.search_range, cfg.mv_block, cfg.mv_block)})"
+            gm, rmse, inl = oracle.ransac(mv, samples[p].ravel(), **DEFAULT_RANSAC)
+            if out["global_motion"][p].numpy().tobytes() != gm.tobytes() or np.float32(out["rmse"][p].item()).tobytes() != rmse.tobytes():
+                return f"ransac pair {p}"
+            mask = out["inlier_mask"][p].numpy()
+            if not np.array_equal(np.flatnonzero(mask), inl):
+                return f"inliers pair {p}"
+            want = oracle.segment(mask, mv, mfw, mfh, cfg.mv_block, cfg.mv_block, seed=cfg.seed * 1000003 + p)
+            types = out["block_types"][p].numpy().astype(np.uint32)
+            if not np.array_equal(types, want):
+                return f"region ids pair {p}"
+            raw = oracle.dct_frame_f64(host[p + 1], cfg.dct_block, cfg.dct_block)
+            q = oracle.quant_frame(raw.astype(np.float32), cfg.mv_block, cfg.mv_block, types, cfg.fg_step, cfg.bg_step)
+            same = np.mean(coeffs[p] == q)
+            tol_ok = np.abs(coeffs[p] - q) <= 1e-4 * np.maximum(1.0, np.abs(q))
+            # a coefficient within rounding distance of a quantiser boundary may land one step away
+            step_ok = np.abs(coeffs[p] - q) <= max(cfg.fg_step, cfg.bg_step) * 1.0001
+            if same < 0.995 or not (tol_ok | step_ok).all():
+                return f"coefficients pair {p} (equal {same:.5f})"
+        return None
+    finally:
+        enc.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--count", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-side", type=int, default=420)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    oracle = binding.Oracle()
+    dev = torch.device("cuda")
+    bad = 0
+    for i in range(args.count):
+        cfg = random_config(rng, i, args.max_side)
+        t0 = time.perf_counter()
+        try:
+            verdict = check(cfg, oracle, dev)
+        except Exception as e:  # noqa: BLE001
+            verdict = f"EXCEPTION {type(e).__name__}: {str(e)[:200]}"
+            if os.environ.get("SWEEP_TRACE"):
+                traceback.print_exc()
+        bad += verdict is not None
+        print(f"{'ok  ' if verdict is None else 'FAIL'} {cfg.name} padded {cfg.padded} {time.perf_counter() - t0:.1f}s {verdict or ''}", flush=True)
+    print(f"{args.count - bad} of {args.count} configurations equal the oracle", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -36,11 +36,14 @@ def _encode(exe, clip, *args):
 
 def _expected(oracle, frames, levels, tb, mv_block=16, search_range=8, seg=None):
     """Header + per frame (tile types, tile coefficients): the oracle's stages with THIS Encoder's draws (pipeline.ransac_samples) and
-    segmentation seeds (seed * 1000003 + clip-wide pair index), serialised with the reference's own arguments."""
+    segmentation seeds (seed * 1000003 + clip-wide pair index), serialised with the reference's own arguments.  tb / mv_block: a side,
+    or (width, height)."""
     h, w, _ = frames[0].shape
-    pw, ph = synth.padded_dims(w, h, mv_block, mv_block, levels)
-    mfw, mfh = pw // mv_block, ph // mv_block
-    header = struct.pack("<8I", len(frames) - 1, w, h, pw - w, ph - h, tb, tb, 3)
+    bw, bh = (mv_block, mv_block) if isinstance(mv_block, int) else mv_block
+    tw, th = (tb, tb) if isinstance(tb, int) else tb
+    pw, ph = synth.padded_dims(w, h, bw, bh, levels)
+    mfw, mfh = pw // bw, ph // bh
+    header = struct.pack("<8I", len(frames) - 1, w, h, pw - w, ph - h, tw, th, 3)
     padded = []
     for fr in frames:
         p = np.zeros((ph, pw, 3), np.uint8)
@@ -52,14 +55,14 @@ def _expected(oracle, frames, levels, tb, mv_block=16, search_range=8, seg=None)
     samples = pipeline.ransac_samples(len(frames) - 1, iters, 1, mfw * mfh, SEED, "cpu").numpy().astype(np.uint32)
     out = []
     for t in range(1, len(frames)):
-        mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, mv_block, mv_block)
+        mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, bw, bh)
         _, _, inliers = oracle.ransac(mv, samples[t - 1].ravel(), **rp)
         mask = np.zeros(mfw * mfh, np.uint8)
         mask[inliers] = 1
-        types = oracle.segment(mask, mv, mfw, mfh, mv_block, mv_block, seed=SEED * 1000003 + (t - 1), **(seg or {}))
-        planes = oracle.dct_frame_f32(padded[t], tb, tb)
-        rec = oracle.serialize_frame(planes, types, w, h, tb, tb, mfw, mv_block, mv_block)
-        rec = rec.view(np.uint32).reshape(-1, 1 + 3 * tb * tb)
+        types = oracle.segment(mask, mv, mfw, mfh, bw, bh, seed=SEED * 1000003 + (t - 1), **(seg or {}))
+        planes = oracle.dct_frame_f32(padded[t], tw, th)
+        rec = oracle.serialize_frame(planes, types, w, h, tw, th, mfw, bw, bh)
+        rec = rec.view(np.uint32).reshape(-1, 1 + 3 * tw * th)
         out.append((rec[:, 0].copy(), rec[:, 1:].copy().view(np.float32)))
     return header, out
 
@@ -96,7 +99,7 @@ def test_batched_encoder_class_any_clip_length(native, oracle, tmp_path, n):
 
 def test_batched_encoder_class_generic_build_and_limits(native, oracle, tmp_path):
     """The build without -DSVC_MOTION_SSE2: --pyr-lvl-count 3 and 8 x 8 MV blocks from the command line; a single-frame clip is a header
-    and nothing else; non-square blocks are refused with a message that names the route that takes them."""
+    and nothing else."""
     n = 6
     clip = synth.SynthClip(360, 200, n, seed=11)
     frames = [clip.frame_bgr(t).numpy() for t in range(n)]
@@ -111,6 +114,20 @@ def test_batched_encoder_class_generic_build_and_limits(native, oracle, tmp_path
     _write_clip(one, frames[:1])
     got, _ = _encode("ref_app_svc_encoder_generic", one, "--verbose", "0")
     assert len(got) == 32 and struct.unpack("<3I", got[:12]) == (0, 360, 200)
-    exe = os.path.join(BIN, "ref_app_svc_encoder_generic")
-    r = subprocess.run([exe, "--verbose", "0", "--mv-block-w", "32", "--mv-block-h", "16", str(path)], capture_output=True, timeout=120)
-    assert r.returncode != 0 and b"square" in r.stderr and b"compat/opencv2" in r.stderr
+
+
+@pytest.mark.parametrize("size,mv,tb,levels", [((344, 280), (32, 16), (16, 8), 3), ((352, 288), (16, 32), (8, 16), 2), ((360, 200), (8, 16), (8, 4), 3)])
+def test_batched_encoder_class_non_square_blocks(native, oracle, tmp_path, size, mv, tb, levels):
+    """--mv-block-w != --mv-block-h and --transform-block-w != --transform-block-h (Validate admits them, libs/encoder.cpp:62-142): the
+    per-level search kernel and the planes + serialiser route instead of the tuned kernels, same stream as the oracle's stages
+    serialised with the reference's own arguments."""
+    n = 5
+    clip = synth.SynthClip(size[0], size[1], n, seed=17)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.svcbgr"
+    _write_clip(path, frames)
+    args = ["--verbose", "0", "--pyr-lvl-count", str(levels), "--mv-block-w", str(mv[0]), "--mv-block-h", str(mv[1]),
+            "--transform-block-w", str(tb[0]), "--transform-block-h", str(tb[1])]
+    got, _ = _encode("ref_app_svc_encoder_generic", path, *args)
+    header, expected = _expected(oracle, frames, levels, tb, mv_block=mv)
+    _check(got, header, expected, tb)
