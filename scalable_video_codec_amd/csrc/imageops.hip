@@ -335,14 +335,14 @@ int svc_hip_bgr2yuv_host(const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* yu
   Staging& st = host_stage();
   const size_t bytes = up256(pixels * 3);
   if ((rc = st.ensure(2 * bytes))) return rc;
-  std::memcpy(st.pin, bgr, pixels * 3);
+  host_copy(st.pin, bgr, pixels * 3);
   SVC_HIP_TRY(hipMemcpyAsync(st.dev, st.pin, pixels * 3, hipMemcpyHostToDevice, st.stream));
   hipLaunchKernelGGL(bgr2yuv_kernel, dim3((uint32_t)((pixels + 1023) / 1024)), dim3(256), 0, st.stream, st.dev, st.dev + bytes,
                      pixels);
   if ((rc = check_launch("bgr2yuv_kernel"))) return rc;
   SVC_HIP_TRY(hipMemcpyAsync(st.pin + bytes, st.dev + bytes, pixels * 3, hipMemcpyDeviceToHost, st.stream));
   SVC_HIP_TRY(hipStreamSynchronize(st.stream));
-  std::memcpy(yuv, st.pin + bytes, pixels * 3);
+  host_copy(yuv, st.pin + bytes, pixels * 3);
   return SVC_OK;
 }
 
@@ -360,7 +360,7 @@ int svc_hip_build_pyramid_host(const uint8_t* level0, uint32_t w, uint32_t h, ui
   Staging& st = host_stage();
   const size_t pyr = up256(pyramid_bytes(w, h, level_count)), n0 = (size_t)w * h;
   if ((rc = st.ensure(pyr))) return rc;
-  std::memcpy(st.pin, level0, n0);
+  host_copy(st.pin, level0, n0);
   SVC_HIP_TRY(hipMemcpyAsync(st.dev, st.pin, n0, hipMemcpyHostToDevice, st.stream));
   if ((rc = launch_pyr_down_levels(st.dev, pyr, 1, w, h, level_count, 0, st.stream))) return rc;
   SVC_HIP_TRY(hipMemcpyAsync(st.pin + n0, st.dev + n0, pyramid_bytes(w, h, level_count) - n0, hipMemcpyDeviceToHost, st.stream));
@@ -368,7 +368,7 @@ int svc_hip_build_pyramid_host(const uint8_t* level0, uint32_t w, uint32_t h, ui
   size_t off = n0;
   for (uint32_t l = 1; l < level_count; ++l) {
     const size_t n = (size_t)(w >> l) * (h >> l);
-    std::memcpy(out_levels[l], st.pin + off, n);
+    host_copy(out_levels[l], st.pin + off, n);
     off += n;
   }
   return SVC_OK;
@@ -508,7 +508,7 @@ int svc_hip_dct_tiles_host(float* image, uint32_t w, uint32_t h, uint32_t block_
   Staging& st = host_stage();
   const size_t img_b = up256(n * 4), xy_b = tiles_xy ? up256((size_t)n_tiles * 8) : 0;
   if ((rc = st.ensure(img_b + xy_b))) return rc;
-  std::memcpy(st.pin, image, n * 4);
+  host_copy(st.pin, image, n * 4);
   if (tiles_xy) std::memcpy(st.pin + img_b, tiles_xy, (size_t)n_tiles * 8);
   SVC_HIP_TRY(hipMemcpyAsync(st.dev, st.pin, img_b + xy_b, hipMemcpyHostToDevice, st.stream));
   rc = launch_dct_tiles(reinterpret_cast<float*>(st.dev), w, h, block_w, block_h,
@@ -516,7 +516,7 @@ int svc_hip_dct_tiles_host(float* image, uint32_t w, uint32_t h, uint32_t block_
   if (rc) return rc;
   SVC_HIP_TRY(hipMemcpyAsync(st.pin, st.dev, n * 4, hipMemcpyDeviceToHost, st.stream));
   SVC_HIP_TRY(hipStreamSynchronize(st.stream));
-  std::memcpy(image, st.pin, n * 4);
+  host_copy(image, st.pin, n * 4);
   return SVC_OK;
 }
 

@@ -58,10 +58,16 @@ struct Staging {
   uint8_t* dev = nullptr;
   uint8_t* pin = nullptr;
   size_t cap = 0;
+  hipEvent_t piece[8] = {};  // D2H of a large result in pieces: piece k's event, so that its copy-out overlaps piece k + 1's transfer
   ~Staging();
   int ensure(size_t bytes);
+  // device -> pinned -> caller's memory, `bytes` from d_src (staged at pin_off) to dst[i] (n_dst equal runs, or one): the transfer goes
+  // out in pieces and each piece is copied out (by the copy crew) while the next one is still on the link.  Synchronises the stream.
+  int download(const uint8_t* d_src, size_t pin_off, size_t bytes, uint8_t* const* dst, uint32_t n_dst);
 };
 Staging& host_stage();
+// pageable <-> pinned copies of the host-pointer entry points: by several threads above 1 MB (csrc/host/copy_crew.hpp)
+void host_copy(void* dst, const void* src, size_t bytes);
 int require_device();
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
