@@ -59,6 +59,19 @@ def test_compat_adapter_host_side_is_clean(tmp_path):
 
 
 @pytest.mark.timeout(600)
+def test_copy_crew_under_thread_and_address_sanitizers():
+    """csrc/host/copy_crew.hpp -- the threads that stage source frames for svc::StreamEncoder and move the host-pointer entry points'
+    results -- under ThreadSanitizer and under ASan + UBSan: flat and pitched copies of awkward sizes, concurrent callers, start / stop."""
+    _make("crew")
+    for exe, env in (("copy_crew_tsan", {"TSAN_OPTIONS": "halt_on_error=1"}),
+                     ("copy_crew_asan", {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})):
+        r = subprocess.run([os.path.join(SAN, "_build", exe)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        out = r.stdout + r.stderr
+        assert r.returncode == 0 and "copy crew ok" in r.stdout, out[-4000:]
+        assert "ThreadSanitizer" not in out and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+
+
+@pytest.mark.timeout(600)
 def test_reference_ransac_reads_past_its_field():
     if not os.path.exists("/root/reference/libs/motion.cpp") or not os.path.exists(HIPCC):
         pytest.skip("needs the reference tree (this container only)")
