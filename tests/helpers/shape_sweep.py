@@ -99,13 +99,22 @@ def main():
     ap.add_argument("--count", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-side", type=int, default=420)
+    ap.add_argument("--shape", action="append", default=[], help="WxH:levels:mv_block:search_range:dct_block -- run these instead of random ones")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     oracle = binding.Oracle()
     dev = torch.device("cuda")
     bad = 0
+    fixed = []
+    for i, spec in enumerate(args.shape):
+        size, levels, mv, rng_, dct = spec.split(":")
+        w, h = size.split("x")
+        fixed.append(configs.CodecConfig(f"shape-{spec}", 900 + i, int(w), int(h), 3, levels=int(levels), mv_block=int(mv), search_range=int(rng_),
+                                         dct_block=int(dct)))
+    if fixed:
+        args.count = len(fixed)
     for i in range(args.count):
-        cfg = random_config(rng, i, args.max_side)
+        cfg = fixed[i] if fixed else random_config(rng, i, args.max_side)
         t0 = time.perf_counter()
         try:
             verdict = check(cfg, oracle, dev)
