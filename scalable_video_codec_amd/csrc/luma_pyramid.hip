@@ -293,92 +293,6 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     }
   }
 }
-// (A/B only, -DSVC_PYR_STREAM=<workgroups>; removed in the next commit: profiles/r04_ab_pyr_stream.txt)
-// The plane-to-plane pass as a stream: a fixed grid, each workgroup walking the tiles of its XCD's share, the NEXT tile's rows on their
-// way into a second LDS buffer by LDS-DMA (global_load_lds_dwordx4: whole 16-byte chunks of whole rows, no registers, asynchronous)
-// while the current tile is reduced.  A tile row in LDS is the 16-byte chunks x0 - 16 .. x0 + TW + 15 (pitch TW + 32, the same columns
-// as luma_pyr1_tile's layout), so the two halo columns on each side come with the row; rows outside the frame are fetched from their
-// reflections; the columns outside the frame (x = -2, -1 and x = w) are substituted from inside the row when the taps are formed.
-template <int TW, int TH>
-__global__ __launch_bounds__(256) void pyr_plane_stream_kernel(LumaPyr1Args a) {
-  constexpr int kCPR = TW / 16 + 2, kPitch = kCPR * 16, kRows = TH + 4, kChunks = kCPR * kRows;
-  constexpr int kSlices = (kChunks + 63) / 64, kBuf = kSlices * 1024, kRounds = (kSlices + 3) / 4;
-  static_assert(kPitch == TW + 2 * kOff, "same column layout as luma_pyr1_tile");
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kBuf];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
-  const uint32_t tid = threadIdx.x, wave = tid / 64u;
-  const int w = (int)a.w, h = (int)a.h;
-  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const uint32_t share = (a.total_tiles + 7u) / 8u, t_first = xcd * share, t_end = min(a.total_tiles, t_first + share);
-
-  auto stage = [&](uint32_t t, uint32_t buf) {
-    const uint32_t frame = t / a.tiles_per_frame, tr = t - frame * a.tiles_per_frame;
-    const uint32_t ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-    const int x0 = (int)tx * TW, y0 = (int)ty * TH;
-    const uint8_t* plane = a.pyr + (size_t)frame * a.pyr_stride + a.src_off;  // uniform over the workgroup
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const uint32_t slice = (uint32_t)r * 4u + wave;  // this wave instruction's 64 chunks
-      if (slice < (uint32_t)kSlices) {                 // wave-uniform
-        const uint32_t chunk = min(slice * 64u + (tid & 63u), (uint32_t)(kChunks - 1));  // lanes past the tile fetch its last chunk again
-        const int row = (int)(chunk / (uint32_t)kCPR), c = (int)(chunk % (uint32_t)kCPR);
-        const int gy = reflect101(min(y0 - 2 + row, h), h);  // rows beyond y = h are never read: fetched from row h's reflection
-        const int gx = min(max(x0 - 16 + 16 * c, 0), w - 16);  // chunks outside the frame: any chunk of the row
-        const uint32_t voff = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-        const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + buf * (uint32_t)kBuf + slice * 1024u);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(plane) : "memory", "m0");
-      }
-    }
-  };
-
-  uint32_t t = t_first + k, i = 0;
-  if (t < t_end) stage(t, 0);
-  for (; t < t_end; t += per, ++i) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of tile t have landed
-    asm volatile("" ::: "memory");
-    __syncthreads();                     // ... and every other wave's; everybody is done reading the other buffer
-    if (t + per < t_end) stage(t + per, (i + 1) & 1u);
-
-    const uint8_t* tile = lds + (i & 1u) * kBuf;
-    const uint32_t frame = t / a.tiles_per_frame, tr = t - frame * a.tiles_per_frame;
-    const uint32_t ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-    const int x0 = (int)tx * TW, y0 = (int)ty * TH;
-    uint8_t* dst = a.pyr + (size_t)frame * a.pyr_stride + a.dst_off;
-    constexpr int kQuads = TW / 8;
-    const int q = (int)tid % kQuads;
-    const int gx = (x0 >> 1) + 4 * q;
-    const bool left = x0 + 8 * q == 0, right = x0 + 8 * q + 8 == w;  // this quad's taps leave the frame at x = -2, -1 / at x = w
-    const int taps[5] = {1, 4, 6, 4, 1};
-    for (int oy = (int)tid / kQuads; oy < TH / 2 && gx < (w >> 1); oy += 256 / kQuads) {
-      const int gy = (y0 >> 1) + oy;
-      if (gy >= (h >> 1)) break;
-      uint32_t acc[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int r5 = 0; r5 < 5; ++r5) {
-        const uint8_t* rowp = &tile[(2 * oy + r5) * kPitch + kOff + 8 * q];
-        uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
-        const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
-        uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
-        if (left) w0 = (mid.x & 0x00FF0000u) | ((mid.x & 0x0000FF00u) << 16);  // x = -2, -1 <- x = 2, 1 (reflect 101)
-        if (right) w3 = (mid.y >> 16) & 0xFFu;                                   // x = w <- x = w - 2
-        constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
-        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.x, w0, 2), kTaps, (mid.x >> 16) & 0xFFu, false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(mid.x, kTaps, mid.y & 0xFFu, false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), kTaps, (mid.y >> 16) & 0xFFu, false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(mid.y, kTaps, w3 & 0xFFu, false);
-        acc[0] += (uint32_t)taps[r5] * h0;
-        acc[1] += (uint32_t)taps[r5] * h1;
-        acc[2] += (uint32_t)taps[r5] * h2;
-        acc[3] += (uint32_t)taps[r5] * h3;
-      }
-      uint32_t out = 0;
-#pragma unroll
-      for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
-      *reinterpret_cast<uint32_t*>(dst + (size_t)gy * (w >> 1) + gx) = out;
-    }
-  }
-}
-
 // any frame width: one pixel per lane
 __global__ __launch_bounds__(256) void luma_any_kernel(const uint8_t* bgr, uint64_t frame_stride, uint8_t* pyr, uint64_t pyr_stride,
                                                         uint32_t px_per_frame, uint32_t total) {
@@ -472,19 +386,12 @@ int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frame
       const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
       if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many tiles for one launch");
       fa.total_tiles = (uint32_t)tt;
-#ifdef SVC_PYR_STREAM
-      {
-        const uint32_t grid = std::min<uint32_t>((fa.total_tiles + 7u) / 8u * 8u, (uint32_t)SVC_PYR_STREAM);
-        hipLaunchKernelGGL((pyr_plane_stream_kernel<kTWPlane, kTHPlane>), dim3(grid), dim3(256), 0, stream, fa);
-      }
-#else
       {
         // a fixed grid whose workgroups walk the tiles: 0.062 -> 0.054 ms per launch at C3 (profiles/r04_ab_pyr_persist.txt; 1024 workgroups
         // are too few, 2048 and 4096 level).  A double-buffered LDS-DMA form of the same walk measured no better (r04_ab_pyr_stream.txt).
         const uint32_t grid = std::min<uint32_t>((fa.total_tiles + 7u) / 8u * 8u, 2048u);
         hipLaunchKernelGGL((luma_pyr1_kernel<false, kTWPlane, kTHPlane, true>), dim3(grid), dim3(256), 0, stream, fa);
       }
-#endif
       if ((rc = check_launch("luma_pyr1_kernel<false>"))) return rc;
       continue;
     }
