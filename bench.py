@@ -320,7 +320,7 @@ def hbm_streaming_rates(device) -> dict:
     b = torch.empty(n, dtype=torch.uint8, device=device)
     a.fill_(1)
     out = {}
-    for name, r, w in (("read_only", 3, 0), ("write_only", 0, 1), ("3_read_1_write", 3, 1), ("1_read_4_write", 1, 4)):
+    for name, r, w in (("read_only", 3, 0), ("write_only", 0, 1), ("copy_1_read_1_write", 1, 1), ("3_read_1_write", 3, 1), ("1_read_4_write", 1, 4)):
         native.probe_stream(a, b, r, w)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -729,9 +729,11 @@ def main() -> None:
             out["sustained"] = {**r["sustained"], "value": r["encoded_per_step"] / (r["sustained"]["ms_per_step"] * 1e-3), "unit": "frames/s",
                                 "note": "untimed for `value`: back-to-back steps after the timed region"}
         if world == 1 and not args.no_hbm_probe:
-            # context only: what plain streaming kernels get from this box's HBM (not a ceiling: the DCT kernel beats the 1:4 probe)
+            # context only: what plain streaming kernels get from this box's HBM, in the form that gets the most out of it (one 4 KiB
+            # unit per short-lived workgroup, XCD-contiguous order: tools/ubench_stream_oneshot.hip)
             out["hbm_streaming_measured"] = {"unit": "GB/s", **hbm_streaming_rates(dev),
-                                             "note": "svc_hip_probe_stream on this GPU, context only; roofline fractions are against the 8 TB/s peak"}
+                                             "note": "svc_hip_probe_stream on this GPU (one unit per workgroup, XCD-contiguous), context only; roofline "
+                                                     "fractions are against the 8 TB/s peak"}
         if r["sample_frames"] is not None and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_rates(cfg, r["sample_frames"])
         if r["sample_frames"] is not None and not args.no_cpu_baseline:

@@ -242,7 +242,7 @@ def block_types_frames(mask: torch.Tensor, out: Optional[torch.Tensor] = None) -
 
 
 def probe_stream(src: torch.Tensor, dst: torch.Tensor, reads: int, writes: int) -> None:
-    """One launch of the plain streaming kernel (measurement aid): reads x 16 B in, writes x 16 B out per lane and iteration."""
+    """One launch of the plain streaming kernel (measurement aid): reads x 16 B in, writes x 16 B out per lane; one 4 KiB unit per workgroup."""
     _check(load().svc_hip_probe_stream(_dev(src, torch.uint8), _dev(dst, torch.uint8), min(src.numel(), dst.numel()),
                                        reads, writes, _stream()))
 
