@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 #define SVC_LUMA_TW 128
 #endif
 #ifndef SVC_LUMA_TH
-#define SVC_LUMA_TH 28
+#define SVC_LUMA_TH 32
 #endif
 constexpr int kTWBgr = SVC_LUMA_TW, kTHBgr = SVC_LUMA_TH, kTWPlane = 512, kTHPlane = 32 /* 128 x 64 ... 512 x 32 measured: profiles/r02_ab_pyr_tile.txt */, kOff = 16;  // LDS column c <-> x = x0 - kOff + c
 
@@ -207,66 +207,35 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
   // row h) and must not be touched: reflect101 folds once, so a row further out would index
   // outside the frame (short frames: found by tests/test_gpu_misc_property.py).
   const int rows = min(kTH + 4, h - y0 + 3);  // LDS rows 0 .. rows-1 <-> y = y0 - 2 .. min(y0 + 33, h)
-  // One round of loads when the tile's segment tasks fit the workgroup ((TH + 4) x TW / 16 <= 256: 128 x 28): every lane issues its
-  // segment's three loads AND its halo pixel's three byte loads before it waits for any of them.  (As two loops -- segments, then
-  // halo pixels, and a second pass of the segment loop for 32 lanes at 128 x 32 -- a workgroup's life held three dependent memory
-  // round trips; profiles/r04_ab_luma_one_round.txt.)
-  constexpr bool kOneRound = FROM_BGR && (kTH + 4) * (kTW / 16) <= 256;
-  if constexpr (kOneRound) {
-    const int task = (int)tid;
-    const bool seg_task = task < rows * segs, halo_task = task < rows * 4;
-    const int hr = task >> 2, hk = task & 3;
-    const int hx = hk < 2 ? x0 - 2 + hk : xe + (hk - 2);
-    uint32_t hb = 0, hg = 0, hrr = 0;
-    if (halo_task) {
-      const uint8_t* p = src + ((size_t)reflect101(y0 - 2 + hr, h) * w + reflect101(hx, w)) * 3;
-      hb = p[0]; hg = p[1]; hrr = p[2];
-    }
-    if (seg_task) {
-      const int r = task / segs, sgm = task - r * segs;
-      const int y = y0 - 2 + r, yr = reflect101(y, h);
-      const int x = x0 + sgm * 16;
+  // (a) segment tasks: 16 pixels of one row -> 4 dwords of LDS (+ the level-0 store)
+  for (int task = (int)tid; task < rows * segs; task += 256) {
+    const int r = task / segs, sgm = task - r * segs;
+    const int y = y0 - 2 + r, yr = reflect101(y, h);
+    const int x = x0 + sgm * 16;
+    uint4 o4;
+    if (FROM_BGR) {
       const uint4* p = reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3);
       const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
       const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
       uint32_t out[4];
       luma16(wd, out);
-      const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
-      *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;
-      if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
+      o4 = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+      o4 = *reinterpret_cast<const uint4*>(src + (size_t)yr * w + x);
     }
-    if (halo_task) tile[hr * kPitch + kOff + (hx - x0)] = (uint8_t)luma_of(hb, hg, hrr);
-  } else {
-    // (a) segment tasks: 16 pixels of one row -> 4 dwords of LDS (+ the level-0 store)
-    for (int task = (int)tid; task < rows * segs; task += 256) {
-      const int r = task / segs, sgm = task - r * segs;
-      const int y = y0 - 2 + r, yr = reflect101(y, h);
-      const int x = x0 + sgm * 16;
-      uint4 o4;
-      if (FROM_BGR) {
-        const uint4* p = reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3);
-        const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-        const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-        uint32_t out[4];
-        luma16(wd, out);
-        o4 = make_uint4(out[0], out[1], out[2], out[3]);
-      } else {
-        o4 = *reinterpret_cast<const uint4*>(src + (size_t)yr * w + x);
-      }
-      *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;  // 16-byte aligned (Guideline 17)
-      if (FROM_BGR && r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
-    }
-    // (b) halo pixels: two columns on each side of the valid part, every row
-    for (int task = (int)tid; task < rows * 4; task += 256) {
-      const int r = task >> 2, k = task & 3;
-      const int yr = reflect101(y0 - 2 + r, h);
-      const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
-      if (FROM_BGR) {
-        const uint8_t* p = src + ((size_t)yr * w + reflect101(x, w)) * 3;
-        tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
-      } else {
-        tile[r * kPitch + kOff + (x - x0)] = src[(size_t)yr * w + reflect101(x, w)];
-      }
+    *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;  // 16-byte aligned (Guideline 17)
+    if (FROM_BGR && r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
+  }
+  // (b) halo pixels: two columns on each side of the valid part, every row
+  for (int task = (int)tid; task < rows * 4; task += 256) {
+    const int r = task >> 2, k = task & 3;
+    const int yr = reflect101(y0 - 2 + r, h);
+    const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
+    if (FROM_BGR) {
+      const uint8_t* p = src + ((size_t)yr * w + reflect101(x, w)) * 3;
+      tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
+    } else {
+      tile[r * kPitch + kOff + (x - x0)] = src[(size_t)yr * w + reflect101(x, w)];
     }
   }
   __syncthreads();
