@@ -34,7 +34,7 @@ def _encode(exe, clip, *args):
     return r.stdout, time.time() - t0
 
 
-def _expected(oracle, frames, levels, tb, mv_block=16, search_range=8, seg=None):
+def _expected(oracle, frames, levels, tb, mv_block=16, search_range=8, seg=None, ransac=None):
     """Header + per frame (tile types, tile coefficients): the oracle's stages with THIS Encoder's draws (pipeline.ransac_samples) and
     segmentation seeds (seed * 1000003 + clip-wide pair index), serialised with the reference's own arguments.  tb / mv_block: a side,
     or (width, height)."""
@@ -50,9 +50,9 @@ def _expected(oracle, frames, levels, tb, mv_block=16, search_range=8, seg=None)
         p[:h, :w] = fr
         padded.append(p)
     pyrs = [oracle.luma_pyramid(p, levels) for p in padded]
-    rp = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
+    rp = {**dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5), **(ransac or {})}
     iters = oracle.ransac_iter_count(**rp)
-    samples = pipeline.ransac_samples(len(frames) - 1, iters, 1, mfw * mfh, SEED, "cpu").numpy().astype(np.uint32)
+    samples = pipeline.ransac_samples(len(frames) - 1, iters, rp["subset_sz"], mfw * mfh, SEED, "cpu").numpy().astype(np.uint32)
     out = []
     for t in range(1, len(frames)):
         mv, _ = oracle.hbma(pyrs[t - 1], pyrs[t], search_range, bw, bh)
@@ -131,3 +131,23 @@ def test_batched_encoder_class_non_square_blocks(native, oracle, tmp_path, size,
     got, _ = _encode("ref_app_svc_encoder_generic", path, *args)
     header, expected = _expected(oracle, frames, levels, tb, mv_block=mv)
     _check(got, header, expected, tb)
+
+
+@pytest.mark.parametrize("opts,kw", [
+    (["--mv-search-range", "16", "--ransac-subset-sz", "3", "--ransac-inlier-thresh", "2.5", "--ransac-success-prob", "0.999", "--ransac-inlier-ratio", "0.4"],
+     dict(search_range=16, ransac=dict(subset_sz=3, inlier_thresh=2.5, success_prob=0.999, inlier_ratio=0.4))),
+    (["--morph-rect-w", "5", "--morph-rect-h", "1", "--kmeans-cluster-count", "6", "--kmeans-attempt-count", "5", "--kmeans-max-iter-count", "4",
+      "--kmeans-epsilon", "2.5", "--connected-components-connectivity", "8"],
+     dict(seg=dict(morph_w=5, morph_h=1, cluster_count=6, attempts=5, max_iter=4, epsilon=2.5, connectivity=8))),
+], ids=["search-range-and-ransac", "segmentation"])
+def test_batched_encoder_class_every_other_option(native, oracle, tmp_path, opts, kw):
+    """The options the tests above leave at their defaults -- search range, the four RANSAC parameters, structuring element, the four
+    k-means parameters, connectivity (apps/encoder.cpp:75-104) -- reach the kernels: same stream as the oracle run with those values."""
+    n = 5
+    clip = synth.SynthClip(352, 288, n, seed=23)
+    frames = [clip.frame_bgr(t).numpy() for t in range(n)]
+    path = tmp_path / "clip.svcbgr"
+    _write_clip(path, frames)
+    got, _ = _encode("ref_app_svc_encoder", path, "--verbose", "0", *opts)
+    header, expected = _expected(oracle, frames, 4, 8, **kw)
+    assert _check(got, header, expected, 8) >= 0
