@@ -37,6 +37,8 @@ __device__ __forceinline__ uint32_t hash(uint32_t x) {
 // 10 x2  lane*8 one row                                           (anchor rows of level 1)
 // 11 x1  lane*4 one row                                           (anchor rows of level 2)
 // 12 x4  lane*16 + 4*(0..3), rows own with 40 % of the lanes on the common row (measured field statistics)
+// 13 x4  even lanes only (32 of 64 active), (lane/2)*16, one row   (anchor rows when two lanes share a block and one of them loads)
+// 14 x4  lanes 0..31 only, lane*16, one row                        (the same with the active lanes packed)
 template <int SHAPE>
 __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ buf, uint32_t* out, uint32_t seed) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -62,6 +64,8 @@ __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ buf, uint32
     if (SHAPE == 10) off = urow * PITCH + lane * 8;
     if (SHAPE == 11) off = urow * PITCH + lane * 4;
     if (SHAPE == 12) off = (((h >> 20) % 10u) < 4u ? urow : row) * PITCH + lane * 16 + sh;
+    if (SHAPE == 13) { if (lane & 1u) continue; off = urow * PITCH + (lane >> 1) * 16; }
+    if (SHAPE == 14) { if (lane >= 32u) continue; off = urow * PITCH + lane * 16; }
     const uint8_t* p = buf + off;
     if (SHAPE == 4 || SHAPE == 10) { u32x2 v = *reinterpret_cast<const u32x2*>(p); acc ^= v.x ^ v.y; }
     else if (SHAPE == 6 || SHAPE == 11) { acc ^= *reinterpret_cast<const uint32_t*>(p); }
@@ -107,5 +111,7 @@ int main() {
   run<10>("x2 lane*8, one row", buf, out);
   run<11>("x1 lane*4, one row", buf, out);
   run<12>("x4 lane*16+4s, 40 % of lanes on a common row", buf, out);
+  run<13>("x4 even lanes only, (lane/2)*16, one row (512 B)", buf, out);
+  run<14>("x4 lanes 0..31 only, lane*16, one row (512 B)", buf, out);
   return 0;
 }
