@@ -147,7 +147,7 @@ def build_compat(force: bool = False) -> str:
         [os.path.join(COMPAT, "opencv2", f) for f in ("core.hpp", "imgproc.hpp", "videoio.hpp", os.path.join("core", "mat.hpp"))]
     if force or not _newer(LIB_COMPAT, srcs + hdrs + [LIB_HIP]):
         cxx = shutil.which("g++") or "g++"
-        _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", f"-I{COMPAT}", f"-I{INCLUDE}", "-o", LIB_COMPAT,
+        _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", f"-I{COMPAT}", f"-I{INCLUDE}", f"-I{CSRC}", "-o", LIB_COMPAT,
               *srcs, f"-L{PKG}", "-lsvc_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB_COMPAT
 

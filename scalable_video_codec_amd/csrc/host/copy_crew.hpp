@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -26,6 +27,24 @@ class CopyCrew {
     wake_.notify_all();
     for (auto& t : threads_) t.join();
   }
+  // job(r0, r1) over [0, rows) cut into one share per thread (the caller's first); returns when every share is done.  `bytes` is what the
+  // job moves in all: below 1 MB the caller runs it alone.  Shares must not overlap in what they write.
+  template <typename Job>
+  void Rows(uint32_t rows, size_t bytes, const Job& job) {
+    std::lock_guard<std::mutex> one_caller(caller_);
+    const uint32_t parts = (uint32_t)threads_.size() + 1;
+    if (parts == 1 || bytes < (1u << 20) || rows == 0) { if (rows) job(0u, rows); return; }
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      job_ = [&job](uint32_t r0, uint32_t r1) { job(r0, r1); };
+      rows_ = rows;
+      left_.store((uint32_t)threads_.size(), std::memory_order_relaxed);
+      ++generation_;
+    }
+    wake_.notify_all();
+    if (rows / parts) job(0u, rows / parts);
+    while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
   // one flat run of bytes, cut into 64 KiB rows for the crew
   void Copy(void* dst, const void* src, size_t bytes) {
     constexpr size_t kRow = 64u << 10;
@@ -35,25 +54,13 @@ class CopyCrew {
   }
   // rows of row_bytes each, from src (pitch src_pitch) to dst (pitch dst_pitch)
   void Copy(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t row_bytes, uint32_t rows) {
-    std::lock_guard<std::mutex> one_caller(caller_);
-    const uint32_t parts = (uint32_t)threads_.size() + 1;
-    if (parts == 1 || (size_t)rows * row_bytes < (1u << 20)) { Rows(dst, dst_pitch, src, src_pitch, row_bytes, 0, rows); return; }
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      dst_ = dst; dst_pitch_ = dst_pitch; src_ = src; src_pitch_ = src_pitch; row_bytes_ = row_bytes; rows_ = rows;
-      left_.store((uint32_t)threads_.size(), std::memory_order_relaxed);
-      ++generation_;
-    }
-    wake_.notify_all();
-    Rows(dst, dst_pitch, src, src_pitch, row_bytes, 0, rows / parts);
-    while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    Rows(rows, (size_t)rows * row_bytes, [=](uint32_t r0, uint32_t r1) {
+      if (dst_pitch == row_bytes && src_pitch == row_bytes) { std::memcpy(dst + (size_t)r0 * row_bytes, src + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes); return; }
+      for (uint32_t y = r0; y < r1; ++y) std::memcpy(dst + (size_t)y * dst_pitch, src + (size_t)y * src_pitch, row_bytes);
+    });
   }
 
  private:
-  static void Rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t row_bytes, uint32_t r0, uint32_t r1) {
-    if (dst_pitch == row_bytes && src_pitch == row_bytes) { std::memcpy(dst + (size_t)r0 * row_bytes, src + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes); return; }
-    for (uint32_t y = r0; y < r1; ++y) std::memcpy(dst + (size_t)y * dst_pitch, src + (size_t)y * src_pitch, row_bytes);
-  }
   void Run(uint32_t index) {
     uint64_t seen = 0;
     for (;;) {
@@ -61,12 +68,11 @@ class CopyCrew {
       wake_.wait(l, [&] { return generation_ != seen; });
       seen = generation_;
       if (stop_) return;
-      uint8_t* dst = dst_; const uint8_t* src = src_;
-      const size_t dp = dst_pitch_, sp = src_pitch_, rb = row_bytes_;
       const uint32_t rows = rows_, parts = (uint32_t)threads_.size() + 1;
+      const std::function<void(uint32_t, uint32_t)>& job = job_;  // stays put until every helper has counted itself out
       l.unlock();
       const uint32_t r0 = (uint32_t)((uint64_t)rows * (index + 1) / parts), r1 = (uint32_t)((uint64_t)rows * (index + 2) / parts);
-      Rows(dst, dp, src, sp, rb, r0, r1);
+      if (r1 > r0) job(r0, r1);
       left_.fetch_sub(1, std::memory_order_release);
     }
   }
@@ -75,12 +81,10 @@ class CopyCrew {
   std::condition_variable wake_;
   uint64_t generation_ = 0;
   bool stop_ = false;
-  uint8_t* dst_ = nullptr; const uint8_t* src_ = nullptr;
-  size_t dst_pitch_ = 0, src_pitch_ = 0, row_bytes_ = 0;
+  std::function<void(uint32_t, uint32_t)> job_;
   uint32_t rows_ = 0;
   std::atomic<uint32_t> left_{0};
 };
-
 
 }  // namespace svc
 

@@ -101,6 +101,46 @@ int main(int argc, char** argv) {
     TermCriteria tc(TermCriteria::COUNT | TermCriteria::EPS, 10, 1.0);
     CHECK(tc.type == 3 && tc.maxCount == 10);
   }
+  {  // frame-sized matrices: the data-movement passes run on several threads above 1 MB (compat/src/core.cpp: ParallelRows) -- every byte arrives
+    const int h = 1080, w = 1920;
+    Mat3b frame(h, w);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) frame(y, x) = Vec3b((uchar)(x + 3 * y), (uchar)(x * 7 + y), (uchar)(x ^ y));
+    Mat3b copy = frame.clone();
+    CHECK(copy.data != frame.data && std::memcmp(copy.data, frame.data, (size_t)h * w * 3) == 0);
+    Mat3b padded;
+    copyMakeBorder(frame, padded, 0, 8, 0, 16, BORDER_CONSTANT, Scalar(0, 0, 0));
+    bool ok = padded.rows == h + 8 && padded.cols == w + 16;
+    for (int y = 0; ok && y < padded.rows; ++y)
+      for (int x = 0; x < padded.cols; ++x) {
+        const Vec3b v = padded(y, x), want = (y < h && x < w) ? frame(y, x) : Vec3b(0, 0, 0);
+        if (v[0] != want[0] || v[1] != want[1] || v[2] != want[2]) { ok = false; break; }
+      }
+    CHECK(ok);
+    Mat3f f;
+    padded.convertTo(f, CV_32FC3);
+    std::vector<Mat1f> planes;
+    split(f, planes);
+    Mat1b green;
+    extractChannel(padded, green, 1);
+    ok = planes.size() == 3;
+    for (int y = 0; ok && y < padded.rows; y += 1)
+      for (int x = 0; x < padded.cols; ++x) {
+        const Vec3b v = padded(y, x);
+        if (f(y, x)[0] != (float)v[0] || f(y, x)[2] != (float)v[2] || planes[0](y, x) != (float)v[0] || planes[1](y, x) != (float)v[1] ||
+            planes[2](y, x) != (float)v[2] || green(y, x) != v[1]) { ok = false; break; }
+      }
+    CHECK(ok);
+    Mat3b view = padded(Rect(16, 8, 1024, 512));  // a view (pitch != row bytes) through the same passes
+    Mat3b view_copy = view.clone();
+    Mat3f view_f;
+    view.convertTo(view_f, CV_32FC3);
+    ok = view_copy.isContinuous() && view_copy.rows == 512 && view_copy.cols == 1024;
+    for (int y = 0; ok && y < 512; ++y)
+      for (int x = 0; x < 1024; ++x)
+        if (view_copy(y, x)[1] != padded(y + 8, x + 16)[1] || view_f(y, x)[2] != (float)padded(y + 8, x + 16)[2]) { ok = false; break; }
+    CHECK(ok);
+  }
   if (argc == 3) {  // the two clip containers written by the Python side: same frames, B,G,R order, fresh storage per read
     VideoCapture a(argv[1]), b(argv[2]);
     CHECK(a.isOpened() && b.isOpened());
