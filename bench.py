@@ -320,7 +320,7 @@ def hbm_streaming_rates(device) -> dict:
     b = torch.empty(n, dtype=torch.uint8, device=device)
     a.fill_(1)
     out = {}
-    for name, r, w in (("read_only", 3, 0), ("write_only", 0, 1), ("copy_1_read_1_write", 1, 1), ("3_read_1_write", 3, 1), ("1_read_4_write", 1, 4)):
+    for name, r, w in (("read_only", 3, 0), ("read_only_16B_per_lane", 1, 0), ("write_only", 0, 1), ("copy_1_read_1_write", 1, 1), ("3_read_1_write", 3, 1), ("1_read_4_write", 1, 4)):
         native.probe_stream(a, b, r, w)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
