@@ -275,8 +275,10 @@ uint64_t svc_hip_serialized_frame_bytes(uint32_t frame_w, uint32_t frame_h,
  * d_planes: [n_frames][3][plane_elems] f32 (plane_elems = padded W * H, what the Dct entry
  * points write); frame_w / frame_h: the tile-loop bounds AND row stride exactly as the
  * reference uses them (the encoder passes the unpadded size, :647-650; pass the padded size
- * for a stream the reference's decoder can parse; the size need not be divisible by the transform block -- the
- * reference's Release build does not check either --, only every read must stay inside planes and motion field).  Frame f is written at
+ * for a stream the reference's decoder can parse; none of the reference's asserts (:230-239, with their swapped w / h) is a
+ * precondition -- its Release build compiles them out and configurations its own Validate admits trip them --, only every read must
+ * stay inside planes and motion field: non-square tiles wider than tall make the reference walk past the planes' end on the last
+ * tile row, which is SVC_ERR_INVALID_ARG here).  Frame f is written at
  * d_out + f * out_stride_bytes (>= svc_hip_serialized_frame_bytes, multiple of 4). */
 int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32_t n_frames,
                              const uint32_t* d_block_types, uint32_t frame_w, uint32_t frame_h,

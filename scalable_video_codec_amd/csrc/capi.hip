@@ -291,13 +291,11 @@ int svc_hip_serialize_frames(const float* d_planes, uint64_t plane_elems, uint32
   SVC_REQUIRE(d_planes && d_block_types && d_out, "serialize: null pointer");
   SVC_REQUIRE(tbw > 0 && tbh > 0, "serialize: transform block must be positive (encoder.cpp:227-228)");
   SVC_REQUIRE(frame_w > 0 && frame_h > 0 && mv_block_w > 0 && mv_block_h > 0, "serialize: empty frame");
-  // The reference's asserts (encoder.cpp:230-239), with its swapped w/h kept -- EXCEPT the divisibility of the frame by the
-  // transform block (:230-231): the encoder hands SerializeEncodedFrame the UNPADDED frame size (:647-650), which is divisible
-  // only by accident, and the reference's documented build (Release, README.md:123) compiles the assert out -- a 344-pixel frame
-  // with 16 x 16 transform blocks encodes there, with a partial last tile column read through the unpadded-stride quirk.  The
-  // loops run as they run there; what IS required is that every read stays inside the planes and the motion field (below).
-  SVC_REQUIRE(tbh <= mv_block_w && tbw <= mv_block_h && mv_block_h % tbw == 0 && mv_block_w % tbh == 0,
-              "serialize: transform block %ux%u must divide the MV block %ux%u (encoder.cpp:235-239)", tbw, tbh, mv_block_w, mv_block_h);
+  // The reference's asserts (encoder.cpp:230-239, with its swapped w / h) are NOT preconditions here: its documented build (Release,
+  // README.md:123) compiles them out, and configurations its own Validate admits trip them -- the encoder hands SerializeEncodedFrame
+  // the UNPADDED frame size (:647-650), divisible by the transform block only by accident (a 344-pixel frame with 16 x 16 blocks), and
+  // with non-square blocks the swapped comparison fails where the real one holds (MV blocks 32 x 8 with 16 x 8 tiles: "16 <= 8").  The
+  // loops run as they run there; what IS required is that every read stays inside the planes and the motion field.
   // every block type and coefficient the loops touch must exist (the reference would read out of bounds)
   const uint32_t last_x = (div_up(frame_w, tbw) - 1) * tbw, last_y = (div_up(frame_h, tbh) - 1) * tbh;
   SVC_REQUIRE(last_x / mv_block_w < mv_field_w && last_y / mv_block_h < mv_field_h,

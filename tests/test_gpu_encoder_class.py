@@ -116,7 +116,9 @@ def test_batched_encoder_class_generic_build_and_limits(native, oracle, tmp_path
     assert len(got) == 32 and struct.unpack("<3I", got[:12]) == (0, 360, 200)
 
 
-@pytest.mark.parametrize("size,mv,tb,levels", [((344, 280), (32, 16), (16, 8), 3), ((352, 288), (16, 32), (8, 16), 2), ((360, 200), (8, 16), (8, 4), 3)])
+@pytest.mark.parametrize("size,mv,tb,levels", [((344, 280), (32, 16), (16, 8), 3), ((352, 288), (16, 32), (8, 16), 2), ((360, 200), (8, 16), (8, 4), 3),
+                                               ((352, 288), (8, 32), (8, 16), 2)])  # the last: tile height 16 > MV block width 8 -- the reference's swapped assert
+                                                                                   # (libs/encoder.cpp:235) would fail, its Release build runs
 def test_batched_encoder_class_non_square_blocks(native, oracle, tmp_path, size, mv, tb, levels):
     """--mv-block-w != --mv-block-h and --transform-block-w != --transform-block-h (Validate admits them, libs/encoder.cpp:62-142): the
     per-level search kernel and the planes + serialiser route instead of the tuned kernels, same stream as the oracle's stages
