@@ -158,3 +158,45 @@ def test_per_call_composition_equals_the_fused_segmentation(native, oracle, mfw,
     fused = native.segment_frames(torch.from_numpy(mask[None]).cuda(), torch.from_numpy(mv[None]).cuda(), mfw, mfh, seed=seed,
                                   connectivity=conn).cpu().numpy()[0]
     assert np.array_equal(fused.astype(np.uint32), got)
+
+
+def test_random_sweep_of_the_per_call_operations(native, oracle):
+    """Seeded random arguments for every per-call operation against its statement in oracle/svc_imageops.c: sizes from 1 x 1 up, odd
+    and degenerate structuring elements, every point dimension and cluster count the definition covers, both connectivities."""
+    rng = np.random.default_rng(20260404)
+    for _ in range(60):
+        w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        kw, kh = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        op = int(rng.integers(0, 4))
+        assert np.array_equal(native.morph_rect_host(img, kw, kh, op), oracle.morph_rect(img, kw, kh, op)), ("morph", w, h, kw, kh, op)
+        binary = np.where(rng.random((h, w)) < rng.random(), img | 1, 0).astype(np.uint8)
+        conn = int(rng.choice([4, 8]))
+        got, gn = native.connected_components_host(binary, conn)
+        want, wn = oracle.connected_components(binary, conn)
+        assert gn == wn and np.array_equal(got, want), ("components", w, h, conn)
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(native.bgr2yuv_host(bgr), oracle.bgr2yuv(bgr)), ("bgr2yuv", w, h)
+    for _ in range(40):
+        n, dims = int(rng.integers(1, 4000)), int(rng.integers(1, 5))
+        k = int(rng.integers(1, min(n, 40) + 1))
+        f = rng.integers(-2000, 2000, (n, dims)).astype(np.float32)
+        if rng.random() < 0.3:
+            f[rng.integers(0, n, n // 2)] = f[0]  # many coinciding points
+        kw = dict(attempts=int(rng.integers(1, 7)), max_iter=int(rng.integers(1, 15)), epsilon=float(rng.choice([0.5, 1.0, 30.0])))
+        seed = int(rng.integers(0, 2 ** 40))
+        got, gc = native.kmeans_host(f, k, seed=seed, **kw)
+        want, wc = oracle.kmeans(f, k, seed=seed, **kw)
+        assert np.array_equal(got, want) and gc == wc, ("kmeans", n, dims, k, kw, seed)
+    for _ in range(25):
+        levels = int(rng.integers(1, 5))
+        f = 1 << (levels - 1)
+        w, h = int(rng.integers(1, 40)) * f * 2, int(rng.integers(1, 30)) * f * 2
+        if min(w, h) >> (levels - 1) < 3 and levels > 1:
+            continue  # reflect-101 needs three pixels on the level that is reduced last
+        y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        planes = native.build_pyramid_host(y, levels)
+        src = y
+        for l in range(1, levels):
+            src = oracle.pyr_down(src)
+            assert np.array_equal(planes[l], src), ("pyramid", w, h, levels, l)
