@@ -169,3 +169,30 @@ def test_dct_block_preconditions(native):
     assert e.value.status == native.SVC_ERR_UNSUPPORTED
     native.dct_records_frames(torch.zeros((1, 32, 32, 3), dtype=torch.uint8, device="cuda"), 4,
                               torch.zeros((1, 4), dtype=torch.int32, device="cuda"))  # 4 x 4: the general kernel emits records
+
+
+def test_random_transform_shapes(native, oracle):
+    """Seeded random transform blocks -- every even side up to 64, single rows and columns of even length -- on random frame sizes they
+    divide: within the parity tolerance of the f64 DCT-II, energy preserved, and the fused quantiser bit-identical to the oracle's quant
+    lines applied to the device DCT."""
+    rng = np.random.default_rng(424242)
+    sides = [1] + list(range(2, 66, 2))
+    for _ in range(40):
+        bw, bh = int(rng.choice(sides)), int(rng.choice(sides))
+        if bw == 1 and bh == 1:
+            continue  # cv::dct has no 1 x 1 transform
+        if (bw == 1 or bh == 1) and rng.random() < 0.7:
+            bw = bh = int(rng.choice(sides[1:]))  # mostly two-dimensional blocks
+        w, h = bw * int(rng.integers(1, max(2, 160 // bw))), bh * int(rng.integers(1, max(2, 120 // bh)))
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = native.dct_host(bgr, (bw, bh))
+        _dct_close(got, oracle.dct_frame_f64(bgr, bw, bh))
+        e_in = (bgr.astype(np.float64) ** 2).sum()
+        assert abs(e_in - (got.astype(np.float64) ** 2).sum()) <= 1e-6 * max(e_in, 1.0), (bw, bh, w, h)
+        mvw, mvh = bw * int(rng.integers(1, 3)), bh * int(rng.integers(1, 3))
+        if w % mvw or h % mvh:
+            continue
+        types = rng.integers(0, 3, (h // mvh) * (w // mvw)).astype(np.uint32)
+        fg, bg = int(rng.choice([1, 2, 5])), int(rng.choice([16, 640]))
+        exp = oracle.quant_frame(got, mvw, mvh, types, fg, bg)
+        assert native.dct_quant_host(bgr, (bw, bh), types, (mvw, mvh), fg, bg).tobytes() == exp.tobytes(), (bw, bh, w, h, mvw, mvh)
