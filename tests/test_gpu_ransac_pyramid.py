@@ -186,3 +186,30 @@ def test_luma_pyramid_golden(native):
             assert np.array_equal(buf[offs[l]:offs[l] + want.size].cpu().numpy().reshape(want.shape), want), (n, l)
         ran += 1
     assert ran >= 2
+
+
+def test_random_ransac_parameters(native, oracle):
+    """Seeded random RansacParams (subset 1 ... 6, thresholds from sub-pixel to larger than any vector, success probabilities and inlier
+    ratios that give 1 ... 200 iterations), field sizes from a handful of vectors to 4K's, integral and fractional vectors, one / two /
+    no dominant motion: global motion, RMSE and the inlier list through svc_hip_ransac_host against the oracle, bit for bit."""
+    rng = np.random.default_rng(99)
+    for case in range(60):
+        n = int(rng.choice([7, 50, 396, 3600, 8160, 8193, 32400]))
+        subset = int(rng.integers(1, 7))
+        p = dict(subset_sz=subset, inlier_thresh=float(rng.choice([0.4, 1.5, 7.5, 40.0])), success_prob=float(rng.choice([0.5, 0.9, 0.99, 0.999])),
+                 inlier_ratio=float(rng.choice([0.2, 0.5, 0.8, 0.95])))
+        iters = oracle.ransac_iter_count(**p)
+        if not 1 <= iters <= 200 or subset > n:
+            continue
+        kind = int(rng.integers(0, 3))
+        mv = rng.integers(-14, 15, (n, 2)).astype(np.float32) if kind == 0 else np.zeros((n, 2), np.float32)
+        if kind >= 1:
+            mv[:] = rng.integers(-6, 7, 2)
+            cut = int(n * rng.random())
+            mv[cut:] = rng.integers(-14, 15, (n - cut, 2)) if kind == 1 else rng.integers(-6, 7, 2)
+        if rng.random() < 0.3:
+            mv += rng.random((n, 2)).astype(np.float32) * 0.5  # fractional vectors: the f32 sums are order-dependent
+        samples = np.stack([rng.permutation(n)[:subset] for _ in range(iters)]).astype(np.uint32)
+        gm, rmse, inl = native.ransac_host(mv, samples, **p)
+        egm, ermse, einl = oracle.ransac(mv, samples.ravel(), **p)
+        assert gm.tobytes() == egm.tobytes() and np.float32(rmse).tobytes() == np.float32(ermse).tobytes() and np.array_equal(inl, einl), (case, n, p, kind)
