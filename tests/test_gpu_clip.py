@@ -204,6 +204,27 @@ def test_sharded_clip_equals_unsharded(native, world, total, schedule):
     """All ranks of a sharded clip in ONE process: rank r's halo transport copies rank r - 1's last pyramid (the
     bytes RCCL would deliver).  Concatenated shard outputs == the unsharded clip's, bit for bit -- uneven shards,
     a rank with a single frame, rank 0 with a single frame (no pair at all) included."""
+    _check_sharding(CFG, world, total, schedule)
+
+
+def test_random_shardings_equal_the_unsharded_clip(native):
+    """Seeded random clip lengths, rank counts (2 ... 8), schedules and configurations (sizes, levels, MV and transform blocks): every
+    sharding of every clip gives the unsharded clip's outputs, bit for bit."""
+    rng = np.random.default_rng(808)
+    for i in range(14):
+        levels = int(rng.integers(1, 5))
+        f = 1 << (levels - 1)
+        mv_block = int(rng.choice([b for b in (8, 16, 32) if b >= 2 * f]))
+        dct_block = int(rng.choice([b for b in (4, 8, 16) if mv_block % b == 0]))
+        w, h = int(rng.integers(2 * mv_block + 1, 300)), int(rng.integers(2 * mv_block + 1, 220))
+        world = int(rng.integers(2, 9))
+        total = int(rng.integers(world, 30))
+        cfg = configs.CodecConfig(f"t-shard{i}-{w}x{h}-{levels}L", 60 + i, w, h, total, levels=levels, mv_block=mv_block,
+                                  search_range=int(rng.choice([r for r in (4, 8, 16) if r >= f])), dct_block=dct_block)
+        _check_sharding(cfg, world, total, int(rng.choice([clipmod.SERIAL, clipmod.PIPELINED])))
+
+
+def _check_sharding(CFG, world, total, schedule):  # noqa: N803 (the body below was written against the module's CFG)
     dev = torch.device("cuda")
     frames = _frames(CFG, total, dev)
     whole = clipmod.Clip(CFG, total, schedule=clipmod.SERIAL)
