@@ -32,6 +32,43 @@ __global__ __launch_bounds__(256) void stream(const uint4* __restrict__ in, uint
   if (W == 0 && acc.x == 0x12345678u && acc.y == 0x9abcdef0u) out[0] = acc;
 }
 
+// the 3 : 1 unit with WORK dependent-free integer dot products per lane and an LDS round trip per 16 of them between its loads and its
+// store: does the chip stream slower when VALU and LDS are busy beside the memory pipeline (the luma kernel: ~620 vector instructions per wave)?
+template <int WORK>
+__global__ __launch_bounds__(256) void stream31_with_work(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t units) {
+  __shared__ uint32_t lds[256 * 4];
+  const size_t u = xcd_contiguous_block(blockIdx.x, units);
+  const size_t i = u * 256 + threadIdx.x;
+  uint4 v0 = in[i * 3], v1 = in[i * 3 + 1], v2 = in[i * 3 + 2];
+  uint32_t a0 = v0.x ^ v1.y, a1 = v0.y ^ v2.z, a2 = v1.x ^ v2.w, a3 = v0.z ^ v1.w;
+#pragma unroll 16
+  for (int k = 0; k < WORK; k += 4) {
+    a0 = __builtin_amdgcn_udot4(v0.x + k, v1.x, a0, false);
+    a1 = __builtin_amdgcn_udot4(v0.y, v1.y + k, a1, false);
+    a2 = __builtin_amdgcn_udot4(v0.z + k, v2.x, a2, false);
+    a3 = __builtin_amdgcn_udot4(v0.w, v2.y + k, a3, false);
+    if ((k & 63) == 60) {
+      lds[threadIdx.x * 4 + (k >> 6 & 3)] = a0 ^ a2;
+      a1 ^= lds[(threadIdx.x ^ 1) * 4 + (k >> 6 & 3)];
+    }
+  }
+  out[u * 256 + threadIdx.x] = make_uint4(a0, a1, a2, a3);
+}
+
+template <int WORK>
+static void run_work(const uint4* in, uint4* out, size_t bytes) {
+  const uint32_t units = (uint32_t)(bytes / 16 / 256 / 3);
+  const double moved = (double)units * 256 * 16 * 4;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  auto launch = [&] { hipLaunchKernelGGL((stream31_with_work<WORK>), dim3(units), dim3(256), 0, 0, in, out, units); };
+  launch(); hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
+  printf("3 read : 1 written + %4d dot products per lane (+ LDS round trips)            %7.3f ms  %5.2f TB/s\n", WORK, ms, moved / ms / 1e9);
+}
+
 template <int R, int W>
 static void run(const char* name, const uint4* in, uint4* out, size_t bytes) {
   const uint32_t units = (uint32_t)(bytes / 16 / 256 / (R > W ? R : W));
@@ -62,5 +99,10 @@ int main() {
   run<1, 1>("copy 1 : 1", in, out, bytes);
   run<3, 1>("3 read : 1 written (luma)", in, out, bytes);
   run<1, 4>("1 read : 4 written (transform)", in, out, bytes);
+  run_work<0>(in, out, bytes);
+  run_work<128>(in, out, bytes);
+  run_work<512>(in, out, bytes);
+  run_work<1024>(in, out, bytes);
+  run_work<2048>(in, out, bytes);
   return 0;
 }
