@@ -214,14 +214,17 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
         exe = os.path.join(bin_dir, "stream_main")
         try:
             raw = os.path.join(d, "clip.raw")
-            n = min(len(src), 65)
-            src[:n].tofile(raw)
+            n = 65  # fixed length whatever the run's --frames (the sample frames, repeated, as for the application rows below)
+            with open(raw, "wb") as f:
+                for lo in range(0, n, len(src)):
+                    src[:min(len(src), n - lo)].tofile(f)
             r = subprocess.run([exe, raw, str(cfg.width), str(cfg.height), str(n), str(cfg.levels), str(cfg.dct_block), "0", "16",
                                 str(cfg.seed), "-"], capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
             out["stream_encoder_fps"] = float(r.stdout.split("encoded frames,")[1].split("frames/s")[0])
-            out["stream_encoder_sample"] = f"{n - 1} encoded frames, batch 16, second pass over the clip (first pass = warm-up)"
+            out["stream_encoder_sample"] = (f"{n - 1} encoded frames ({min(len(src), n)} distinct sample frames"
+                                            f"{', repeated' if len(src) < n else ''}), batch 16, second pass over the clip (first pass = warm-up)")
             os.remove(raw)
         except Exception as e:  # noqa: BLE001
             out["stream_encoder_fps"] = None
@@ -499,11 +502,27 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
                 enc.step()
             enc.sync()
             n_sus += 50
-        res["sustained"] = {"ms_per_step": (time.perf_counter() - t_sus) / n_sus * 1e3, "steps": n_sus,
-                            "seconds": time.perf_counter() - t_sus}
+        dt_sus = time.perf_counter() - t_sus
+        res["sustained"] = {"ms_per_step": dt_sus / n_sus * 1e3, "steps": n_sus, "seconds": dt_sus}
     enc.close()
     torch.cuda.empty_cache()
     return res
+
+
+def _launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a CHILD process (never an exec: this process has not touched the GPU and does not from here on), relay its
+    stdout (the one JSON line of rank 0), stderr and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"bench.py: --gpus {n} without a launcher (WORLD_SIZE unset): starting {n} ranks as a child: {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SVC_BENCH_SELF_LAUNCHED="1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main() -> None:
@@ -542,13 +561,24 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="N = 1: skip the PCIe-inclusive end_to_end object (measured outside the timed region)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="N = 1: measure end_to_end also on a shortened clip (--frames): by default only the full-length run does (it writes "
+                         "~1.2 GB of clips to /dev/shm and starts four child processes on the GPU)")
     args = ap.parse_args()
+    if args.frames and not args.end_to_end:
+        args.no_end_to_end = True
 
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: this process becomes the launcher and NEVER touches the GPU (nothing above this line has:
+        # importing torch and the package does not initialise HIP) -- a run must never report fewer ranks than it was asked for
+        raise SystemExit(_launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would report a rank count the run did not have")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # SVC_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (RCCL
@@ -611,6 +641,7 @@ def main() -> None:
     modes = ["strong"] if world == 1 else (["strong", "weak"] if args.scaling == "both" else [args.scaling])
     results = {m: run_mode(args, cfg, m, rank, world, dev, backend, comm) for m in modes}
 
+    rccl_mismatch = False
     if rank == 0:
         main_mode = modes[0]
         r = results[main_mode]
@@ -662,7 +693,11 @@ def main() -> None:
             pr = r["per_rank"]
             out["multi_gpu"] = {
                 "transport": r["halo"],
-                "rccl_ranks": clipmod.comm_info(comm)[0] if comm is not None else None,  # ncclCommCount of the C ABI's communicator
+                # ncclCommCount of the C ABI's communicator; torch's RCCL process group when the halo went through it; None = gloo rehearsal
+                "rccl_ranks": clipmod.comm_info(comm)[0] if comm is not None else (dist.get_world_size() if backend == "nccl" else None),
+                "rccl_ranks_source": "ncclCommCount (svc_hip_comm_info)" if comm is not None else
+                                     ("torch.distributed process group, backend nccl = RCCL" if backend == "nccl" else None),
+                "launcher": "bench.py itself (torch.distributed.run as a child process)" if os.environ.get("SVC_BENCH_SELF_LAUNCHED") else "external",
                 "transport_note": comm_note,
                 "halo_check": r["halo_check"],
                 "ms_per_step_by_rank": [x[0] for x in pr],
@@ -673,6 +708,9 @@ def main() -> None:
                         "between barriers.  halo_exchange_ms: event-to-event on the communication stream (includes waiting for the "
                         "neighbour's pyramid kernel)",
             }
+            if backend == "nccl" and out["multi_gpu"]["rccl_ranks"] != world:
+                print(f"bench.py: RCCL reports {out['multi_gpu']['rccl_ranks']} ranks, the line would say n_gpus = {world}", file=sys.stderr, flush=True)
+                rccl_mismatch = True
             out["multi_gpu"]["prediction"] = predicted_step(cfg, max(int(x[2]) for x in pr), out["ms_per_step"], world) if main_mode == "strong" else None
         if "weak" in results and main_mode != "weak":
             w = results["weak"]
@@ -745,12 +783,15 @@ def main() -> None:
             if cb.get("hbma_ms_per_frame") and "hbma" in kt:
                 # the one like-for-like ratio: the unmodified reference's motion search vs the MAD kernel, per frame pair
                 out["speedup_hbma_vs_cpu_1core"] = cb["hbma_ms_per_frame"] / (kt["hbma"] / info.pairs)
-        print(json.dumps(out), flush=True)
+        if not rccl_mismatch:
+            print(json.dumps(out), flush=True)
     if comm is not None:
         torch.cuda.synchronize()
         clipmod.comm_destroy(comm)
     if world > 1:
         dist.destroy_process_group()
+    if rccl_mismatch:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

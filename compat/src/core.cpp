@@ -1,7 +1,6 @@
 // compat/src/core.cpp -- cv::Mat storage and the core functions of compat/opencv2/core.hpp.
 // PRODUCT-SIDE ADAPTER, NOT AN ORACLE (see compat/opencv2/core/mat.hpp).  Arithmetic goes to include/svc_hip.h; what
 // stays on the host is allocation, copies, interleaving and type conversion of pixel data.
-#include <malloc.h>
 
 #include <algorithm>
 #include <chrono>
@@ -160,8 +159,10 @@ void Flush(Buffer& b) {
 // The application built on this adapter allocates and frees frame-sized blocks at frame rate -- the reference's SerializeEncodedFrame
 // grows a 25 MB std::vector by doubling for every frame (libs/encoder.cpp:241-266), its queues move such vectors between threads.  glibc
 // serves those sizes with mmap / munmap: a page fault per 4 KB, every frame.  Keeping them on the heap lets a frame reuse the pages the
-// previous one returned (the same two settings csrc/host/encoder_hip.cpp makes for its own vectors).
-static const int g_heap_keeps_large_blocks = (mallopt(M_MMAP_THRESHOLD, 1 << 30), mallopt(M_TRIM_THRESHOLD, 1 << 30), 0);
+// previous one returned -- but that is the HOST PROCESS's malloc policy, so loading this library changes nothing unless the process
+// asked: SVC_KEEP_LARGE_BLOCKS=1 in its environment (or its own call of svc_hip_tune_host_allocator).
+static const int g_heap_tuning_if_asked =
+    svc_hip_host_tuning_requested() ? svc_hip_tune_host_allocator(SVC_HOST_KEEP_LARGE_BLOCKS) : 0;
 
 void detail::ParallelRows(int rows, size_t bytes, const std::function<void(int, int)>& job) {
   if (rows <= 0) return;

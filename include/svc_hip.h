@@ -71,8 +71,25 @@ typedef struct svc_segment_params {
 #define SVC_HBMA_FORCE_LANE 8u           /* fused kernel, lane-per-block form without LDS (every fused shape) */
 
 const char* svc_hip_last_error(void);
-int svc_hip_abi_version(void); /* 4 (round 4: additions only -- svc_hip_dct_planes_host and the per-call image operations svc_hip_bgr2yuv_host ... svc_hip_dct_tiles_host) */
+int svc_hip_abi_version(void); /* 5 (round 5: additions only -- svc_hip_tune_host_allocator / svc_hip_host_tuning_requested; round 4 added svc_hip_dct_planes_host and the per-call image operations svc_hip_bgr2yuv_host ... svc_hip_dct_tiles_host) */
 int svc_hip_device_count(int* count);
+
+/* Host allocator tuning -- OPT-IN, never applied by loading a library or constructing an object.  An application that moves
+ * frame-sized blocks at frame rate (the reference's SerializeEncodedFrame grows a 25 MB std::vector per frame,
+ * libs/encoder.cpp:241-266; its queues move such vectors between threads, libs/encoder.hpp:57) pays a page fault per 4 KB on
+ * every one of them with glibc's defaults (mmap / munmap above 128 KB).  This call changes the CALLING PROCESS's malloc policy:
+ *   SVC_HOST_KEEP_LARGE_BLOCKS  mallopt(M_MMAP_THRESHOLD, 1 GiB) + mallopt(M_TRIM_THRESHOLD, 1 GiB): large blocks stay on the
+ *                               heap and are reused; the heap is not trimmed again (RSS stays at its high-water mark);
+ *   SVC_HOST_ONE_ARENA          mallopt(M_ARENA_MAX, 1): one heap for all threads (a block freed by the writer thread is reused by
+ *                               the encoding thread); serialises malloc / free across threads.
+ * Nothing in this repository calls it unless the process's environment has SVC_KEEP_LARGE_BLOCKS=1 (then compat/'s loader and
+ * class Encoder apply the flags they used to apply unasked in round 4).  Returns SVC_OK, or
+ * SVC_INVALID for unknown flag bits. */
+#define SVC_HOST_KEEP_LARGE_BLOCKS 1u
+#define SVC_HOST_ONE_ARENA 2u
+int svc_hip_tune_host_allocator(uint32_t flags);
+/* 1 when the environment opts in (SVC_KEEP_LARGE_BLOCKS=1), else 0: what the libraries consult before tuning anything. */
+int svc_hip_host_tuning_requested(void);
 
 /* Measurement aid, not part of the hot path: one launch of a plain streaming kernel (dwordx4 per lane,
  * contiguous across the workgroup) that per iteration reads `reads` x 16 B from d_in and writes `writes` x

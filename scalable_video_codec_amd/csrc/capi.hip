@@ -6,7 +6,10 @@
 // synchronous calls (libs/encoder.cpp:472-498).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+
+#include <malloc.h>
 
 #include "host/copy_crew.hpp"
 #include "svc_common.hpp"
@@ -144,7 +147,22 @@ using namespace svc;
 extern "C" {
 
 const char* svc_hip_last_error(void) { return g_err; }
-int svc_hip_abi_version(void) { return 4; }  // 4: + svc_hip_dct_planes_host, the per-call image operations of imageops.hip
+int svc_hip_abi_version(void) { return 5; }  // 5: + svc_hip_tune_host_allocator, svc_hip_host_tuning_requested (4: svc_hip_dct_planes_host, imageops.hip)
+
+// Opt-in only (include/svc_hip.h): nothing in this library calls it on its own.
+int svc_hip_tune_host_allocator(uint32_t flags) {
+  SVC_REQUIRE((flags & ~(SVC_HOST_KEEP_LARGE_BLOCKS | SVC_HOST_ONE_ARENA)) == 0, "tune_host_allocator: unknown flag bits 0x%x", flags);
+  if (flags & SVC_HOST_KEEP_LARGE_BLOCKS) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  }
+  if (flags & SVC_HOST_ONE_ARENA) mallopt(M_ARENA_MAX, 1);
+  return SVC_OK;
+}
+int svc_hip_host_tuning_requested(void) {
+  const char* e = std::getenv("SVC_KEEP_LARGE_BLOCKS");
+  return e && e[0] == '1' && e[1] == 0;
+}
 
 int svc_hip_device_count(int* count) {
   SVC_REQUIRE(count, "device_count: null output");

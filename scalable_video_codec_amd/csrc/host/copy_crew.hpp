@@ -12,14 +12,18 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace svc {
 
 // One core moves 6 MB in ~0.55 ms, which is what a 1080p frame's share of PCIe takes in BOTH directions together, so a single copying
 // thread -- not the link -- would bound a host-fed pipeline.  The calling thread takes the first share of the rows itself and waits for
 // the others, so Copy() returns when the bytes are there.  One caller at a time (callers serialise on a mutex).
+// fork(): threads do not survive into the child, so a crew inherited from the parent has no helpers -- the child (any process whose
+// pid is not the constructing one) runs every job on the calling thread alone and never touches the inherited locks.
 class CopyCrew {
  public:
-  explicit CopyCrew(uint32_t helpers) {
+  explicit CopyCrew(uint32_t helpers) : owner_(getpid()) {
     for (uint32_t i = 0; i < helpers; ++i) threads_.emplace_back([this, i] { Run(i); });
   }
   ~CopyCrew() {
@@ -31,6 +35,7 @@ class CopyCrew {
   // job moves in all: below 1 MB the caller runs it alone.  Shares must not overlap in what they write.
   template <typename Job>
   void Rows(uint32_t rows, size_t bytes, const Job& job) {
+    if (getpid() != owner_) { if (rows) job(0u, rows); return; }  // a forked child: no helper threads here
     std::lock_guard<std::mutex> one_caller(caller_);
     const uint32_t parts = (uint32_t)threads_.size() + 1;
     if (parts == 1 || bytes < (1u << 20) || rows == 0) { if (rows) job(0u, rows); return; }
@@ -42,8 +47,18 @@ class CopyCrew {
       ++generation_;
     }
     wake_.notify_all();
+    // the helpers hold a reference to `job` until they have counted out: whatever the caller's share does (throwing included),
+    // this frame must not unwind before they have
+    struct WaitForHelpers {
+      CopyCrew* c;
+      ~WaitForHelpers() {
+        for (int spin = 0; spin < 4096 && c->left_.load(std::memory_order_acquire) != 0; ++spin) std::this_thread::yield();
+        if (c->left_.load(std::memory_order_acquire) == 0) return;
+        std::unique_lock<std::mutex> l(c->mu_);  // a helper was descheduled: sleep instead of burning the core
+        c->done_.wait(l, [this] { return c->left_.load(std::memory_order_acquire) == 0; });
+      }
+    } wait{this};
     if (rows / parts) job(0u, rows / parts);
-    while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
   }
   // one flat run of bytes, cut into 64 KiB rows for the crew
   void Copy(void* dst, const void* src, size_t bytes) {
@@ -73,12 +88,16 @@ class CopyCrew {
       l.unlock();
       const uint32_t r0 = (uint32_t)((uint64_t)rows * (index + 1) / parts), r1 = (uint32_t)((uint64_t)rows * (index + 2) / parts);
       if (r1 > r0) job(r0, r1);
-      left_.fetch_sub(1, std::memory_order_release);
+      if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        std::lock_guard<std::mutex> g(mu_);  // the caller may be asleep on done_ (it checks left_ under mu_)
+        done_.notify_one();
+      }
     }
   }
   std::vector<std::thread> threads_;
   std::mutex caller_, mu_;
-  std::condition_variable wake_;
+  std::condition_variable wake_, done_;
+  const pid_t owner_;
   uint64_t generation_ = 0;
   bool stop_ = false;
   std::function<void(uint32_t, uint32_t)> job_;

@@ -13,7 +13,6 @@
 //
 // Scope: every configuration the reference's Validate admits -- non-square MV and transform blocks included (those take the per-level
 // search kernel and the planes + serialiser route instead of the tuned ones).
-#include <malloc.h>
 
 #include <algorithm>
 #include <chrono>
@@ -28,6 +27,7 @@
 #include "codec.hpp"    // the reference's (Header)
 #include "encoder.hpp"  // the reference's (class Encoder, EncoderConfig, Validate)
 #include "svc/stream_encoder.hpp"
+#include "svc_hip.h"  // svc_hip_tune_host_allocator (opt-in)
 
 namespace {
 bool g_seeded = false;
@@ -135,11 +135,10 @@ void Encoder::operator()() {
   }
 
   // Every encoded frame leaves as a fresh 25 MB std::vector (the queue's element type, libs/encoder.hpp:57) that the writer thread frees
-  // a moment later.  glibc serves such sizes with mmap / munmap -- a page fault per 4 KB on every frame; keeping them on the heap
-  // lets the next frame reuse the block the writer just returned.
-  mallopt(M_MMAP_THRESHOLD, 1 << 30);
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_ARENA_MAX, 1);  // ... whichever thread fills it: one heap for the copy helpers below, this thread and the writer
+  // a moment later.  glibc serves such sizes with mmap / munmap -- a page fault per 4 KB on every frame; keeping them on ONE heap lets
+  // the next frame reuse the block the writer just returned.  That is the host process's malloc policy: applied only where the process
+  // opted in (SVC_KEEP_LARGE_BLOCKS=1, or its own svc_hip_tune_host_allocator call before this one).
+  if (svc_hip_host_tuning_requested()) svc_hip_tune_host_allocator(SVC_HOST_KEEP_LARGE_BLOCKS | SVC_HOST_ONE_ARENA);
   try {
     const auto t_begin = std::chrono::steady_clock::now();
     svc::StreamEncoder enc(c);  // page-locks the batch buffers: most of a short run's time

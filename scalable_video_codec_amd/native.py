@@ -54,6 +54,8 @@ SIGNATURES = {
     "svc_hip_last_error": (C.c_char_p, []),
     "svc_hip_abi_version": (C.c_int, []),
     "svc_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "svc_hip_tune_host_allocator": (C.c_int, [_u32]),
+    "svc_hip_host_tuning_requested": (C.c_int, []),
     "svc_hip_pyramid_bytes": (_u64, [_u32, _u32, _u32]),
     "svc_hip_hbma_pairs": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp]),
     "svc_hip_hbma_kernel_name": (C.c_char_p, [_u32, _u32, _u32, _u32, _u32, _u32, _u32]),

@@ -10,6 +10,12 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+#include <stdexcept>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "host/copy_crew.hpp"
 
 static int g_fail = 0;
@@ -63,6 +69,36 @@ int main() {
     svc::CopyCrew crew(1 + i % 4);
     if (i & 1) flat(crew, (size_t)(1u << 20) + i, 200 + i);
   }
+  {  // a job that throws on the caller's share: the helpers finish against a live job, the exception reaches the caller, the crew still works
+    svc::CopyCrew crew(3);
+    std::atomic<uint32_t> rows_done{0};
+    bool thrown = false;
+    try {
+      crew.Rows(64, (size_t)4 << 20, [&](uint32_t r0, uint32_t r1) {
+        if (r0 == 0) throw std::runtime_error("caller's share");
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));  // still running when the caller's frame would unwind
+        rows_done.fetch_add(r1 - r0);
+      });
+    } catch (const std::runtime_error&) { thrown = true; }
+    CHECK(thrown && rows_done.load() == 48);
+    flat(crew, (size_t)(2u << 20) + 11, 300);
+  }
+#if !defined(__SANITIZE_THREAD__)
+  {  // fork(): the child inherits the crew object but none of its threads -- a large copy there must complete on the calling thread
+    svc::CopyCrew crew(3);
+    flat(crew, (size_t)(2u << 20), 400);
+    std::fflush(stdout);
+    pid_t pid = fork();
+    if (pid == 0) {
+      g_fail = 0;
+      flat(crew, (size_t)(3u << 20) + 9, 401);
+      _exit(g_fail ? 1 : 0);
+    }
+    int status = -1;
+    CHECK(pid > 0 && waitpid(pid, &status, 0) == pid && WIFEXITED(status) && WEXITSTATUS(status) == 0);
+    flat(crew, (size_t)(2u << 20) + 1, 402);  // the parent's crew is untouched
+  }
+#endif
   if (g_fail) return 1;
   std::puts("copy crew ok");
   return 0;

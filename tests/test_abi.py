@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/svc_hip.h but not exported"
     assert set(names) == set(native.SIGNATURES), set(names) ^ set(native.SIGNATURES)
-    assert lib.svc_hip_abi_version() == 4
+    assert lib.svc_hip_abi_version() == 5
 
 
 def test_clip_header_symbols_are_exported():

@@ -76,3 +76,41 @@ def test_reference_encoder_sources_compile_unchanged(compat_lib, tmp_path):
     for piece in ("apps/encoder.cpp", "libs/encoder.cpp", "libs/cli.cpp", "compat/src/thread_guard.cpp", "-lsvc_opencv_compat",
                   "-DSVC_MOTION_SSE2"):
         assert piece in text, piece
+
+
+_MALLOC_PROBE = r"""
+import ctypes, sys
+libc = ctypes.CDLL("libc.so.6")
+class MI(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("arena", "ordblks", "smblks", "hblks", "hblkhd", "usmblks", "fsmblks", "uordblks", "fordblks", "keepcost")]
+libc.mallinfo.restype = MI
+libc.malloc.restype = ctypes.c_void_p
+libc.malloc.argtypes = [ctypes.c_size_t]
+libc.free.argtypes = [ctypes.c_void_p]
+lib = ctypes.CDLL(sys.argv[1])
+if len(sys.argv) > 2:  # the explicit call an application may make instead of the environment variable
+    hip = ctypes.CDLL(sys.argv[2])
+    assert hip.svc_hip_tune_host_allocator(ctypes.c_uint32(1)) == 0 and hip.svc_hip_tune_host_allocator(ctypes.c_uint32(64)) != 0
+before = libc.mallinfo().hblks
+p = libc.malloc(64 << 20)  # well above glibc's largest dynamic mmap threshold (32 MB): mmapped unless the policy was changed
+after = libc.mallinfo().hblks
+libc.free(p)
+print("mmapped" if after > before else "heap")
+"""
+
+
+def test_loading_the_adapter_leaves_the_host_allocator_alone(compat_lib):
+    """Round 4's libsvc_opencv_compat.so called mallopt from a static initialiser: any process that loaded it got a 1 GiB mmap
+    threshold and an untrimmed heap.  Now opt-in: nothing changes unless the process's environment says SVC_KEEP_LARGE_BLOCKS=1 (or it
+    calls svc_hip_tune_host_allocator itself)."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "SVC_KEEP_LARGE_BLOCKS"}
+
+    def probe(extra_env, *more):
+        r = subprocess.run([sys.executable, "-c", _MALLOC_PROBE, compat_lib, *more], capture_output=True, text=True, timeout=120, env=dict(env, **extra_env))
+        assert r.returncode == 0, r.stderr
+        return r.stdout.strip()
+    assert probe({}) == "mmapped"                               # did not ask: glibc's default policy
+    assert probe({"SVC_KEEP_LARGE_BLOCKS": "0"}) == "mmapped"
+    assert probe({"SVC_KEEP_LARGE_BLOCKS": "1"}) == "heap"      # asked through the environment
+    assert probe({}, build.LIB_HIP) == "heap"                   # asked through the C ABI

@@ -100,3 +100,33 @@ def test_ransac_samples_are_distinct_and_in_range():
     srt = s.sort(dim=-1).values
     assert bool((srt[..., 1:] != srt[..., :-1]).all())
     assert torch.equal(s, pipeline.ransac_samples(5, 35, 3, 8160, 99, "cpu"))
+
+
+def _bench(args, env_extra, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+
+
+def test_bench_refuses_a_rank_count_it_does_not_have():
+    """--gpus N must equal WORLD_SIZE whenever a launcher set one (decided before anything touches a GPU, so this runs here)."""
+    r = _bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+    r = _bench(["--gpus", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    r = _bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_gpus_n_without_launcher_becomes_the_launcher():
+    """No GPU here: the ranks the self-launcher starts each refuse ("needs a GPU") and the parent relays the failure -- what matters
+    is that TWO ranks were started rather than one rank printing n_gpus 1."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the -m gpu test on a GPU box")
+    r = _bench(["--gpus", "2", "--frames", "4", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "starting 2 ranks as a child" in r.stderr and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
