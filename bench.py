@@ -719,25 +719,29 @@ def main() -> None:
                            "frames_per_gpu": w["info"].frames, "encoded_frames_per_step": w["encoded_per_step"],
                            "rank0_kernel_ms_per_step": {k: v for k, v in w["stage_ms_per_step"].items() if k not in side}}
         if "hbma" in kt:
-            pmc = pipeline.load_pmc_traffic().get(cfg.name, {})
+            # the library's own dispatch names the kernel this run launched (svc_hip_hbma_kernel_name)
+            kname = native.hbma_kernel_name(cfg.levels, pw, ph, cfg.search_range, cfg.mv_block, cfg.mv_block, hbma_flags_of(args))
 
-            def traffic(key, pairs):  # offline PMC, recorded for a whole-clip launch: scaled to this launch's pairs
-                v, base = pmc.get(key), pmc.get("pairs")
-                return v * pairs / base if v is not None and base else None
+            def traffic(group, key, pairs, launched=None):
+                """Counter traffic is collected offline (rocprofv3 --pmc passes cannot share a run with the timed region) and only quoted
+                when it is tied to THIS build: same kernel dispatched, same sources (hash recorded at collection time).  Recorded for a
+                whole-clip launch, scaled to this launch's pairs.  Returns (bytes or None, where it came from or why it is null)."""
+                v, base, why = pipeline.pmc_traffic_for(cfg.name, group, key, launched)
+                if v is None:
+                    return None, f"null: {why}"
+                return v * pairs / base, f"offline PMC ({why}), same {group} sources as this build, scaled from {base} to {pairs} frame pairs; not measured in this run"
             hbma_bytes = cfg.hbma_bytes_per_frame() * info.pairs
             hbma_ms = kt["hbma"] / nl["hbma"]
             hbma_gbps = hbma_bytes / (hbma_ms * 1e-3) / 1e9
-            # the library's own dispatch names the kernel this run launched (svc_hip_hbma_kernel_name)
-            kname = native.hbma_kernel_name(cfg.levels, pw, ph, cfg.search_range, cfg.mv_block, cfg.mv_block, hbma_flags_of(args))
+            hbma_traffic, hbma_traffic_source = traffic("hbma", "hbma_bytes_per_launch", info.pairs, kname)
             out["roofline"] = {
                 "kernel": {"hbma_tiled16_kernel": "hbma_tiled16_kernel (MAD search, all pyramid levels, windows of levels 2 and 1 staged in LDS)",
                            "hbma_fused_kernel": "hbma_fused_kernel (MAD search, all pyramid levels, lane per block)",
                            "hbma_wave_level_kernel": "hbma_wave_level_kernel (LDS-staged wave-per-block search)"}[kname],
                 "bound": "hbm", "achieved": hbma_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": hbma_gbps / HBM_PEAK_GBPS,
-                "traffic": traffic("hbma_bytes_per_launch", info.pairs),
-                "traffic_source": (f"offline PMC ({pmc.get('source')}), scaled from {pmc.get('pairs')} to {info.pairs} frame pairs; not measured in this run"
-                                   if pmc else None),
+                "traffic": hbma_traffic,
+                "traffic_source": hbma_traffic_source,
                 "algorithmic_bytes_per_launch": hbma_bytes,
                 "avg_launch_ms": hbma_ms,
                 "launches_per_step": nl["hbma"],
@@ -748,12 +752,14 @@ def main() -> None:
                 dct_bytes = cfg.dct_bytes_per_frame() * info.pairs
                 dct_ms = kt["dct_quant"] / nl["dct_quant"]
                 dct_gbps = dct_bytes / (dct_ms * 1e-3) / 1e9
+                dct_key = "dct_records_bytes_per_launch" if args.wire else "dct_bytes_per_launch"
+                dct_traffic, dct_traffic_source = traffic("dct", dct_key, info.pairs)
                 out["roofline_dct"] = {
                     "kernel": f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)",
                     "bound": "hbm", "achieved": dct_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": dct_gbps / HBM_PEAK_GBPS,
-                    "traffic": traffic("dct_bytes_per_launch", info.pairs),
-                    "traffic_source": out["roofline"]["traffic_source"],
+                    "traffic": dct_traffic,
+                    "traffic_source": dct_traffic_source,
                     "algorithmic_bytes_per_launch": dct_bytes, "avg_launch_ms": dct_ms, "launches_per_step": nl["dct_quant"],
                 }
         if world == 1 and "hbma" in kt and "dct_quant" in kt:

@@ -479,6 +479,9 @@ int svc_hip_connected_components_host(const uint8_t* image, uint32_t w, uint32_t
   a.labels = reinterpret_cast<int32_t*>(st.dev + img_b + par_b);
   a.count = reinterpret_cast<uint32_t*>(st.dev + img_b + par_b + n * 4);
   a.w = w; a.h = h; a.n = (uint32_t)n; a.conn = connectivity;
+  // ONE workgroup by design (union_find.hpp, SCOPE): this is the per-call form behind compat/'s cv::connectedComponents, fed MV-field-sized
+  // masks (8 160 cells at 1080p, 32 400 at 4K: tens of microseconds).  The size cap above admits far larger images, which then take
+  // milliseconds on one CU -- correct, slow, and not the throughput path (the batched form is segment.hip's label kernel).
   hipLaunchKernelGGL(cc_kernel, dim3(1), dim3(kCcT), 0, st.stream, a);
   if ((rc = check_launch("cc_kernel"))) return rc;
   SVC_HIP_TRY(hipMemcpyAsync(st.pin + img_b, a.labels, n * 4 + 4, hipMemcpyDeviceToHost, st.stream));

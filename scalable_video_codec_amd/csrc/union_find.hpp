@@ -9,6 +9,11 @@ namespace svc {
 
 // Lock-free union-find on `parent` (LDS or global): a set's root is its smallest index (= its first element in raster
 // order); links always go from the larger root to the smaller with atomicMin, so concurrent unions commute.
+// SCOPE: uf_find reads `parent` with plain loads while other waves atomicMin it.  That is sound for waves of ONE workgroup (one CU: LDS, or
+// global memory seen through that CU's one vector L1, where a stale parent is still an ancestor and the loop in uf_unite retries).  Every
+// user in this repo is a single workgroup per union-find domain (segment.hip's label kernel: one workgroup per frame; imageops.hip's
+// cc_kernel: one workgroup per image).  A grid that unites across workgroups would need device-scope atomic loads here (L1s of
+// different CUs are not coherent) and a grid-wide phase split between uniting and numbering, as segment.hip's launch sequences have.
 __device__ __forceinline__ uint32_t uf_find(const uint32_t* parent, uint32_t x) {
   uint32_t p = parent[x];
   while (p != x) { x = p; p = parent[x]; }

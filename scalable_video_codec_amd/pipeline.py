@@ -41,6 +41,54 @@ def load_pmc_traffic() -> Dict[str, float]:
         return {}
 
 
+# The kernel sources each counter-traffic figure depends on (svc_common.hpp, shared with the host staging code, is left out): a figure is only quoted for a build whose sources hash the same as the
+# build it was collected on (tools/summarize_pmc.py records the hashes next to every summary; bench.py compares).
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+KERNEL_SOURCE_GROUPS = {
+    "hbma": ("hbma_fused.hip", "hbma_fused8.hip", "hbma_fused32.hip", "hbma_fused_kernel.hpp", "hbma_search.hpp", "hbma_tiled.hip",
+             "hbma_wave.hip"),
+    "dct": ("dct.hip", "dct_tables.inc"),
+    "luma_pyr1": ("luma_pyramid.hip",),
+}
+
+
+def kernel_source_hashes() -> Dict[str, Optional[str]]:
+    """sha256[:16] over the sources of each kernel group as they are in THIS checkout (None where a file is missing)."""
+    import hashlib
+    out = {}
+    for group, files in KERNEL_SOURCE_GROUPS.items():
+        h = hashlib.sha256()
+        try:
+            for fn in files:
+                with open(os.path.join(_CSRC, fn), "rb") as f:
+                    h.update(fn.encode() + b"\0" + f.read() + b"\0")
+            out[group] = h.hexdigest()[:16]
+        except OSError:
+            out[group] = None
+    return out
+
+
+def pmc_traffic_for(config_name: str, group: str, key: str, launched_kernel: Optional[str] = None):
+    """(bytes per recorded launch, recorded pairs, source) of profiles/pmc_traffic.json for `key` -- or (None, None, reason) when the
+    figure cannot be tied to this build: no record, no source hash recorded with it, sources of `group` changed since it was
+    collected, or (motion search) the library now dispatches another kernel than the one that was measured."""
+    rec = load_pmc_traffic().get(config_name)
+    if not rec or rec.get(key) is None or not rec.get("pairs"):
+        return None, None, f"no counter traffic recorded for {config_name} / {key} in profiles/pmc_traffic.json"
+    on = rec.get("collected_on") or {}
+    want = (on.get("source_sha16") or {}).get(group)
+    if not want:
+        return None, None, f"{rec.get('source')}: no source hash was recorded with it (collected before round 5): not tied to this build"
+    have = kernel_source_hashes().get(group)
+    if have != want:
+        return None, None, (f"{rec.get('source')}: collected on {group} sources {want}, this build has {have}: the kernels changed since; "
+                            "re-collect with tools/pmc_passes.sh")
+    measured = (on.get("kernels") or {}).get(group)
+    if launched_kernel is not None and measured and not any(launched_kernel in m for m in measured):
+        return None, None, f"{rec.get('source')}: collected on {measured}, this run launches {launched_kernel}"
+    return rec[key], rec["pairs"], rec.get("source")
+
+
 def plan_shards(total_frames: int, world: int) -> List[Tuple[int, int, bool]]:
     """Cuts a clip of `total_frames` into `world` consecutive chunks, the first `total_frames % world` ranks one frame
     longer -- the plan of svc::PlanShard (include/svc/clip_encoder.hpp), restated here in plain Python so that the CPU

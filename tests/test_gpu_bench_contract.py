@@ -54,6 +54,10 @@ def test_bench_line_contract():
     assert set(d["hbm_streaming_measured"]) >= {"read_only", "write_only", "copy_1_read_1_write", "3_read_1_write", "unit"}
     assert not any(k.startswith("frac_of_streaming") for k in r)
     assert "traffic_source" in r and d["config"]["driver"].startswith("svc::ClipEncoder")
+    # counter traffic is tied to the build (schema, both branches): a number with the file it came from, or null with the reason
+    for rf in (r, d["roofline_dct"]):
+        assert (rf["traffic"] is None and rf["traffic_source"].startswith("null: ")) or \
+               (rf["traffic"] > 0 and rf["traffic_source"].startswith("offline PMC (profiles/")), rf
     assert set(d["kernel_ms_per_step"]) == {"luma_pyramid", "hbma", "dct_quant"}  # the main stream, back to back
     assert set(d["overlapped_ms_per_step"]) == {"ransac", "segment", "note"}        # beside it (pipelined schedule)
     assert all(v > 0 for v in d["kernel_ms_per_step"].values())

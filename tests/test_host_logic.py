@@ -130,3 +130,31 @@ def test_bench_gpus_n_without_launcher_becomes_the_launcher():
     r = _bench(["--gpus", "2", "--frames", "4", "--steps", "1", "--warmup", "0"], {})
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "starting 2 ranks as a child" in r.stderr and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+
+
+def test_counter_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
+    """roofline.traffic comes from an offline counter run; it is quoted only for the kernels it was collected on (name and
+    source hash), else null with the reason (both branches)."""
+    import json
+    h = pipeline.kernel_source_hashes()
+    assert set(h) == {"hbma", "dct", "luma_pyr1"} and all(v and len(v) == 16 for v in h.values())
+    db = {"X": {"source": "profiles/x.csv", "pairs": 10, "hbma_bytes_per_launch": 1000.0, "dct_bytes_per_launch": 5000.0,
+                "collected_on": {"kernels": {"hbma": ["svc::hbma_fused_kernel<16, 3, 2>"]}, "source_sha16": {"hbma": h["hbma"], "dct": "0" * 16}}},
+          "OLD": {"source": "profiles/old.csv", "pairs": 10, "hbma_bytes_per_launch": 1.0}}
+    p = tmp_path / "pmc.json"
+    p.write_text(json.dumps(db))
+    monkeypatch.setattr(pipeline, "_PMC_JSON", str(p))
+    assert pipeline.pmc_traffic_for("X", "hbma", "hbma_bytes_per_launch", "hbma_fused_kernel") == (1000.0, 10, "profiles/x.csv")
+    v, _, why = pipeline.pmc_traffic_for("X", "hbma", "hbma_bytes_per_launch", "hbma_tiled16_kernel")
+    assert v is None and "this run launches hbma_tiled16_kernel" in why
+    v, _, why = pipeline.pmc_traffic_for("X", "dct", "dct_bytes_per_launch")
+    assert v is None and "kernels changed since" in why
+    v, _, why = pipeline.pmc_traffic_for("OLD", "hbma", "hbma_bytes_per_launch", "hbma_fused_kernel")
+    assert v is None and "no source hash" in why
+    v, _, why = pipeline.pmc_traffic_for("nope", "hbma", "hbma_bytes_per_launch")
+    assert v is None and "no counter traffic recorded" in why
+    # the committed table: every record that claims a hash names the kernels it was collected on
+    monkeypatch.undo()
+    for name, rec in pipeline.load_pmc_traffic().items():
+        if isinstance(rec, dict) and rec.get("collected_on", {}).get("source_sha16"):
+            assert set(rec["collected_on"]["source_sha16"]) <= set(rec["collected_on"]["kernels"]), name

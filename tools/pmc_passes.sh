@@ -26,5 +26,5 @@ for i in ${PMC_GROUPS:-1 2 3 4 5}; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-probe --no-end-to-end --sustain-seconds 0 --schedule serial "$@" > "$out/pass$i.log" 2>&1
   echo "pass $i ($grp): exit $?"
 done
-python3 tools/summarize_pmc.py "$out" "$out/summary.csv"
+SVC_PMC_BENCH_ARGS="--schedule serial $*" python3 tools/summarize_pmc.py "$out" "$out/summary.csv"
 rm -rf "$out"/pass*/  # raw per-dispatch CSVs are large; the summary is what is kept

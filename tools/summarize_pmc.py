@@ -19,3 +19,15 @@ for k in sorted(acc):
 out = sys.argv[2] if len(sys.argv) > 2 else None
 f = open(out, "w", newline="") if out else sys.stdout
 csv.writer(f).writerows(lines)
+
+if out:
+    # what the summary was collected ON, next to it: the kernels seen and the hash of their sources in this checkout (the run and this
+    # script share one snapshot of the repo on the GPU box).  bench.py quotes counter traffic only for a build with the same hashes.
+    import datetime, json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from scalable_video_codec_amd import pipeline
+    f.close()
+    meta = {"summary": os.path.basename(out), "kernels": sorted(acc), "source_sha16": pipeline.kernel_source_hashes(),
+            "collected_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"), "bench_args": os.environ.get("SVC_PMC_BENCH_ARGS", "")}
+    with open(out + ".meta.json", "w") as m:
+        json.dump(meta, m, indent=1)
