@@ -400,7 +400,8 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     schedule = clipmod.SERIAL if args.schedule == "serial" else clipmod.PIPELINED
     hbma_flags = hbma_flags_of(args)
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
-             (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0)
+             (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0) | \
+             (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
                        lat_depth=args.lat_depth, tuning=tuning)
@@ -540,6 +541,9 @@ def main() -> None:
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
+    ap.add_argument("--two-bgr-passes", action="store_true",
+                    help="--wire: luma + pyramid and the record-emitting transform as two passes over the BGR clip (A/B of the default, which reads "
+                         "it once: records + luma plane from one kernel at the front of the step, type words stored after the segmentation)")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-stage HIP events on every n-th timed step (every step when --steps < 8)")
     # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The
     # environment variables of the round-2 scripts under tools/ are honoured HERE as defaults, not inside the library.
@@ -749,13 +753,16 @@ def main() -> None:
                         + ("; RANSAC + segmentation of an earlier step may still be running beside it (pipelined schedule)" if args.schedule == "pipelined" else ""),
             }
             if "dct_quant" in kt:
-                dct_bytes = cfg.dct_bytes_per_frame() * info.pairs
+                one_pass = "type_patch" in kt  # --wire: the transform kernel also stores the luma plane (one pass over the BGR clip)
+                dct_bytes = (cfg.dct_bytes_per_frame() + (pw * ph if one_pass else 0)) * info.pairs
                 dct_ms = kt["dct_quant"] / nl["dct_quant"]
                 dct_gbps = dct_bytes / (dct_ms * 1e-3) / 1e9
                 dct_key = "dct_records_bytes_per_launch" if args.wire else "dct_bytes_per_launch"
                 dct_traffic, dct_traffic_source = traffic("dct", dct_key, info.pairs)
                 out["roofline_dct"] = {
-                    "kernel": f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)",
+                    "kernel": (f"dct_kernel<{cfg.dct_block}, records, luma> (records of the raw coefficients + the luma plane from one pass over the BGR clip)" if one_pass else
+                               f"dct_kernel<{cfg.dct_block}, records> (raw coefficients, libs/encoder.cpp:638-650)" if args.wire else
+                               f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)"),
                     "bound": "hbm", "achieved": dct_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": dct_gbps / HBM_PEAK_GBPS,
                     "traffic": dct_traffic,
@@ -766,11 +773,18 @@ def main() -> None:
             # the whole step against the same peak: the three main-stream kernels run back to back and are all
             # HBM-bound, so (their algorithmic bytes) / (step time) says how far the STEP is from the roofline
             step_bytes = cfg.luma_pyramid_bytes_per_frame() * info.frames + hbma_bytes + dct_bytes
+            if one_pass:
+                # BGR in once, pyramid out, coefficients out: what the one-pass form must move (the transform's figure above already holds the BGR
+                # read and the luma plane's store; left of the pyramid stage are the first frame's own luma pass and the levels above 0)
+                step_bytes = hbma_bytes + dct_bytes + cfg.luma_pyramid_bytes_per_frame() * (info.frames - info.pairs) + \
+                    (cfg.luma_pyramid_bytes_per_frame() - 4 * pw * ph) * info.pairs
             step_gbps = step_bytes / (r["elapsed"] / args.steps) / 1e9
             out["roofline_step"] = {"bound": "hbm", "achieved": step_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": step_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
-                                    "note": "luma+pyramid, motion search and transform of one step / ms_per_step; "
-                                            "RANSAC + segmentation move < 1 % of these bytes"}
+                                    "note": ("one pass over the BGR clip (--wire): BGR in once, pyramid out, motion search, records out / ms_per_step; the same step as two "
+                                             "passes moves 3 W H more per frame" if one_pass else
+                                             "luma+pyramid, motion search and transform of one step / ms_per_step; "
+                                             "RANSAC + segmentation move < 1 % of these bytes")}
         if r.get("sustained"):
             out["sustained_ms_per_step"] = r["sustained"]["ms_per_step"]
             out["sustained"] = {**r["sustained"], "value": r["encoded_per_step"] / (r["sustained"]["ms_per_step"] * 1e-3), "unit": "frames/s",

@@ -23,6 +23,13 @@
 // iterations to finish, consecutive steps alternating between
 // two such streams, and the halo of the newest step crosses xGMI meanwhile.  The small per-frame outputs exist in four
 // sets, pyramids in two; Flush() drains the pipeline.
+//
+// Wire output (records of the RAW coefficients, what the reference's encoder emits: libs/encoder.cpp:638-650) with the tuned 8x8 /
+// 16x16 transform reads the BGR clip ONCE per step: the record-emitting transform of step s runs at the FRONT of the step and stores
+// the luma plane as a by-product (svc_hip_dct_records_luma_frames), the pyramid's other levels follow from it, and the type words --
+// region ids that exist only after motion search, RANSAC and segmentation of the same step -- are stored into the records where the
+// transform used to run, 2 + depth iterations later (svc_hip_wire_patch_types_frames).  A step's records are complete when its patch
+// has run, so they exist in as many sets as the small per-frame outputs.
 #ifndef SVC_CLIP_ENCODER_HPP
 #define SVC_CLIP_ENCODER_HPP
 
@@ -71,9 +78,10 @@ struct ClipEncoderConfig {
   bool segment_fork = false;            // pipelined: let the segmentation fork its heavy attempts to a side stream
   bool inline_rmse = false;             // pipelined: keep RANSAC's in-order RMSE sum inside its kernel instead of beside the segmentation
   bool narrow_attempts = false;         // segmentation: one workgroup per (frame, attempt) whatever the shard size (SVC_LAUNCH_NO_WIDE)
+  bool two_bgr_passes = false;          // wire: luma + pyramid and the record-emitting transform as two passes over the BGR clip (A/B of the fused form)
 };
 
-enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kCount };
+enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kTypePatch, kCount };
 enum class Buffer : uint32_t { kMv = 0, kMinMad, kGlobalMotion, kRmse, kInlierMask, kInlierCount, kBlockTypes,
                                kCoeffs, kRecords, kPyramids, kBgr, kCount };
 

@@ -30,6 +30,8 @@ typedef struct svc_clip svc_clip;
 #define SVC_CLIP_TUNE_SEGMENT_FORK 2u      /* pipelined: the segmentation may fork its heavy attempts to a side stream */
 #define SVC_CLIP_TUNE_INLINE_RMSE 8u       /* pipelined: RANSAC keeps its in-order RMSE sum inside its kernel */
 #define SVC_CLIP_TUNE_NARROW_ATTEMPTS 4u   /* segmentation: never spread a heavy frame's k-means attempts over workgroups */
+#define SVC_CLIP_TUNE_TWO_BGR_PASSES 16u   /* wire: keep luma + pyramid and the record-emitting transform as two passes over the BGR clip
+                                              (the default reads it once: records + luma plane from one kernel, type words stored afterwards) */
 
 typedef struct svc_clip_config {
   uint32_t struct_size;   /* sizeof(svc_clip_config) of the caller's build: svc_clip_create refuses any other value, so a
@@ -64,7 +66,8 @@ typedef struct svc_clip_info {
 
 /* stage ids for svc_clip_stage_time */
 enum { SVC_STAGE_LUMA_PYRAMID = 0, SVC_STAGE_HALO, SVC_STAGE_HBMA, SVC_STAGE_RANSAC, SVC_STAGE_SEGMENT,
-       SVC_STAGE_TRANSFORM, SVC_STAGE_COUNT };
+       SVC_STAGE_TRANSFORM, SVC_STAGE_TYPE_PATCH /* wire, one BGR pass: region ids into the records emitted before they existed */,
+       SVC_STAGE_COUNT };
 /* buffer ids for svc_clip_output / svc_clip_read */
 enum { SVC_BUF_MV = 0, SVC_BUF_MIN_MAD, SVC_BUF_GLOBAL_MOTION, SVC_BUF_RMSE, SVC_BUF_INLIER_MASK,
        SVC_BUF_INLIER_COUNT, SVC_BUF_BLOCK_TYPES, SVC_BUF_COEFFS, SVC_BUF_RECORDS, SVC_BUF_PYRAMIDS,

@@ -320,6 +320,25 @@ int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes
                                uint32_t bg_step, uint32_t emit_frame_h, uint8_t* d_records,
                                uint64_t records_stride_bytes, void* stream);
 
+/* The record emitter with the luma plane as a by-product: ONE pass over the BGR bytes feeds both the transform (records of the RAW
+ * coefficients, what the reference's encoder emits: libs/encoder.cpp:638-650) and cv::cvtColor + extractChannel (:468-469) -- Y is
+ * pointwise, so the lane that holds 16 pixels of a row for the transform stores their 16 luma bytes into level 0 of the frame's packed
+ * pyramid (frame f at d_pyr + f * pyr_stride_bytes; levels 1.. are then svc_hip_pyramid_levels_frames).  The clip is read once per
+ * step instead of twice.  Region ids do not exist yet when this runs (they need the pyramid it produces): every record's type word
+ * is written as 0 (background, libs/codec.hpp:6) and svc_hip_wire_patch_types_frames stores the foreground ids afterwards -- the two
+ * calls together leave exactly the bytes of svc_hip_dct_records_frames(fg_step = bg_step = 0).  block: 8 or 16; frame_w a multiple of
+ * 16; UNSUPPORTED otherwise (call svc_hip_luma_pyramid_frames + svc_hip_dct_records_frames). */
+int svc_hip_dct_records_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames,
+                                    uint32_t frame_w, uint32_t frame_h, uint32_t block, uint32_t emit_frame_h,
+                                    uint8_t* d_records, uint64_t records_stride_bytes, uint8_t* d_pyr,
+                                    uint64_t pyr_stride_bytes, void* stream);
+/* Type words of records that were emitted before the region ids were known (libs/encoder.cpp:243-249: the id of the MV block that
+ * holds the tile).  Stores the word of every tile of a FOREGROUND block (id != 0); all_tiles != 0 stores the zeros too (records whose
+ * type words hold anything else than 0). */
+int svc_hip_wire_patch_types_frames(const uint32_t* d_block_types, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                                    uint32_t emit_frame_h, uint32_t block, uint32_t mv_block_w, uint32_t mv_block_h,
+                                    uint8_t* d_records, uint64_t records_stride_bytes, int all_tiles, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Decoder-side inverse path, headless: DecodeBlock over every tile
  * (libs/decoder.cpp:128-149, :183-207) without the GUI.  d_planes: coefficient planes as the
@@ -355,6 +374,10 @@ int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_byte
                                 uint32_t frame_h, uint32_t level_count,
                                 uint8_t* d_pyr, uint64_t pyr_stride_bytes,
                                 void* stream);
+/* cv::buildPyramid (libs/encoder.cpp:470) from level-0 planes that already exist: levels 1 .. level_count - 1 of n_frames packed
+ * pyramids (same layout, same kernels as the levels svc_hip_luma_pyramid_frames produces past its first). */
+int svc_hip_pyramid_levels_frames(uint8_t* d_pyr, uint64_t pyr_stride_bytes, uint32_t n_frames, uint32_t frame_w,
+                                  uint32_t frame_h, uint32_t level_count, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-frame global motion: the three estimators of libs/motion.hpp:38-59.  No caller in the

@@ -63,7 +63,7 @@ def _run(cmd: List[str]) -> None:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "union_find.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "hbma_fused_kernel.hpp"), os.path.join(CSRC, "dct_tables.inc"),
+    headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "union_find.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "hbma_fused_kernel.hpp"), os.path.join(CSRC, "dct_tables.inc"), os.path.join(CSRC, "luma16.hpp"),
                os.path.join(INCLUDE, "svc_hip.h")]
     jobs, objs = [], []
     for s in HIP_SOURCES:

@@ -501,6 +501,53 @@ int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_byte
                              pyr_stride_bytes, static_cast<hipStream_t>(stream));
 }
 
+int svc_hip_pyramid_levels_frames(uint8_t* d_pyr, uint64_t pyr_stride_bytes, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                                  uint32_t level_count, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  SVC_REQUIRE(d_pyr, "pyramid_levels: null pointer");
+  SVC_REQUIRE(level_count > 0 && level_count <= 16, "pyramid_levels: level_count %u out of range", level_count);
+  const uint32_t f = 1u << (level_count - 1);
+  SVC_REQUIRE(frame_w > 0 && frame_h > 0 && frame_w % f == 0 && frame_h % f == 0,
+              "pyramid_levels: frame %ux%u must be divisible by 2^(levels-1) = %u", frame_w, frame_h, f);
+  SVC_REQUIRE(n_frames <= 1 || pyr_stride_bytes >= pyramid_bytes(frame_w, frame_h, level_count), "pyramid_levels: pyramid stride too small");
+  return launch_pyr_down_levels(d_pyr, pyr_stride_bytes, n_frames, frame_w, frame_h, level_count, 0, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_dct_records_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
+                                    uint32_t frame_h, uint32_t block, uint32_t emit_frame_h, uint8_t* d_records,
+                                    uint64_t records_stride_bytes, uint8_t* d_pyr, uint64_t pyr_stride_bytes, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  int rc = validate_dct(d_bgr, d_records, frame_w, frame_h, block, block);
+  if (rc) return rc;
+  SVC_REQUIRE(d_pyr, "dct_records_luma: null pyramid");
+  SVC_REQUIRE(emit_frame_h > 0 && emit_frame_h <= frame_h, "dct_records_luma: emit_frame_h %u outside (0, %u]", emit_frame_h, frame_h);
+  SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_records, 4) && records_stride_bytes % 4 == 0 &&
+                  records_stride_bytes >= svc_hip_serialized_frame_bytes(frame_w, emit_frame_h, block, block),
+              "dct_records_luma: frames must be 16-byte aligned; records 4-byte aligned with a stride of at least one frame");
+  SVC_REQUIRE(aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0 && (n_frames <= 1 || pyr_stride_bytes >= (uint64_t)frame_w * frame_h),
+              "dct_records_luma: pyramids must be 16-byte aligned (stride too), a stride of at least one luma plane");
+  return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block, block, nullptr, block, block, 1, 1, false, nullptr,
+                    static_cast<hipStream_t>(stream), d_records, records_stride_bytes, emit_frame_h, d_pyr, pyr_stride_bytes);
+}
+
+int svc_hip_wire_patch_types_frames(const uint32_t* d_block_types, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                                    uint32_t emit_frame_h, uint32_t block, uint32_t mv_block_w, uint32_t mv_block_h, uint8_t* d_records,
+                                    uint64_t records_stride_bytes, int all_tiles, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  SVC_REQUIRE(d_block_types && d_records, "wire_patch_types: null pointer");
+  SVC_REQUIRE(block > 0 && frame_w > 0 && frame_h > 0 && frame_w % block == 0 && frame_h % block == 0 && block <= 64,
+              "wire_patch_types: frame %ux%u not divisible by block %u", frame_w, frame_h, block);
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && mv_block_w % block == 0 && mv_block_h % block == 0 &&
+                  frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "wire_patch_types: MV block %ux%u must be a multiple of the transform block %u and divide the frame", mv_block_w, mv_block_h, block);
+  SVC_REQUIRE(emit_frame_h > 0 && emit_frame_h <= frame_h, "wire_patch_types: emit_frame_h %u outside (0, %u]", emit_frame_h, frame_h);
+  SVC_REQUIRE(aligned(d_records, 4) && records_stride_bytes % 4 == 0 &&
+                  records_stride_bytes >= svc_hip_serialized_frame_bytes(frame_w, emit_frame_h, block, block),
+              "wire_patch_types: records 4-byte aligned with a stride of at least one frame");
+  return launch_wire_patch_types(d_block_types, n_frames, frame_w, frame_h, emit_frame_h, block, mv_block_w, mv_block_h, d_records,
+                                 records_stride_bytes, all_tiles != 0, static_cast<hipStream_t>(stream));
+}
+
 // ---- host-pointer forms -----------------------------------------------------------
 
 // ---- whole-frame global motion (libs/motion.hpp:38-59), see global_motion.hip ---------------------

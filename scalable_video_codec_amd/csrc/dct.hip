@@ -26,6 +26,7 @@
 // (ds_write_b128) and the column reads (ds_read_b128 / ds_read_b64) conflict-free.
 // Stores: N = 8, float2 per lane = 512 contiguous bytes per wave instruction;
 // N = 16, one float per lane = 256 contiguous bytes.
+#include "luma16.hpp"
 #include "svc_common.hpp"
 
 namespace svc {
@@ -49,6 +50,9 @@ struct DctArgs {
   uint8_t* records;
   uint64_t records_stride;  // bytes per frame
   uint32_t emit_bands;      // tile rows emitted per frame (frame_h as passed / N)
+  // LUMA: the frame's Y plane (level 0 of its packed pyramid) as a by-product of the pass over the BGR bytes
+  uint8_t* luma;
+  uint64_t luma_stride;     // bytes from one frame's level 0 to the next (the pyramid stride)
 };
 
 template <int N> struct Basis;
@@ -169,8 +173,16 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // consecutive aligned addresses, 1 KiB per instruction: whole lines except at the stretch's two ends.  A wave whose segment
 // columns do not form such a stretch (the clip's last wave, a frame boundary inside it, rows SerializeEncodedFrame does not
 // visit) stores from the registers directly.  No extra HBM traffic versus planar output.
-template <int N, bool QUANT, bool WIRE>
+//
+// LUMA (with WIRE, no QUANT: the reference encoder's real output is raw coefficients, libs/encoder.cpp:638-650): the lane that holds 16
+// B,G,R pixels of a row for the transform also has everything cv::cvtColor needs for them (libs/encoder.cpp:468-469) -- Y is pointwise --
+// so it stores the 16 luma bytes into level 0 of the frame's pyramid and the clip's BGR bytes are read ONCE per step instead of twice
+// (luma pass + transform: 1.88 of 13.75 GB per step at C3).  The region id of a tile is not known yet when this runs (it needs the
+// pyramid this kernel is producing): every record's type word is written as 0 = background (libs/codec.hpp:6) and
+// wire_patch_types_kernel (wire.hip) stores the foreground ids once the segmentation has them.
+template <int N, bool QUANT, bool WIRE, bool LUMA = false>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
+  static_assert(!LUMA || (WIRE && !QUANT), "the luma by-product rides on the raw-coefficient record emitter only");
   constexpr int kSegPerWg = 256 / N;  // 512- and 1024-lane workgroups (longer runs per row) measured level or worse: profiles/r03_ab_dct_lanes.txt
   constexpr int kSlab = WIRE ? (N == 8 ? kSlabWire8 : kSlabWire16) : (N == 8 ? kSlab8 : kSlab16);
   __shared__ __attribute__((aligned(16))) uint8_t lds[kSegPerWg * kSlab];
@@ -197,12 +209,18 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
     wds[8] = v2.x; wds[9] = v2.y; wds[10] = v2.z; wds[11] = v2.w;
   }
 
+  if (LUMA) {
+    uint32_t y16[4];
+    luma16(wds, y16);
+    *reinterpret_cast<uint4*>(a.luma + (size_t)frame * a.luma_stride + (size_t)(y_pix + j) * a.w + x_pix) = make_uint4(y16[0], y16[1], y16[2], y16[3]);
+  }
+
   uint8_t* slab = lds + sc_local * kSlab;
   float* out_frame = a.planes + (size_t)frame * 3 * a.w * a.h;
 
   float step = 1.f, inv_step = 1.f;
   uint32_t t = 0;
-  if (QUANT || WIRE) {
+  if ((QUANT || WIRE) && !LUMA) {
     // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249);
     // background (0, libs/codec.hpp:6) takes bg_step (libs/decoder.cpp:130-135)
     const uint32_t col = N == 8 ? x_pix + 2 * j : x_pix + j;
@@ -503,9 +521,12 @@ static int launch_dct_general(const uint8_t* d_bgr, uint64_t frame_stride, uint3
 int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w,
                uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
-               hipStream_t stream, uint8_t* d_records, uint64_t records_stride, uint32_t emit_h) {
+               hipStream_t stream, uint8_t* d_records, uint64_t records_stride, uint32_t emit_h, uint8_t* d_luma,
+               uint64_t luma_stride) {
   const bool wire = d_records != nullptr;
   const bool fast = bw == bh && (bw == 8 || bw == 16) && w % 16 == 0;
+  if (d_luma && !(fast && wire && !quant))
+    return fail(SVC_ERR_UNSUPPORTED, "dct: the luma by-product needs the tuned record emitter (8x8 / 16x16 blocks, width a multiple of 16, no quant)");
   if (!fast)
     return launch_dct_general(d_bgr, frame_stride, n_frames, w, h, bw, bh, d_types, mv_bw, mv_bh, fg_step, bg_step, quant,
                               d_planes, stream, d_records, records_stride, emit_h);
@@ -523,6 +544,8 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   a.records = d_records;
   a.records_stride = records_stride;
   a.emit_bands = wire ? div_up(emit_h, bh) : 0;
+  a.luma = d_luma;
+  a.luma_stride = luma_stride;
   if (quant || wire) {
     a.types = d_types;
     a.mv_bw = mv_bw; a.mv_bh = mv_bh;
@@ -538,7 +561,10 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   const uint32_t seg_per_wg = 256 / bw;
   const dim3 grid(div_up(a.total_segcols, seg_per_wg)), block(256);
 #define SVC_DCT_LAUNCH(N_, Q_, W_) hipLaunchKernelGGL((dct_kernel<N_, Q_, W_>), grid, block, 0, stream, a)
-  if (bw == 8) {
+  if (d_luma) {
+    if (bw == 8) hipLaunchKernelGGL((dct_kernel<8, false, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((dct_kernel<16, false, true, true>), grid, block, 0, stream, a);
+  } else if (bw == 8) {
     if (wire) { if (quant) SVC_DCT_LAUNCH(8, true, true); else SVC_DCT_LAUNCH(8, false, true); }
     else { if (quant) SVC_DCT_LAUNCH(8, true, false); else SVC_DCT_LAUNCH(8, false, false); }
   } else {

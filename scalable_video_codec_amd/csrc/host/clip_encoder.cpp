@@ -75,7 +75,7 @@ struct ClipEncoder::Impl {
   static constexpr int kMaxDepth = 3, kSets = kMaxDepth + 2;
   int depth = 1, nsets = 1;
   hipStream_t sM = nullptr, sL[kMaxDepth] = {nullptr, nullptr, nullptr}, sC = nullptr;
-  DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records;
+  DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records[kSets + 1];
   DevBuf<float> mv[kSets], mad[kSets], gm[kSets], rmse[kSets], coeffs;
   DevBuf<uint32_t> count[kSets], types[kSets], samples;
   hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {}, e_rfork = nullptr, e_rmse[kSets] = {};
@@ -94,6 +94,12 @@ struct ClipEncoder::Impl {
   // pipelined schedule: RANSAC + segmentation run beside the main stream's kernels and ask for shapes that fit there
   uint32_t lat_flags = 0;
   bool fused_records = false;  // wire output straight from the transform kernel (square transform blocks)
+  bool one_bgr_pass = false;   // wire, tuned transform blocks: records + luma plane from ONE kernel at the front of the step, type words
+                               // stored once the step's region ids exist (clip_encoder.hpp); records then exist in `nsets` sets
+  // nsets + 1 of them: the front of step s + nsets + 1 rewrites the set in the iteration AFTER the one whose last launch completed step s's
+  // records (with nsets it would be the same iteration, and the front runs first)
+  int rec_sets = 1;
+  DevBuf<uint8_t>& Records(uint64_t s) { return records[(int)(s % (uint64_t)rec_sets)]; }
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
@@ -137,6 +143,22 @@ struct ClipEncoder::Impl {
   // ---- the stages; `s` is the step index, its buffers are those of set Par(s) ---------------
   void Luma(uint64_t s, hipStream_t st, bool timing) {
     const int b = Par(s);
+    if (one_bgr_pass) {
+      // own frame j lives in pyramid slot 1 + j; encoded frame p is own frame p (halo in slot 0) or p + 1 (frame 0 is tracked only)
+      const uint32_t skip = sh.needs_halo ? 0u : 1u;
+      uint8_t* slots = pyr[b].p + (uint64_t)(1 + skip) * pyr_stride;
+      Run(Stage::kTransform, st, timing, [&] {
+        Abi(svc_hip_dct_records_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, ph,
+                                            Records(s).p, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
+      });
+      Run(Stage::kLumaPyramid, st, timing, [&] {
+        if (skip)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
+          Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, 1, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
+              "svc_hip_luma_pyramid_frames");
+        Abi(svc_hip_pyramid_levels_frames(slots, pyr_stride, sh.pairs, pw, ph, c.levels, st), "svc_hip_pyramid_levels_frames");
+      });
+      return;
+    }
     Run(Stage::kLumaPyramid, st, timing, [&] {
       Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, sh.frames, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
           "svc_hip_luma_pyramid_frames");
@@ -212,16 +234,23 @@ struct ClipEncoder::Impl {
     if (!sh.pairs || !c.dct_block_w) return;
     const int b = Set(s);
     const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
+    if (one_bgr_pass) {  // the records left at the front of step s; what is still missing are the region ids of its foreground tiles
+      Run(Stage::kTypePatch, st, timing, [&] {
+        Abi(svc_hip_wire_patch_types_frames(types[b].p, sh.pairs, pw, ph, ph, c.dct_block_w, c.mv_block, c.mv_block, Records(s).p,
+                                            record_bytes, 0, st), "svc_hip_wire_patch_types_frames");
+      });
+      return;
+    }
     Run(Stage::kTransform, st, timing, [&] {
       // records carry RAW coefficients, as the reference's encoder serialises them (libs/encoder.cpp:638-650:
       // the decoder picks the step per tile, libs/decoder.cpp:130-135); planes carry the quantised ones
       if (c.wire && fused_records)
         Abi(svc_hip_dct_records_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block,
-                                       0, 0, ph, records.p, record_bytes, st), "svc_hip_dct_records_frames");
+                                       0, 0, ph, records[0].p, record_bytes, st), "svc_hip_dct_records_frames");
       else if (c.wire) {  // any other transform block: Dct, then SerializeEncodedFrame
         Abi(svc_hip_dct_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, coeffs.p, st), "svc_hip_dct_frames");
         Abi(svc_hip_serialize_frames(coeffs.p, plane_elems, sh.pairs, types[b].p, pw, ph, c.dct_block_w, c.dct_block_h, mfw, mfh,
-                                     c.mv_block, c.mv_block, records.p, record_bytes, st), "svc_hip_serialize_frames");
+                                     c.mv_block, c.mv_block, records[0].p, record_bytes, st), "svc_hip_serialize_frames");
       } else
         Abi(svc_hip_dct_quant_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, types[b].p, c.mv_block,
                                      c.mv_block, c.fg_step, c.bg_step, coeffs.p, st), "svc_hip_dct_quant_frames");
@@ -374,8 +403,12 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   }
   for (int k = 0; k < m.depth; ++k) m.seg_ws[k].Alloc(m.seg_ws_bytes);
   m.fused_records = c.wire && c.dct_block_w == c.dct_block_h && c.dct_block_w <= 64 && c.dct_block_w % 2 == 0;
+  // one pass over the BGR clip: the tuned record emitter (8x8 / 16x16 on widths that are whole 16-pixel segments) also leaves the luma plane
+  m.one_bgr_pass = m.fused_records && !c.two_bgr_passes && transform && (c.dct_block_w == 8 || c.dct_block_w == 16) && m.pw % 16 == 0 &&
+                   c.mv_block % c.dct_block_w == 0 && P > 0;
   if (transform) {
-    if (c.wire) m.records.Alloc((size_t)P * m.record_bytes);
+    if (c.wire)
+      for (int b = 0; b < (m.rec_sets = m.one_bgr_pass && pipelined ? m.nsets + 1 : 1); ++b) m.records[b].Alloc((size_t)P * m.record_bytes);
     if (!c.wire || !m.fused_records) m.coeffs.Alloc((size_t)P * 3 * m.plane_elems);
   }
   // RANSAC draws: distinct within an iteration, a function of (seed, clip frame, iteration) only --
@@ -472,7 +505,7 @@ void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
     case Buffer::kInlierCount: ptr = m.count[par].p; n = m.count[par].bytes(); break;
     case Buffer::kBlockTypes: ptr = m.types[par].p; n = m.types[par].bytes(); break;
     case Buffer::kCoeffs: ptr = m.coeffs.p; n = m.coeffs.bytes(); break;
-    case Buffer::kRecords: ptr = m.records.p; n = m.records.bytes(); break;
+    case Buffer::kRecords: { auto& r = m.n_dct ? m.Records(m.n_dct - 1) : m.records[0]; ptr = r.p; n = r.bytes(); break; }
     case Buffer::kPyramids: ptr = m.pyr[ppar].p; n = m.pyr[ppar].bytes(); break;
     case Buffer::kBgr: ptr = m.bgr.p; n = m.bgr.bytes(); break;
     default: throw std::runtime_error("svc::ClipEncoder: unknown buffer");
@@ -530,7 +563,8 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
       throw std::runtime_error("svc_clip_create: config->struct_size is " + std::to_string(k->struct_size) + ", this build's svc_clip_config has " +
                                std::to_string(sizeof(svc_clip_config)) + " bytes (set struct_size = sizeof(svc_clip_config))");
     constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
-    constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE;
+    constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
+                                   SVC_CLIP_TUNE_TWO_BGR_PASSES;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -547,6 +581,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.segment_fork = (k->tuning & SVC_CLIP_TUNE_SEGMENT_FORK) != 0;
     c.narrow_attempts = (k->tuning & SVC_CLIP_TUNE_NARROW_ATTEMPTS) != 0;
     c.inline_rmse = (k->tuning & SVC_CLIP_TUNE_INLINE_RMSE) != 0;
+    c.two_bgr_passes = (k->tuning & SVC_CLIP_TUNE_TWO_BGR_PASSES) != 0;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
     h->enc.reset(new svc::ClipEncoder(c));

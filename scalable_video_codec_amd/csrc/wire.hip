@@ -66,4 +66,51 @@ int launch_serialize(const float* d_planes, uint64_t plane_elems, uint32_t n_fra
   return check_launch("serialize_kernel");
 }
 
+// ---- region ids into records that were emitted before they were known ------------------------------------------------------
+// dct_kernel<N, false, true, LUMA = true> writes every record's type word as 0 (background): it runs BEFORE the frame's pyramid -- and so
+// its motion field, global motion and region ids -- exists.  Once the segmentation has the ids, this kernel stores the type word of every
+// tile whose MV block is foreground (libs/encoder.cpp:243-249); background tiles already hold their 0.  One lane per MV block: it reads
+// the block's id (coalesced) and, if non-zero, writes the (mv_bw / tb) x (mv_bh / tb) type words of its tiles (4 at 16 / 8, 1 at 16 / 16).
+struct PatchArgs {
+  const uint32_t* types;  // [frames][mv_blocks]
+  uint32_t* out;          // frame f at out + f * out_stride_dw
+  uint64_t out_stride_dw;
+  uint32_t mfw, mv_blocks, total_blocks, tiles_per_side_x, tiles_per_side_y, tiles_x, emit_tile_rows, rec_dw;
+  uint32_t force_all;     // also store the zeros (records that were not emitted by the LUMA kernel)
+};
+
+__global__ __launch_bounds__(256) void wire_patch_types_kernel(PatchArgs a) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= a.total_blocks) return;
+  const uint32_t t = a.types[g];
+  if (t == 0 && !a.force_all) return;
+  const uint32_t frame = g / a.mv_blocks, b = g - frame * a.mv_blocks;
+  const uint32_t by = b / a.mfw, bx = b - by * a.mfw;
+  uint32_t* out = a.out + (size_t)frame * a.out_stride_dw;
+  for (uint32_t ty = by * a.tiles_per_side_y; ty < (by + 1) * a.tiles_per_side_y && ty < a.emit_tile_rows; ++ty)
+    for (uint32_t tx = bx * a.tiles_per_side_x; tx < (bx + 1) * a.tiles_per_side_x; ++tx)
+      out[(size_t)(ty * a.tiles_x + tx) * a.rec_dw] = t;
+}
+
+int launch_wire_patch_types(const uint32_t* d_types, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h, uint32_t emit_h, uint32_t tb,
+                            uint32_t mv_bw, uint32_t mv_bh, uint8_t* d_out, uint64_t out_stride, bool force_all, hipStream_t stream) {
+  PatchArgs a;
+  a.types = d_types;
+  a.out = reinterpret_cast<uint32_t*>(d_out);
+  a.out_stride_dw = out_stride / 4;
+  a.mfw = frame_w / mv_bw;
+  a.mv_blocks = a.mfw * (frame_h / mv_bh);
+  const uint64_t total = (uint64_t)a.mv_blocks * n_frames;
+  if (total == 0) return SVC_OK;
+  if (total > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "wire_patch_types: %llu MV blocks exceed one launch", (unsigned long long)total);
+  a.total_blocks = (uint32_t)total;
+  a.tiles_per_side_x = mv_bw / tb; a.tiles_per_side_y = mv_bh / tb;
+  a.tiles_x = frame_w / tb;
+  a.emit_tile_rows = div_up(emit_h, tb);
+  a.rec_dw = 1 + 3 * tb * tb;
+  a.force_all = force_all ? 1u : 0u;
+  hipLaunchKernelGGL(wire_patch_types_kernel, dim3(div_up(a.total_blocks, 256)), dim3(256), 0, stream, a);
+  return check_launch("wire_patch_types_kernel");
+}
+
 }  // namespace svc

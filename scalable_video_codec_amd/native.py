@@ -80,6 +80,9 @@ SIGNATURES = {
     "svc_hip_quant": (C.c_int, [_vp, _u64, _u32, _vp]),
     "svc_hip_quant_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _vp]),
     "svc_hip_luma_pyramid_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
+    "svc_hip_pyramid_levels_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp]),
+    "svc_hip_dct_records_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _vp]),
+    "svc_hip_wire_patch_types_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u64, C.c_int, _vp]),
     "svc_hip_hbma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32]),
     "svc_hip_ebma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_ransac_host": (C.c_int, [_vp, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp]),
@@ -377,6 +380,35 @@ def luma_pyramid_frames(bgr: torch.Tensor, levels: int, out: Optional[torch.Tens
     _check(load().svc_hip_luma_pyramid_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, levels,
                                               _dev(out, torch.uint8), stride, _stream()))
     return out, stride
+
+
+def dct_records_luma_frames(bgr: torch.Tensor, block: int, levels: int, emit_h: Optional[int] = None,
+                            records: Optional[torch.Tensor] = None, pyr: Optional[torch.Tensor] = None,
+                            stride: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """ONE pass over bgr (frames, H, W, 3) u8: the raw-coefficient records (type words 0) AND level 0 of each frame's packed pyramid,
+    then the pyramid's other levels from it.  -> (records (frames, bytes) u8, flat pyramid buffer, pyramid stride)."""
+    n, h, w, _ = bgr.shape
+    emit_h = h if emit_h is None else emit_h
+    per = serialized_frame_bytes(w, emit_h, block, block)
+    if records is None:
+        records = torch.empty((n, per), dtype=torch.uint8, device=bgr.device)
+    stride = pyramid_stride(w, h, levels) if stride is None else stride
+    if pyr is None:
+        pyr = torch.empty(n * stride, dtype=torch.uint8, device=bgr.device)
+    _check(load().svc_hip_dct_records_luma_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, emit_h, _dev(records, torch.uint8),
+                                                  records.stride(0), _dev(pyr, torch.uint8), stride, _stream()))
+    _check(load().svc_hip_pyramid_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels, _stream()))
+    return records, pyr, stride
+
+
+def wire_patch_types_frames(records: torch.Tensor, block_types: torch.Tensor, w: int, h: int, block: int, mv_block: int = 16,
+                            emit_h: Optional[int] = None, all_tiles: bool = False) -> torch.Tensor:
+    """Stores the region id of every foreground MV block into the type words of its tiles' records (in place)."""
+    n = records.shape[0]
+    emit_h = h if emit_h is None else emit_h
+    _check(load().svc_hip_wire_patch_types_frames(_dev(block_types, torch.int32), n, w, h, emit_h, block, mv_block, mv_block,
+                                                  _dev(records, torch.uint8), records.stride(0), 1 if all_tiles else 0, _stream()))
+    return records
 
 
 # ---- host-pointer forms (numpy in, numpy out): what include/svc/motion.hpp calls ----

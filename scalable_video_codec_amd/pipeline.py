@@ -47,8 +47,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 KERNEL_SOURCE_GROUPS = {
     "hbma": ("hbma_fused.hip", "hbma_fused8.hip", "hbma_fused32.hip", "hbma_fused_kernel.hpp", "hbma_search.hpp", "hbma_tiled.hip",
              "hbma_wave.hip"),
-    "dct": ("dct.hip", "dct_tables.inc"),
-    "luma_pyr1": ("luma_pyramid.hip",),
+    "dct": ("dct.hip", "dct_tables.inc", "luma16.hpp"),
+    "luma_pyr1": ("luma_pyramid.hip", "luma16.hpp"),
 }
 
 

@@ -365,3 +365,69 @@ def test_eight_pixel_mv_blocks_on_a_frame_not_16_wide(native, oracle):
     c = enc.read("coeffs").view(cfg.frames - 1, 3, 200, 360)[1].numpy()
     assert np.mean(c == got) > 0.999  # away from rounding boundaries the quantised values agree exactly
     enc.close()
+
+
+@pytest.mark.parametrize("dct", [8, 16])
+@pytest.mark.parametrize("schedule,steps,rank", [(clipmod.SERIAL, 2, 0), (clipmod.PIPELINED, 1, 0), (clipmod.PIPELINED, 6, 0), (clipmod.PIPELINED, 7, 1)])
+def test_wire_one_bgr_pass_equals_two_passes(native, dct, schedule, steps, rank):
+    """Wire output reads the BGR clip once per step by default (records + luma plane from one kernel at the front of the step, type
+    words stored once the segmentation has the region ids); SVC_CLIP_TUNE_TWO_BGR_PASSES keeps the two-pass order.  Same bytes in every
+    buffer, on an unsharded clip (frame 0 tracked only: its pyramid comes from the plain luma kernel) and on a shard behind a halo."""
+    dev = torch.device("cuda")
+    n = 9
+    cfg = configs.CodecConfig("t-360p-3L", 41, 640, 360, n, levels=3, dct_block=dct)
+    frames = _frames(cfg, n, dev)
+    world = 2 if rank else 1
+    first, cnt, pairs, _ = clipmod.plan_shard(n, world, rank)
+    halo_src = None
+    if rank:
+        whole = clipmod.Clip(cfg, n, schedule=clipmod.SERIAL)
+        whole.load_frames(frames)
+        whole.step()
+        whole.sync()
+        halo_src = whole.read("pyramids", device=dev)
+    got = {}
+    for name, tuning in (("two", clipmod.TUNE_TWO_BGR_PASSES), ("one", 0)):
+        enc = clipmod.Clip(cfg, n, rank=rank, world=world, schedule=schedule, wire=True, tuning=tuning)
+        enc.load_frames(frames[first:first + cnt].contiguous())
+        if rank:
+            stride = enc.info.pyramid_stride
+            enc.set_halo_transport(lambda send, recv, nbytes, stream: _hip_memcpy_async(recv, halo_src.data_ptr() + first * stride, nbytes, stream))
+        for _ in range(steps):
+            enc.step(timed=True)
+        enc.sync()
+        got[name] = (enc.outputs(), enc.read("records"), enc.read("pyramids"), enc.stage_times_ms())
+        enc.close()
+    for k in got["two"][0]:
+        assert torch.equal(got["one"][0][k], got["two"][0][k]), k
+    assert got["two"][0]["block_types"].count_nonzero() > 0  # there are foreground ids to store
+    assert torch.equal(got["one"][1], got["two"][1])
+    assert torch.equal(got["one"][2], got["two"][2])
+    assert "type_patch" in got["one"][3] and "type_patch" not in got["two"][3]
+    assert all(launches == steps for _, launches in got["one"][3].values())
+
+
+def test_wire_one_bgr_pass_record_sets_never_serve_stale_steps(native):
+    """A step's records are emitted at its front and completed (type words) 2 + depth iterations later, in a set of their own; the clip
+    changes between bursts, so records of a stale set -- or region ids patched into another step's records -- would show."""
+    dev = torch.device("cuda")
+    n = 7
+    cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
+    fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    want = {}
+    for name, f in (("a", fa), ("b", fb)):
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, wire=True, tuning=clipmod.TUNE_TWO_BGR_PASSES)
+        s.load_frames(f)
+        s.step()
+        s.sync()
+        want[name] = s.read("records")
+        s.close()
+    assert not torch.equal(want["a"], want["b"])
+    for lat_depth in (0, 1, 3):
+        enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, wire=True, lat_depth=lat_depth)
+        for burst, (name, f, k) in enumerate((("a", fa, 8), ("b", fb, 1), ("a", fa, 2), ("b", fb, 3), ("a", fa, 5), ("b", fb, 6))):
+            enc.load_frames(f)
+            for _ in range(k):
+                enc.step()
+            assert torch.equal(enc.read("records"), want[name]), (lat_depth, burst)
+        enc.close()

@@ -131,3 +131,49 @@ def test_frame_not_divisible_by_the_transform_block(native, oracle):
     tile column reads through the unpadded-stride quirk.  Bug-compatible bytes against the literal restatement."""
     _case(native, oracle, 352, 288, 344, 280, 16, 16, frames=2, seed=8)
     _case(native, oracle, 352, 288, 346, 282, 8, 8, frames=1, seed=9)
+
+
+@pytest.mark.parametrize("block,w,h,levels,mvb", [(8, 160, 96, 3, 16), (16, 160, 96, 3, 16), (8, 1920, 64, 1, 16), (16, 352, 288, 4, 16), (8, 208, 80, 2, 8),
+                                                   (16, 256, 128, 4, 32)])
+def test_records_and_luma_plane_from_one_pass(native, block, w, h, levels, mvb):
+    """dct_kernel<N, false, true, LUMA>: ONE pass over the BGR bytes leaves (i) the raw-coefficient records with every type word 0 and
+    (ii) level 0 of each frame's pyramid; svc_hip_pyramid_levels_frames adds the other levels, svc_hip_wire_patch_types_frames the
+    region ids.  Together: exactly the bytes of svc_hip_luma_pyramid_frames and of svc_hip_dct_records_frames with the ids given up
+    front (libs/encoder.cpp:468-470, :638-650, :243-249)."""
+    rng = np.random.default_rng(block + w + levels)
+    n = 3
+    bgr = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+    mfw, mfh = w // mvb, h // mvb
+    types = torch.from_numpy((rng.integers(0, 5, (n, mfw * mfh)) * rng.integers(0, 2, (n, mfw * mfh))).astype(np.int32)).cuda()
+    want_pyr, stride = native.luma_pyramid_frames(bgr, levels)
+    for emit_h in (h, h - 16):
+        want = native.dct_records_frames(bgr, block, types, mvb, 0, 0, emit_h=emit_h)
+        rec, pyr, stride2 = native.dct_records_luma_frames(bgr, block, levels, emit_h=emit_h)
+        torch.cuda.synchronize()
+        assert stride2 == stride
+        used = sum((w >> l) * (h >> l) for l in range(levels))
+        for f in range(n):
+            assert torch.equal(pyr[f * stride:f * stride + used], want_pyr[f * stride:f * stride + used]), (f, emit_h)
+        zero_types = native.dct_records_frames(bgr, block, torch.zeros_like(types), mvb, 0, 0, emit_h=emit_h)
+        assert torch.equal(rec, zero_types)  # type words are 0 = background until patched
+        native.wire_patch_types_frames(rec, types, w, h, block, mvb, emit_h=emit_h)
+        torch.cuda.synchronize()
+        assert torch.equal(rec, want), emit_h
+        # all_tiles: records whose type words hold anything (here: another frame set's ids) get every word, zeros included
+        other = native.dct_records_frames(bgr, block, torch.full_like(types, 7), mvb, 0, 0, emit_h=emit_h)
+        native.wire_patch_types_frames(other, types, w, h, block, mvb, emit_h=emit_h, all_tiles=True)
+        torch.cuda.synchronize()
+        assert torch.equal(other, want)
+
+
+def test_one_pass_entry_points_refuse_what_they_do_not_cover(native):
+    bgr = torch.zeros((1, 64, 168, 3), dtype=torch.uint8, device="cuda")  # 168: not whole 16-pixel segments
+    with pytest.raises(RuntimeError, match="luma by-product"):
+        native.dct_records_luma_frames(bgr, 8, 1)
+    bgr = torch.zeros((1, 64, 160, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="luma by-product"):
+        native.dct_records_luma_frames(bgr, 4, 1)
+    rec = torch.zeros((1, native.serialized_frame_bytes(160, 64, 8, 8)), dtype=torch.uint8, device="cuda")
+    types = torch.zeros((1, 40), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of the transform block"):
+        native.wire_patch_types_frames(rec, types, 160, 64, 8, mv_block=12)
