@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t b, uint32_t g, uint32_t r) 
 // plane-to-plane pass has a third of the bytes per pixel and takes 512 x 32, so that a lane has four or five loads in flight
 // (per launch at C3, 1080p level 1 -> 2: 128x64 75.6 us, 256x64 66.4, 256x32 67.0, 128x128 71.6, 512x32 64.2, 256x128 76.0;
 // profiles/r02_ab_pyr_tile.txt).
-template <bool FROM_BGR, int TW, int TH>
+template <bool FROM_BGR, int TW, int TH, int RPT = 1>
 __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t, uint8_t* tile) {
   constexpr int kTW = TW, kTH = TH, kPitch = TW + 2 * kOff;
   static_assert(kPitch % 16 == 0 && kOff % 16 == 0, "LDS rows keep 16-byte alignment for the ds_write_b128");
@@ -191,6 +191,28 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
   // row h) and must not be touched: reflect101 folds once, so a row further out would index
   // outside the frame (short frames: found by tests/test_gpu_misc_property.py).
   const int rows = min(kTH + 4, h - y0 + 3);  // LDS rows 0 .. rows-1 <-> y = y0 - 2 .. min(y0 + 33, h)
+  if constexpr (!FROM_BGR) {
+    // plane to plane: a lane's four or five segment loads AND its halo bytes are all issued before the first is waited for -- no branch
+    // (clamped addresses; idle tasks store into 16 spare bytes behind the tile): as a loop of load -> LDS store rounds this pass paid the
+    // memory latency once per round, 4.5 round trips per tile (profiles/r05_ab_pyr2.txt)
+    constexpr int kSegsMax = kTW / 16, kRounds = ((kTH + 4) * kSegsMax + 255) / 256, kSpare = (kTH + 4) * kPitch;
+    uint4 v[kRounds];
+    int at[kRounds];
+#pragma unroll
+    for (int it = 0; it < kRounds; ++it) {
+      const int task = (int)tid + 256 * it, r = task / kSegsMax, sgm = task - r * kSegsMax;
+      const bool ok = r < rows && sgm < segs;
+      at[it] = ok ? r * kPitch + kOff + sgm * 16 : kSpare;
+      v[it] = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(min(y0 - 2 + r, h), h) * w + min(x0 + sgm * 16, w - 16));
+    }
+    static_assert((kTH + 4) * 4 <= 256, "one round of halo tasks");
+    const int hr = (int)tid >> 2, hk = (int)tid & 3, hx = hk < 2 ? x0 - 2 + hk : xe + (hk - 2);
+    const int hat = hr < rows ? hr * kPitch + kOff + (hx - x0) : kSpare;
+    const uint8_t hv = src[(size_t)reflect101(min(y0 - 2 + hr, h), h) * w + reflect101(hx, w)];
+#pragma unroll
+    for (int it = 0; it < kRounds; ++it) *reinterpret_cast<uint4*>(&tile[at[it]]) = v[it];
+    tile[hat] = hv;
+  } else {
   // (a) segment tasks: 16 pixels of one row -> 4 dwords of LDS (+ the level-0 store)
   for (int task = (int)tid; task < rows * segs; task += 256) {
     const int r = task / segs, sgm = task - r * segs;
@@ -222,48 +244,69 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
       tile[r * kPitch + kOff + (x - x0)] = src[(size_t)yr * w + reflect101(x, w)];
     }
   }
+  }  // FROM_BGR
   __syncthreads();
 
-  // (c) next level: lane = (output row, quad of 4 output columns)
+  // (c) next level: a task = a quad of 4 output columns x RPT consecutive output rows.  The output rows of a task share source rows (2 RPT + 3
+  // of them instead of 5 RPT) and the four horizontal 5-tap sums of a source row are formed once: per quad of outputs 100 vector
+  // instructions and 15 LDS reads at RPT = 1, 62 / 11 at 2, 53 / 8 at 4.  Measured on the plane-to-plane pass (profiles/r05_ab_plane_rpt.txt,
+  // C3 wire pyramid stage = Y -> level 1 -> level 2): RPT 1 0.273-0.282 ms, 2 0.266-0.275, 4 0.324-0.326 (one long task per lane hides its
+  // LDS latency worse than two short ones): the pass is not bound by its instruction count.  The BGR pass keeps 1, the plane pass takes 2.
   constexpr int kQuads = kTW / 8;  // quads of output columns per tile row
-  const int q = (int)tid % kQuads;
-  const int gx = (x0 >> 1) + 4 * q;  // output-level coordinates
-  const int taps[5] = {1, 4, 6, 4, 1};
-  for (int oy = (int)tid / kQuads; oy < kTH / 2 && gx < (w >> 1); oy += 256 / kQuads) {
-    const int gy = (y0 >> 1) + oy;
-    if (gy >= (h >> 1)) break;
-    uint32_t acc[4] = {0, 0, 0, 0};
+  constexpr int kGroups = kTH / 2 / RPT;
+  static_assert(kTH / 2 % RPT == 0, "row groups tile the output rows");
+  constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
+  constexpr int taps[5] = {1, 4, 6, 4, 1};
+  for (int task = (int)tid; task < kQuads * kGroups; task += 256) {
+    const int q = task % kQuads, oy0 = (task / kQuads) * RPT;
+    const int gx = (x0 >> 1) + 4 * q, gy0 = (y0 >> 1) + oy0;  // output-level coordinates
+    if (gx >= (w >> 1) || gy0 >= (h >> 1)) continue;
+    uint32_t acc[RPT][4];
 #pragma unroll
-    for (int r5 = 0; r5 < 5; ++r5) {
+    for (int o = 0; o < RPT; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0;
+#pragma unroll
+    for (int r = 0; r < 2 * RPT + 3; ++r) {
       // centre of output column 4q + o is LDS column kOff + 8q + 2o; taps span kOff + 8q - 2 .. + 8
-      const uint8_t* rowp = &tile[(2 * oy + r5) * kPitch + kOff + 8 * q];
+      const uint8_t* rowp = &tile[(2 * oy0 + r) * kPitch + kOff + 8 * q];
       const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
       const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
       const uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
       // taps 1 4 6 4 of an output are one 4 x u8 dot product over the dword that starts at its first tap;
       // the fifth tap (weight 1) enters as the accumulator
-      constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
       const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.x, w0, 2), kTaps, (mid.x >> 16) & 0xFFu, false);
       const uint32_t h1 = __builtin_amdgcn_udot4(mid.x, kTaps, mid.y & 0xFFu, false);
       const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), kTaps, (mid.y >> 16) & 0xFFu, false);
       const uint32_t h3 = __builtin_amdgcn_udot4(mid.y, kTaps, w3 & 0xFFu, false);
-      acc[0] += (uint32_t)taps[r5] * h0;
-      acc[1] += (uint32_t)taps[r5] * h1;
-      acc[2] += (uint32_t)taps[r5] * h2;
-      acc[3] += (uint32_t)taps[r5] * h3;
-    }
-    uint32_t out = 0;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) out |= ((acc[o] + 128u) >> 8) << (8 * o);
-    *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)gy * (w >> 1) + gx) = out;
+      for (int o = 0; o < RPT; ++o) {
+        const int t5 = r - 2 * o;  // which tap of output row o this source row is
+        if (t5 >= 0 && t5 < 5) {
+          acc[o][0] += (uint32_t)taps[t5] * h0;
+          acc[o][1] += (uint32_t)taps[t5] * h1;
+          acc[o][2] += (uint32_t)taps[t5] * h2;
+          acc[o][3] += (uint32_t)taps[t5] * h3;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) {
+      if (gy0 + o >= (h >> 1)) break;
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out |= ((acc[o][k] + 128u) >> 8) << (8 * k);
+      *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)(gy0 + o) * (w >> 1) + gx) = out;
+    }
   }
 }
 
+#ifndef SVC_PLANE_RPT
+#define SVC_PLANE_RPT 2
+#endif
 // One tile per workgroup (the BGR pass: 76 500 workgroups at C3), or -- PERSIST, the plane-to-plane pass, whose tiles take 1 - 2 us
 // each -- a fixed grid whose workgroups walk the tiles of their XCD's share: see launch_pyr_down_levels.
 template <bool FROM_BGR, int TW, int TH, bool PERSIST = false>
 __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[(TH + 4) * (TW + 2 * kOff)];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(TH + 4) * (TW + 2 * kOff) + 16];  // + 16 spare bytes (idle load tasks of the plane pass)
   if (!PERSIST) {
     const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
     if (t < a.total_tiles) luma_pyr1_tile<FROM_BGR, TW, TH>(a, t, tile);
@@ -272,7 +315,7 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3, per = gridDim.x >> 3;
     const uint32_t share = (a.total_tiles + 7u) / 8u, t0 = xcd * share, t1 = min(a.total_tiles, t0 + share);
     for (uint32_t t = t0 + k; t < t1; t += per) {
-      luma_pyr1_tile<FROM_BGR, TW, TH>(a, t, tile);
+      luma_pyr1_tile<FROM_BGR, TW, TH, SVC_PLANE_RPT>(a, t, tile);
       __syncthreads();  // the tile buffer is rewritten by the next round
     }
   }

@@ -401,6 +401,12 @@ def dct_records_luma_frames(bgr: torch.Tensor, block: int, levels: int, emit_h: 
     return records, pyr, stride
 
 
+def pyramid_levels_frames(pyr: torch.Tensor, stride: int, n: int, w: int, h: int, levels: int) -> torch.Tensor:
+    """Levels 1 .. levels - 1 of `n` packed pyramids whose level-0 planes are in place (cv::buildPyramid, libs/encoder.cpp:470)."""
+    _check(load().svc_hip_pyramid_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels, _stream()))
+    return pyr
+
+
 def wire_patch_types_frames(records: torch.Tensor, block_types: torch.Tensor, w: int, h: int, block: int, mv_block: int = 16,
                             emit_h: Optional[int] = None, all_tiles: bool = False) -> torch.Tensor:
     """Stores the region id of every foreground MV block into the type words of its tiles' records (in place)."""

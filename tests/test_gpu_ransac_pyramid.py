@@ -166,6 +166,34 @@ def test_luma_pyramid(native, oracle, w, h, levels):
             assert np.array_equal(got, p), f"frame {i} level {l}: {(got != p).sum()} px differ"
 
 
+# two levels per pass (pyr_down2_kernel: 256 x 64 source tiles) wherever two more are wanted and the plane is whole 16-byte segments wide:
+# one tile, partial tiles in x / in y / both, planes whose edge falls exactly on a tile boundary, 1080p and 4K level-0 shapes, small planes
+# whose mirrored middle samples all come from one tile, an odd number of levels left (two at once, then one), widths that fall back
+@pytest.mark.parametrize("w,h,levels", [(256, 64, 3), (512, 128, 3), (272, 72, 3), (1920, 1088, 3), (1920, 1088, 4), (3840, 2160, 4), (3840, 2160, 5),
+                                        (16, 8, 3), (32, 16, 3), (48, 12, 3), (240, 68, 3), (768, 192, 5), (1008, 500, 3), (264, 64, 3),
+                                        (128, 8, 2), (720, 576, 4)])
+def test_pyramid_levels_from_an_existing_plane(native, oracle, w, h, levels):
+    """svc_hip_pyramid_levels_frames (cv::buildPyramid from given level-0 planes, libs/encoder.cpp:470) against the oracle, level by level."""
+    rng = np.random.default_rng(w * 7 + h + levels)
+    n = 3
+    planes = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(n)]
+    planes[1][:] = 255  # saturated: the rounding at the top of the range
+    stride = native.pyramid_stride(w, h, levels)
+    buf = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+    for i, p in enumerate(planes):
+        buf[i * stride:i * stride + w * h] = torch.from_numpy(p.ravel()).cuda()
+    native.pyramid_levels_frames(buf, stride, n, w, h, levels)
+    torch.cuda.synchronize()
+    offs = synth.level_offsets(w, h, levels)
+    for i, p in enumerate(planes):
+        want = p
+        for l in range(1, levels):
+            want = oracle.pyr_down(want)
+            got = buf[i * stride + offs[l]: i * stride + offs[l] + want.size].cpu().numpy().reshape(want.shape)
+            assert np.array_equal(got, want), f"frame {i} level {l}: {(got != want).sum()} of {want.size} px differ"
+        assert np.array_equal(buf[i * stride:i * stride + w * h].cpu().numpy().reshape(h, w), p)  # level 0 untouched
+
+
 def test_luma_pyramid_golden(native):
     """The committed fixture (tests/golden/luma_pyramid.npz, expected values from an independent numpy / scipy formulation):
     the frames wide enough for the device entry point, through the C ABI."""

@@ -1,0 +1,22 @@
+set -o pipefail
+mkdir -p gpurun_out/r05d
+timeout -k 10 600 python -m pytest tests/test_gpu_ransac_pyramid.py tests/test_gpu_wire.py tests/test_gpu_clip.py tests/test_gpu_imageops.py -m gpu -x -q > gpurun_out/r05d/tests.log 2>&1; echo "tests rc $?" >> gpurun_out/r05d/tests.log
+tail -3 gpurun_out/r05d/tests.log
+run() {  # label
+for rep in 1 2; do
+for cfg in C3-1080p-3L-dct8-quant C3b-1080p-4L-dct8-quant C5-4k-4L-dct16; do
+for mode in "--wire" ""; do
+  python3 bench.py --config $cfg $mode --schedule serial --no-cpu-baseline --no-hbm-probe --no-end-to-end --sustain-seconds 0 2>> gpurun_out/r05d/ab.err | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$1', d['config']['workload'][:4], '$mode', round(d['ms_per_step'],4), {k:round(v,4) for k,v in d['kernel_ms_per_step'].items()})" >> gpurun_out/r05d/ab.txt
+done; done; done
+}
+run pyr2_1536
+touch scalable_video_codec_amd/csrc/luma_pyramid.hip
+SVC_EXTRA_HIPCC_FLAGS="-DSVC_PYR2_GRID=2048" python3 -c "from scalable_video_codec_amd import build as b; b.build_hip(verbose=True)" >> gpurun_out/r05d/build.log 2>&1
+run pyr2_2048
+touch scalable_video_codec_amd/csrc/luma_pyramid.hip
+SVC_EXTRA_HIPCC_FLAGS="-DSVC_NO_PYR2" python3 -c "from scalable_video_codec_amd import build as b; b.build_hip(verbose=True)" >> gpurun_out/r05d/build.log 2>&1
+run single_level
+cat gpurun_out/r05d/ab.txt
