@@ -401,7 +401,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     hbma_flags = hbma_flags_of(args)
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
              (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0) | \
-             (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0)
+             (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0) | (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
                        lat_depth=args.lat_depth, tuning=tuning)
@@ -505,6 +505,9 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
             n_sus += 50
         dt_sus = time.perf_counter() - t_sus
         res["sustained"] = {"ms_per_step": dt_sus / n_sus * 1e3, "steps": n_sus, "seconds": dt_sus}
+    if info.pairs:
+        # what the speculative transform had to redo: the share of MV blocks whose region id is not 0 (outside the timed region)
+        res["foreground_share"] = float((enc.read("block_types", device=dev) != 0).float().mean().item())
     enc.close()
     torch.cuda.empty_cache()
     return res
@@ -542,8 +545,12 @@ def main() -> None:
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
     ap.add_argument("--two-bgr-passes", action="store_true",
-                    help="--wire: luma + pyramid and the record-emitting transform as two passes over the BGR clip (A/B of the default, which reads "
-                         "it once: records + luma plane from one kernel at the front of the step, type words stored after the segmentation)")
+                    help="luma + pyramid and the transform as two passes over the BGR clip (A/B of the default, which reads it once: the transform at the "
+                         "front of the step also leaves the luma plane; what needs region ids -- the records' type words with --wire, the foreground "
+                         "tiles' quantisation otherwise -- follows after the segmentation)")
+    ap.add_argument("--always-speculate", action="store_true",
+                    help="planes + quant: the speculative one-pass form on every step (default: only while the newest foreground share that has arrived "
+                         "is at most 2 %%; A/B)")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-stage HIP events on every n-th timed step (every step when --steps < 8)")
     # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The
     # environment variables of the round-2 scripts under tools/ are honoured HERE as defaults, not inside the library.
@@ -652,7 +659,8 @@ def main() -> None:
         info = r["info"]
         pw, ph = cfg.padded
         kt, nl = r["stage_ms_per_step"], r["launches_per_step"]
-        side = ("ransac", "segment", "halo_exchange") if args.schedule == "pipelined" else ("halo_exchange",)
+        # type_patch (what a one-pass step owes once its region ids exist) rides the latency stream behind the segmentation
+        side = ("ransac", "segment", "type_patch", "halo_exchange") if args.schedule == "pipelined" else ("halo_exchange",)
         main_kt = {k: v for k, v in kt.items() if k not in side}
         side_kt = {k: v for k, v in kt.items() if k in side}
         elapsed = r["elapsed"]
@@ -676,6 +684,11 @@ def main() -> None:
                 "clip_frames": r["clip_frames"],
                 "frames_per_gpu": info.frames if world == 1 else [clipmod.plan_shard(r["clip_frames"], world, q)[1] for q in range(world)],
                 "encoded_frames_per_step": r["encoded_per_step"],
+                "foreground_mv_blocks": r.get("foreground_share"),
+                "bgr_passes_per_step": ("two (luma + pyramid, later the transform)" if "type_patch" not in kt else
+                                        "one (records + luma plane from one kernel; type words stored after the segmentation)" if args.wire else
+                                        "one, speculative (every tile quantised as background + the luma plane at the front of the step; foreground tiles redone "
+                                        f"in type_patch); timed steps that speculated: {r['launches_timed'].get('type_patch', 0)} of {r['launches_timed'].get('dct_quant', 0)} timed"),
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
                 "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-4) back to back on one stream; "
@@ -753,14 +766,16 @@ def main() -> None:
                         + ("; RANSAC + segmentation of an earlier step may still be running beside it (pipelined schedule)" if args.schedule == "pipelined" else ""),
             }
             if "dct_quant" in kt:
-                one_pass = "type_patch" in kt  # --wire: the transform kernel also stores the luma plane (one pass over the BGR clip)
+                one_pass = "type_patch" in kt  # the transform kernel ran at the front of the step: --wire: the transform kernel also stores the luma plane (one pass over the BGR clip)
                 dct_bytes = (cfg.dct_bytes_per_frame() + (pw * ph if one_pass else 0)) * info.pairs
                 dct_ms = kt["dct_quant"] / nl["dct_quant"]
                 dct_gbps = dct_bytes / (dct_ms * 1e-3) / 1e9
                 dct_key = "dct_records_bytes_per_launch" if args.wire else "dct_bytes_per_launch"
                 dct_traffic, dct_traffic_source = traffic("dct", dct_key, info.pairs)
                 out["roofline_dct"] = {
-                    "kernel": (f"dct_kernel<{cfg.dct_block}, records, luma> (records of the raw coefficients + the luma plane from one pass over the BGR clip)" if one_pass else
+                    "kernel": (f"dct_kernel<{cfg.dct_block}, quant, luma, speculative> (every tile quantised as background + the luma plane from one pass over the BGR clip; "
+                               "the foreground tiles are redone in type_patch)" if one_pass and not args.wire else
+                               f"dct_kernel<{cfg.dct_block}, records, luma> (records of the raw coefficients + the luma plane from one pass over the BGR clip)" if one_pass else
                                f"dct_kernel<{cfg.dct_block}, records> (raw coefficients, libs/encoder.cpp:638-650)" if args.wire else
                                f"dct_kernel<{cfg.dct_block}, quant> (the step's longest kernel)"),
                     "bound": "hbm", "achieved": dct_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -781,8 +796,8 @@ def main() -> None:
             step_gbps = step_bytes / (r["elapsed"] / args.steps) / 1e9
             out["roofline_step"] = {"bound": "hbm", "achieved": step_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": step_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
-                                    "note": ("one pass over the BGR clip (--wire): BGR in once, pyramid out, motion search, records out / ms_per_step; the same step as two "
-                                             "passes moves 3 W H more per frame" if one_pass else
+                                    "note": ("one pass over the BGR clip: BGR in once, pyramid out, motion search, coefficients out / ms_per_step (the redo of the foreground "
+                                             "tiles is not counted as algorithmic bytes); the same step as two passes moves 3 W H more per frame" if one_pass else
                                              "luma+pyramid, motion search and transform of one step / ms_per_step; "
                                              "RANSAC + segmentation move < 1 % of these bytes")}
         if r.get("sustained"):

@@ -30,6 +30,15 @@
 // region ids that exist only after motion search, RANSAC and segmentation of the same step -- are stored into the records where the
 // transform used to run, 2 + depth iterations later (svc_hip_wire_patch_types_frames).  A step's records are complete when its patch
 // has run, so they exist in as many sets as the small per-frame outputs.
+//
+// Planes + quant reads the clip once per step too, by SPECULATION, where that pays: the quantiser's step is the tile's region id's, so the
+// transform at the front of the step quantises every tile as background and leaves the luma plane (svc_hip_dct_quant_luma_frames), and the
+// tiles of foreground MV blocks are redone once the ids exist (svc_hip_dct_quant_redo_frames).  The redo moves scattered 16-pixel pieces
+// and costs ~5 ms per clip's worth of foreground at C3 against ~0.14 ms saved per step: it pays below ~2.7 % foreground MV blocks
+// (profiles/r05_ab_speculative_quant.txt: C3 0.5 % -> 2.43 -> 2.31 ms; C3b / C5 13 % -> 2.67 -> 3.18 ms).  So the driver measures: after every
+// segmentation a counting kernel leaves the step's foreground share in pinned host memory (no wait), and a step speculates only if the
+// newest share that has arrived is at most 2 % (none yet: the plain order) and the shard is at least 50 M pixels x frames (below ~25 frames
+// of 1080p the fixed cost of the extra launches eats the saving).  Results never depend on the choice.
 #ifndef SVC_CLIP_ENCODER_HPP
 #define SVC_CLIP_ENCODER_HPP
 
@@ -78,7 +87,8 @@ struct ClipEncoderConfig {
   bool segment_fork = false;            // pipelined: let the segmentation fork its heavy attempts to a side stream
   bool inline_rmse = false;             // pipelined: keep RANSAC's in-order RMSE sum inside its kernel instead of beside the segmentation
   bool narrow_attempts = false;         // segmentation: one workgroup per (frame, attempt) whatever the shard size (SVC_LAUNCH_NO_WIDE)
-  bool two_bgr_passes = false;          // wire: luma + pyramid and the record-emitting transform as two passes over the BGR clip (A/B of the fused form)
+  bool two_bgr_passes = false;          // never the one-pass forms: luma + pyramid, later the transform, two passes over the BGR clip (A/B)
+  bool always_speculate = false;        // planes + quant: the speculative one-pass form on every step, whatever the foreground share
 };
 
 enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kTypePatch, kCount };

@@ -30,8 +30,11 @@ typedef struct svc_clip svc_clip;
 #define SVC_CLIP_TUNE_SEGMENT_FORK 2u      /* pipelined: the segmentation may fork its heavy attempts to a side stream */
 #define SVC_CLIP_TUNE_INLINE_RMSE 8u       /* pipelined: RANSAC keeps its in-order RMSE sum inside its kernel */
 #define SVC_CLIP_TUNE_NARROW_ATTEMPTS 4u   /* segmentation: never spread a heavy frame's k-means attempts over workgroups */
-#define SVC_CLIP_TUNE_TWO_BGR_PASSES 16u   /* wire: keep luma + pyramid and the record-emitting transform as two passes over the BGR clip
-                                              (the default reads it once: records + luma plane from one kernel, type words stored afterwards) */
+#define SVC_CLIP_TUNE_TWO_BGR_PASSES 16u   /* never read the BGR clip once per step: luma + pyramid, later the transform (the plain order).  Default:
+                                              wire output always reads it once (records + luma plane from one kernel, type words stored afterwards);
+                                              planes + quant speculates -- every tile quantised as background at the front of the step, the foreground
+                                              tiles redone -- while the foreground share of recent steps is small (clip_encoder.hpp) */
+#define SVC_CLIP_TUNE_ALWAYS_SPECULATE 32u /* planes + quant: speculate on every step, whatever the foreground share (tests, A/B) */
 
 typedef struct svc_clip_config {
   uint32_t struct_size;   /* sizeof(svc_clip_config) of the caller's build: svc_clip_create refuses any other value, so a

@@ -339,6 +339,31 @@ int svc_hip_wire_patch_types_frames(const uint32_t* d_block_types, uint32_t n_fr
                                     uint32_t emit_frame_h, uint32_t block, uint32_t mv_block_w, uint32_t mv_block_h,
                                     uint8_t* d_records, uint64_t records_stride_bytes, int all_tiles, void* stream);
 
+/* Dct + quant with the BGR clip read ONCE per step -- speculation on the region ids.  The quantiser's step is the tile's region id's
+ * (libs/decoder.cpp:130-135), and the id exists only after luma -> pyramid -> motion search -> RANSAC -> segmentation of the same frame;
+ * the plain order therefore reads every frame twice (svc_hip_luma_pyramid_frames, later svc_hip_dct_quant_frames).  Instead:
+ *   svc_hip_dct_quant_luma_frames   at the FRONT of a step: every tile quantised as background (bg_step) into d_planes, and the luma
+ *                                   plane (cv::cvtColor + extractChannel, libs/encoder.cpp:468-469) into level 0 of the frame's packed
+ *                                   pyramid, from one pass over the B,G,R bytes (levels 1..: svc_hip_pyramid_levels_frames);
+ *   svc_hip_dct_quant_redo_frames   once the ids exist: the tiles of every MV block whose id is not 0 are transformed again and
+ *                                   quantised with fg_step.  d_ws: svc_hip_dct_redo_workspace_bytes(n_frames, frame_w, frame_h,
+ *                                   mv_block_w, mv_block_h) bytes, 16-byte aligned.
+ * The two calls together leave exactly the bytes of svc_hip_dct_quant_frames.  Cost: 15 bytes per FOREGROUND pixel moved again against
+ * 3 bytes per pixel of every frame saved -- ahead while less than ~17 % of the MV blocks are foreground, behind above that.
+ * block: 8 or 16; frame_w a multiple of 16; MV blocks whole 16-pixel segments wide and whole transform blocks tall; else UNSUPPORTED. */
+int svc_hip_dct_quant_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
+                                  uint32_t frame_h, uint32_t block, uint32_t bg_step, float* d_planes, uint8_t* d_pyr,
+                                  uint64_t pyr_stride_bytes, void* stream);
+/* *d_count = how many of the n region ids are not 0 (foreground MV blocks): the feedback a driver decides on whether the next step
+ * speculates (svc::ClipEncoder does: speculation pays while the share of foreground blocks is a few per cent). */
+int svc_hip_count_foreground(const uint32_t* d_block_types, uint64_t n, uint32_t* d_count, void* stream);
+uint64_t svc_hip_dct_redo_workspace_bytes(uint32_t n_frames, uint32_t frame_w, uint32_t frame_h, uint32_t mv_block_w,
+                                          uint32_t mv_block_h);
+int svc_hip_dct_quant_redo_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
+                                  uint32_t frame_h, uint32_t block, const uint32_t* d_block_types, uint32_t mv_block_w,
+                                  uint32_t mv_block_h, uint32_t fg_step, float* d_planes, uint8_t* d_ws, uint64_t ws_bytes,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Decoder-side inverse path, headless: DecodeBlock over every tile
  * (libs/decoder.cpp:128-149, :183-207) without the GUI.  d_planes: coefficient planes as the

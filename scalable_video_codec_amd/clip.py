@@ -19,7 +19,7 @@ from .native import RansacParams, SegmentParams
 _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
 
 SERIAL, PIPELINED = 0, 1
-TUNE_STANDALONE_SHAPES, TUNE_SEGMENT_FORK, TUNE_NARROW_ATTEMPTS, TUNE_INLINE_RMSE, TUNE_TWO_BGR_PASSES = 1, 2, 4, 8, 16  # svc_clip_config.tuning bits
+TUNE_STANDALONE_SHAPES, TUNE_SEGMENT_FORK, TUNE_NARROW_ATTEMPTS, TUNE_INLINE_RMSE, TUNE_TWO_BGR_PASSES, TUNE_ALWAYS_SPECULATE = 1, 2, 4, 8, 16, 32  # svc_clip_config.tuning bits
 STAGES = ("luma_pyramid", "halo_exchange", "hbma", "ransac", "segment", "dct_quant", "type_patch")
 BUFFERS = {"mv": (0, torch.float32), "min_mad": (1, torch.float32), "global_motion": (2, torch.float32),
            "rmse": (3, torch.float32), "inlier_mask": (4, torch.uint8), "inlier_count": (5, torch.int32),

@@ -530,6 +530,49 @@ int svc_hip_dct_records_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_
                     static_cast<hipStream_t>(stream), d_records, records_stride_bytes, emit_frame_h, d_pyr, pyr_stride_bytes);
 }
 
+int svc_hip_dct_quant_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
+                                  uint32_t frame_h, uint32_t block, uint32_t bg_step, float* d_planes, uint8_t* d_pyr,
+                                  uint64_t pyr_stride_bytes, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block, block);
+  if (rc) return rc;
+  SVC_REQUIRE(d_pyr, "dct_quant_luma: null pyramid");
+  SVC_REQUIRE(bg_step > 0, "dct_quant_luma: quant step must be positive (libs/decoder.cpp:35-47)");
+  if ((rc = validate_dct_alignment(d_bgr, frame_stride_bytes, d_planes, frame_w, block, block))) return rc;
+  SVC_REQUIRE(aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0 && (n_frames <= 1 || pyr_stride_bytes >= (uint64_t)frame_w * frame_h),
+              "dct_quant_luma: pyramids must be 16-byte aligned (stride too), a stride of at least one luma plane");
+  return launch_dct_quant_speculative(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block, bg_step, d_planes, d_pyr,
+                                      pyr_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+int svc_hip_count_foreground(const uint32_t* d_block_types, uint64_t n, uint32_t* d_count, void* stream) {
+  SVC_REQUIRE(d_count && (d_block_types || n == 0), "count_foreground: null pointer");
+  return launch_count_foreground(d_block_types, n, d_count, static_cast<hipStream_t>(stream));
+}
+
+uint64_t svc_hip_dct_redo_workspace_bytes(uint32_t n_frames, uint32_t frame_w, uint32_t frame_h, uint32_t mv_block_w, uint32_t mv_block_h) {
+  if (!mv_block_w || !mv_block_h) return 0;
+  return dct_redo_workspace_bytes(n_frames, (frame_w / mv_block_w) * (frame_h / mv_block_h));
+}
+
+int svc_hip_dct_quant_redo_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
+                                  uint32_t block, const uint32_t* d_block_types, uint32_t mv_block_w, uint32_t mv_block_h,
+                                  uint32_t fg_step, float* d_planes, uint8_t* d_ws, uint64_t ws_bytes, void* stream) {
+  if (n_frames == 0) return SVC_OK;
+  int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block, block);
+  if (rc) return rc;
+  SVC_REQUIRE(d_block_types && d_ws, "dct_quant_redo: null pointer");
+  SVC_REQUIRE(fg_step > 0, "dct_quant_redo: quant step must be positive (libs/decoder.cpp:35-47)");
+  SVC_REQUIRE(mv_block_w > 0 && mv_block_h > 0 && mv_block_w % block == 0 && mv_block_h % block == 0 &&
+                  frame_w % mv_block_w == 0 && frame_h % mv_block_h == 0,
+              "dct_quant_redo: MV block %ux%u must be a multiple of the transform block %u and divide the frame", mv_block_w, mv_block_h, block);
+  if ((rc = validate_dct_alignment(d_bgr, frame_stride_bytes, d_planes, frame_w, block, block))) return rc;
+  SVC_REQUIRE(aligned(d_ws, 16) && ws_bytes >= svc_hip_dct_redo_workspace_bytes(n_frames, frame_w, frame_h, mv_block_w, mv_block_h),
+              "dct_quant_redo: workspace must be 16-byte aligned and hold svc_hip_dct_redo_workspace_bytes()");
+  return launch_dct_quant_redo_foreground(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block, d_block_types, mv_block_w, mv_block_h,
+                                          fg_step, d_planes, d_ws, static_cast<hipStream_t>(stream));
+}
+
 int svc_hip_wire_patch_types_frames(const uint32_t* d_block_types, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
                                     uint32_t emit_frame_h, uint32_t block, uint32_t mv_block_w, uint32_t mv_block_h, uint8_t* d_records,
                                     uint64_t records_stride_bytes, int all_tiles, void* stream) {

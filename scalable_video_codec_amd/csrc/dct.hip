@@ -26,6 +26,8 @@
 // (ds_write_b128) and the column reads (ds_read_b128 / ds_read_b64) conflict-free.
 // Stores: N = 8, float2 per lane = 512 contiguous bytes per wave instruction;
 // N = 16, one float per lane = 256 contiguous bytes.
+#include <algorithm>
+
 #include "luma16.hpp"
 #include "svc_common.hpp"
 
@@ -53,6 +55,10 @@ struct DctArgs {
   // LUMA: the frame's Y plane (level 0 of its packed pyramid) as a by-product of the pass over the BGR bytes
   uint8_t* luma;
   uint64_t luma_stride;     // bytes from one frame's level 0 to the next (the pyramid stride)
+  // SPEC = 2 (redo the foreground): the MV blocks whose region id is not 0, as fg_list[0 .. *fg_count) = frame * mv_blocks + block
+  const uint32_t* fg_list;
+  const uint32_t* fg_count;
+  uint32_t segs_per_block_x, segs_per_block;  // segment columns of one MV block: (mv_bw / 16) x (mv_bh / N)
 };
 
 template <int N> struct Basis;
@@ -180,21 +186,49 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // (luma pass + transform: 1.88 of 13.75 GB per step at C3).  The region id of a tile is not known yet when this runs (it needs the
 // pyramid this kernel is producing): every record's type word is written as 0 = background (libs/codec.hpp:6) and
 // wire_patch_types_kernel (wire.hip) stores the foreground ids once the segmentation has them.
-template <int N, bool QUANT, bool WIRE, bool LUMA = false>
+//
+// SPEC (planes + quant): the quantiser's step depends on the tile's region id (libs/decoder.cpp:130-135), which exists only after luma ->
+// pyramid -> motion search -> RANSAC -> segmentation of the SAME frame -- that is why the two-pass step reads the BGR clip twice.  Speculation
+// removes the second read: SPEC = 1 runs at the FRONT of the step (with LUMA), quantises EVERY tile as background (id 0: bg_step) and leaves the
+// luma plane; once the ids exist, SPEC = 2 redoes exactly the tiles of foreground MV blocks (fg_list, built by fg_list_kernel) with fg_step:
+// a fixed grid whose workgroups walk the list.  Same arithmetic, same bytes as SPEC = 0 with the ids up front.  The redo costs 15 bytes per
+// foreground pixel; the saving is 3 bytes per pixel of every frame: ahead while less than ~17 % of the MV blocks are foreground (C3: 0.5 %).
+template <int N, bool QUANT, bool WIRE, bool LUMA = false, int SPEC = 0>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
-  static_assert(!LUMA || (WIRE && !QUANT), "the luma by-product rides on the raw-coefficient record emitter only");
+  static_assert(!LUMA || (WIRE && !QUANT) || (QUANT && !WIRE && SPEC == 1), "the luma by-product rides on the raw-coefficient record emitter or on the speculative quantiser");
+  static_assert(SPEC == 0 || (QUANT && !WIRE), "speculation is about the quantiser's step");
   constexpr int kSegPerWg = 256 / N;  // 512- and 1024-lane workgroups (longer runs per row) measured level or worse: profiles/r03_ab_dct_lanes.txt
   constexpr int kSlab = WIRE ? (N == 8 ? kSlabWire8 : kSlabWire16) : (N == 8 ? kSlab8 : kSlab16);
   __shared__ __attribute__((aligned(16))) uint8_t lds[kSegPerWg * kSlab];
 
   const uint32_t tid = threadIdx.x;
   const uint32_t sc_local = tid / N, j = tid % N;
-  // a workgroup's place in the clip follows the XCD it runs on: the 2 KiB row pieces that neighbouring
-  // workgroups write land in the same L2 and leave it as longer runs (stores alone: 1.33 -> 1.25 ms)
-  const uint32_t gsc = xcd_contiguous_block(blockIdx.x, gridDim.x) * kSegPerWg + sc_local;
-  if (gsc >= a.total_segcols) return;  // whole N-lane groups leave together
-  const uint32_t band_g = gsc / a.segs_per_band, seg = gsc - band_g * a.segs_per_band;
-  const uint32_t frame = band_g / a.bands_per_frame, band = band_g - frame * a.bands_per_frame;
+  uint32_t n_units = 1, unit = 0;
+  if (SPEC == 2) {  // workgroup-uniform trip count: the list's segment columns / segment columns per workgroup trip
+    const uint32_t total = *a.fg_count * a.segs_per_block;
+    n_units = (total + kSegPerWg - 1) / kSegPerWg;
+    unit = blockIdx.x;
+  }
+  for (; unit < n_units; unit += SPEC == 2 ? gridDim.x : 1u) {
+  uint32_t gsc, frame, band, seg;
+  if (SPEC == 2) {
+    gsc = unit * kSegPerWg + sc_local;  // index into the list's segment columns
+    if (gsc >= *a.fg_count * a.segs_per_block) break;  // whole N-lane groups leave together (the last trip of the last workgroup)
+    const uint32_t item = a.fg_list[gsc / a.segs_per_block], sub = gsc % a.segs_per_block;
+    frame = item / a.mv_blocks;
+    const uint32_t b = item - frame * a.mv_blocks, by = b / a.mfw, bx = b - by * a.mfw;
+    band = by * (a.mv_bh / N) + sub / a.segs_per_block_x;
+    seg = bx * a.segs_per_block_x + sub % a.segs_per_block_x;
+  } else {
+    // a workgroup's place in the clip follows the XCD it runs on: the 2 KiB row pieces that neighbouring
+    // workgroups write land in the same L2 and leave it as longer runs (stores alone: 1.33 -> 1.25 ms)
+    gsc = xcd_contiguous_block(blockIdx.x, gridDim.x) * kSegPerWg + sc_local;
+    if (gsc >= a.total_segcols) return;  // whole N-lane groups leave together
+    const uint32_t band_g = gsc / a.segs_per_band;
+    seg = gsc - band_g * a.segs_per_band;
+    frame = band_g / a.bands_per_frame;
+    band = band_g - frame * a.bands_per_frame;
+  }
   const uint32_t y_pix = band * N, x_pix = seg * 16;
 
   // 16 BGR pixels of row j of this segment column
@@ -219,8 +253,8 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   float* out_frame = a.planes + (size_t)frame * 3 * a.w * a.h;
 
   float step = 1.f, inv_step = 1.f;
-  uint32_t t = 0;
-  if ((QUANT || WIRE) && !LUMA) {
+  uint32_t t = SPEC == 2 ? 1u : 0u;  // SPEC 1: everything as background; SPEC 2: the list holds foreground blocks only
+  if ((QUANT || WIRE) && !LUMA && SPEC == 0) {
     // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249);
     // background (0, libs/codec.hpp:6) takes bg_step (libs/decoder.cpp:130-135)
     const uint32_t col = N == 8 ? x_pix + 2 * j : x_pix + j;
@@ -359,6 +393,21 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
         }
     }
   }
+  }  // the trips of SPEC = 2 (one trip otherwise); a slab is rewritten by the wave that owns it, behind its own wave_lds_sync
+}
+
+// The foreground MV blocks of a batch of frames as a list (order irrelevant: every entry is redone independently).
+__global__ __launch_bounds__(256) void fg_list_kernel(const uint32_t* types, uint32_t total_blocks, uint32_t* list, uint32_t* count) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  const bool fg = g < total_blocks && types[g] != 0;
+  // one atomic per wave: the wave's foreground lanes take consecutive slots
+  const uint64_t m = __builtin_amdgcn_ballot_w64(fg);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)__builtin_popcountll(m);
+  uint32_t base = 0;
+  if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, n);
+  base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
+  if (fg) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = g;
 }
 
 // ---- any transform block the reference's Validate admits (libs/encoder.cpp:62-142) ---------------
@@ -573,6 +622,94 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   }
 #undef SVC_DCT_LAUNCH
   return check_launch("dct_kernel");
+}
+
+// How many MV blocks of a batch are foreground (region id != 0): the feedback the driver's speculation policy runs on.
+__global__ __launch_bounds__(256) void fg_count_kernel(const uint32_t* types, uint32_t total_blocks, uint32_t* count) {
+  uint32_t n = 0;
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total_blocks; g += gridDim.x * 256u) n += types[g] != 0 ? 1u : 0u;
+  const uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
+  if (m == 0) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(count, n);
+}
+
+int launch_count_foreground(const uint32_t* d_types, uint64_t n, uint32_t* d_count, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_count, 0, 4, stream);
+  if (e != hipSuccess) return fail(SVC_ERR_HIP, "count_foreground: hipMemsetAsync: %s", hipGetErrorString(e));
+  if (n == 0) return SVC_OK;
+  if (n > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "count_foreground: too many MV blocks for one launch");
+  hipLaunchKernelGGL(fg_count_kernel, dim3(std::min<uint32_t>(div_up((uint32_t)n, 256), 1024u)), dim3(256), 0, stream, d_types, (uint32_t)n, d_count);
+  return check_launch("fg_count_kernel");
+}
+
+// ---- speculative quantisation: one pass over the BGR clip per step (see dct_kernel, SPEC) --------------------------------------
+static bool spec_shape_ok(uint32_t w, uint32_t block) { return (block == 8 || block == 16) && w % 16 == 0; }
+
+// planes quantised with bg_step EVERYWHERE (every tile taken for background) + the luma plane, at the front of a step
+int launch_dct_quant_speculative(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t block,
+                                 uint32_t bg_step, float* d_planes, uint8_t* d_luma, uint64_t luma_stride, hipStream_t stream) {
+  if (!spec_shape_ok(w, block))
+    return fail(SVC_ERR_UNSUPPORTED, "dct_quant_luma: the speculative form needs the tuned transform (8x8 / 16x16 blocks, width a multiple of 16)");
+  DctArgs a{};
+  a.bgr = d_bgr; a.frame_stride = frame_stride;
+  a.w = w; a.h = h;
+  a.segs_per_band = w / 16;
+  a.bands_per_frame = h / block;
+  const uint64_t total = (uint64_t)n_frames * a.segs_per_band * a.bands_per_frame;
+  if (total == 0) return SVC_OK;
+  if (total > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "dct: %llu segment columns exceed one launch", (unsigned long long)total);
+  a.total_segcols = (uint32_t)total;
+  a.planes = d_planes;
+  a.luma = d_luma; a.luma_stride = luma_stride;
+  a.fg_step = a.bg_step = (float)bg_step;
+  a.fg_inv = a.bg_inv = 1.0f / a.bg_step;
+  const dim3 grid(div_up(a.total_segcols, 256 / block)), blk(256);
+  if (block == 8) hipLaunchKernelGGL((dct_kernel<8, true, false, true, 1>), grid, blk, 0, stream, a);
+  else hipLaunchKernelGGL((dct_kernel<16, true, false, true, 1>), grid, blk, 0, stream, a);
+  return check_launch("dct_kernel<speculative>");
+}
+
+uint64_t dct_redo_workspace_bytes(uint32_t n_frames, uint32_t mv_blocks) { return 16 + 4ull * n_frames * mv_blocks; }
+
+// the tiles of foreground MV blocks once more, with fg_step: list the blocks, then a fixed grid walks the list
+int launch_dct_quant_redo_foreground(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t block,
+                                     const uint32_t* d_types, uint32_t mv_bw, uint32_t mv_bh, uint32_t fg_step, float* d_planes,
+                                     uint8_t* d_ws, hipStream_t stream) {
+  if (!spec_shape_ok(w, block) || mv_bw % 16 != 0 || mv_bh % block != 0)
+    return fail(SVC_ERR_UNSUPPORTED, "dct_quant_redo: needs the tuned transform (8x8 / 16x16, width a multiple of 16) and MV blocks that are whole "
+                                     "16-pixel segments wide and whole transform blocks tall");
+  DctArgs a{};
+  a.bgr = d_bgr; a.frame_stride = frame_stride;
+  a.w = w; a.h = h;
+  a.segs_per_band = w / 16;
+  a.bands_per_frame = h / block;
+  a.planes = d_planes;
+  a.mv_bw = mv_bw; a.mv_bh = mv_bh;
+  a.mfw = w / mv_bw;
+  a.mv_blocks = a.mfw * (h / mv_bh);
+  const uint64_t total_blocks = (uint64_t)n_frames * a.mv_blocks;
+  if (total_blocks == 0) return SVC_OK;
+  if (total_blocks * (mv_bw / 16) * (mv_bh / block) > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "dct_quant_redo: too many MV blocks for one launch");
+  a.fg_step = a.bg_step = (float)fg_step;
+  a.fg_inv = a.bg_inv = 1.0f / a.fg_step;
+  uint32_t* count = reinterpret_cast<uint32_t*>(d_ws);
+  uint32_t* list = reinterpret_cast<uint32_t*>(d_ws + 16);
+  a.fg_count = count; a.fg_list = list;
+  a.segs_per_block_x = mv_bw / 16;
+  a.segs_per_block = a.segs_per_block_x * (mv_bh / block);
+  hipError_t e = hipMemsetAsync(count, 0, 16, stream);
+  if (e != hipSuccess) return fail(SVC_ERR_HIP, "dct_quant_redo: hipMemsetAsync: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(fg_list_kernel, dim3(div_up((uint32_t)total_blocks, 256)), dim3(256), 0, stream, d_types, (uint32_t)total_blocks, list, count);
+  int rc = check_launch("fg_list_kernel");
+  if (rc) return rc;
+  // 36 KB of LDS: four workgroups per CU are resident; the grid never outnumbers the work a list of EVERY block would hold
+  const uint64_t worst = div_up((uint32_t)(total_blocks * a.segs_per_block), 256 / block);
+  const dim3 grid((uint32_t)std::min<uint64_t>(worst, 2048)), blk(256);
+  if (block == 8) hipLaunchKernelGGL((dct_kernel<8, true, false, false, 2>), grid, blk, 0, stream, a);
+  else hipLaunchKernelGGL((dct_kernel<16, true, false, false, 2>), grid, blk, 0, stream, a);
+  return check_launch("dct_kernel<redo foreground>");
 }
 
 // ---- cv::dct over a LIST of tiles of one f32 image, in place -------------------------------------

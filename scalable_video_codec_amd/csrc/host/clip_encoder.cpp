@@ -76,7 +76,8 @@ struct ClipEncoder::Impl {
   int depth = 1, nsets = 1;
   hipStream_t sM = nullptr, sL[kMaxDepth] = {nullptr, nullptr, nullptr}, sC = nullptr;
   DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records[kSets + 1];
-  DevBuf<float> mv[kSets], mad[kSets], gm[kSets], rmse[kSets], coeffs;
+  DevBuf<float> mv[kSets], mad[kSets], gm[kSets], rmse[kSets], coeffs[kSets + 1];
+  DevBuf<uint8_t> redo_ws[kMaxDepth];  // spec_quant: the foreground list of the step being finished, one per latency stream (as seg_ws)
   DevBuf<uint32_t> count[kSets], types[kSets], samples;
   hipEvent_t e_pyr[2] = {nullptr, nullptr}, e_halo[2] = {nullptr, nullptr}, e_fork = nullptr, e_join[kSets] = {}, e_rfork = nullptr, e_rmse[kSets] = {};
   bool halo_recorded[2] = {false, false}, join_pending[kSets] = {}, rmse_pending[kSets] = {};
@@ -100,6 +101,49 @@ struct ClipEncoder::Impl {
   // records (with nsets it would be the same iteration, and the front runs first)
   int rec_sets = 1;
   DevBuf<uint8_t>& Records(uint64_t s) { return records[(int)(s % (uint64_t)rec_sets)]; }
+  // The same for planes + quant: the transform runs at the front of the step with every tile quantised as background and leaves the luma
+  // plane (svc_hip_dct_quant_luma_frames); the tiles of foreground MV blocks are redone with fg_step where the transform used to run
+  // (svc_hip_dct_quant_redo_frames).  Coefficient planes then exist in rec_sets sets too.
+  bool spec_quant = false;  // the configuration CAN speculate; whether a step does is spec_step[]
+  DevBuf<float>& Coeffs(uint64_t s) { return coeffs[spec_quant ? (int)(s % (uint64_t)rec_sets) : 0]; }
+  bool spec_step[kSets + 1] = {};  // step s speculated (indexed like the record / coefficient sets)
+  bool& SpecStep(uint64_t s) { return spec_step[(int)(s % (uint64_t)rec_sets)]; }
+  // The policy's feedback: after the segmentation of a step a counting kernel + a 4-byte copy leave the step's number of foreground MV
+  // blocks in pinned host memory; nobody waits for it -- a step decides on the newest count that has arrived by then.
+  static constexpr int kFgSlots = 8;
+  static constexpr double kSpecMaxShare = 0.02;
+  static constexpr uint64_t kSpecMinPixels = 50000000ull;  // encoded frames x padded pixels of the shard
+  DevBuf<uint32_t> fg_dev;
+  uint32_t* fg_host = nullptr;
+  hipEvent_t e_fg[kFgSlots] = {};
+  bool fg_pending[kFgSlots] = {};
+  uint64_t n_fg = 0;
+  double fg_share = -1.0;  // newest foreground share known (-1: none yet)
+  void MeasureForeground(int set, hipStream_t st) {
+    if (!spec_quant || c.two_bgr_passes || c.always_speculate || !sh.pairs) return;  // only the adaptive policy asks
+    const int slot = (int)(n_fg % kFgSlots);
+    if (fg_pending[slot] && hipEventQuery(e_fg[slot]) != hipSuccess) return;  // eight measurements in flight: skip this one
+    Abi(svc_hip_count_foreground(types[set].p, (uint64_t)sh.pairs * blocks, fg_dev.p + slot, st), "svc_hip_count_foreground");
+    Hip(hipMemcpyAsync(fg_host + slot, fg_dev.p + slot, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+    Hip(hipEventRecord(e_fg[slot], st), "hipEventRecord");
+    fg_pending[slot] = true;
+    ++n_fg;
+  }
+  bool DecideSpeculation() {
+    if (!spec_quant || c.two_bgr_passes) return false;
+    if (c.always_speculate) return true;
+    // small shards do not pay: the front-of-step transform costs a fixed ~10 us more than it saves below ~25 frames of 1080p
+    // (profiles/r05_ab_speculative_quant.txt: 1080p shards of 150 / 75 / 38 / 19 frames -6 / -4 / -2 / +-1 %; C2's 29 frames of 720p +5 %)
+    if ((uint64_t)sh.pairs * pw * ph < kSpecMinPixels) return false;
+    for (uint64_t k = n_fg; k > 0 && k + kFgSlots > n_fg; --k) {  // newest first
+      const int slot = (int)((k - 1) % kFgSlots);
+      if (!fg_pending[slot]) continue;
+      if (hipEventQuery(e_fg[slot]) != hipSuccess) continue;
+      fg_share = (double)fg_host[slot] / ((double)sh.pairs * blocks);
+      break;
+    }
+    return fg_share >= 0.0 && fg_share <= kSpecMaxShare;
+  }
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[kStages];
@@ -114,6 +158,9 @@ struct ClipEncoder::Impl {
     for (hipEvent_t e : {e_pyr[0], e_pyr[1], e_halo[0], e_halo[1], e_fork, e_rfork, e_join[0], e_join[1], e_join[2], e_join[3], e_join[4],
                          e_rmse[0], e_rmse[1], e_rmse[2], e_rmse[3], e_rmse[4]})
       if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : e_fg)
+      if (e) (void)hipEventDestroy(e);
+    if (fg_host) (void)hipHostFree(fg_host);
     for (hipStream_t s : {sM, sL[0], sL[1], sL[2], sC})
       if (s) (void)hipStreamDestroy(s);
   }
@@ -143,13 +190,18 @@ struct ClipEncoder::Impl {
   // ---- the stages; `s` is the step index, its buffers are those of set Par(s) ---------------
   void Luma(uint64_t s, hipStream_t st, bool timing) {
     const int b = Par(s);
-    if (one_bgr_pass) {
+    if (spec_quant) SpecStep(s) = DecideSpeculation();
+    if (one_bgr_pass || (spec_quant && SpecStep(s))) {
       // own frame j lives in pyramid slot 1 + j; encoded frame p is own frame p (halo in slot 0) or p + 1 (frame 0 is tracked only)
       const uint32_t skip = sh.needs_halo ? 0u : 1u;
       uint8_t* slots = pyr[b].p + (uint64_t)(1 + skip) * pyr_stride;
       Run(Stage::kTransform, st, timing, [&] {
-        Abi(svc_hip_dct_records_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, ph,
-                                            Records(s).p, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
+        if (!one_bgr_pass)
+          Abi(svc_hip_dct_quant_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.bg_step,
+                                            Coeffs(s).p, slots, pyr_stride, st), "svc_hip_dct_quant_luma_frames");
+        else
+          Abi(svc_hip_dct_records_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, ph,
+                                              Records(s).p, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
       });
       Run(Stage::kLumaPyramid, st, timing, [&] {
         if (skip)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
@@ -228,17 +280,36 @@ struct ClipEncoder::Impl {
       else
         Abi(svc_hip_block_types_frames(mask[b].p, blocks, sh.pairs, types[b].p, st), "svc_hip_block_types_frames");
     });
+    MeasureForeground(b, st);
+    if (c.schedule == Schedule::kPipelined && OnePassStep(s)) FinishOnePass(s, st, timing);
+  }
+
+  bool OnePassStep(uint64_t s) { return one_bgr_pass || (spec_quant && SpecStep(s)); }
+
+  // What a one-pass step still owes once its region ids exist: the type words of the records it emitted at its front (wire), or the tiles
+  // of its foreground MV blocks once more with fg_step (planes).  Latency-bound (a list, a few thousand scattered tiles): in the pipelined
+  // schedule it runs on the latency stream right behind the segmentation, beside the main stream's kernels, and the main stream only joins.
+  void FinishOnePass(uint64_t s, hipStream_t st, bool timing) {
+    if (!sh.pairs || !c.dct_block_w) return;
+    const int b = Set(s);
+    const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
+    DevBuf<uint8_t>& rws = redo_ws[c.schedule == Schedule::kPipelined ? (int)(s % (uint64_t)depth) : 0];
+    Run(Stage::kTypePatch, st, timing, [&] {
+      if (one_bgr_pass)
+        Abi(svc_hip_wire_patch_types_frames(types[b].p, sh.pairs, pw, ph, ph, c.dct_block_w, c.mv_block, c.mv_block, Records(s).p,
+                                            record_bytes, 0, st), "svc_hip_wire_patch_types_frames");
+      else
+        Abi(svc_hip_dct_quant_redo_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block, c.fg_step,
+                                          Coeffs(s).p, rws.p, rws.bytes(), st), "svc_hip_dct_quant_redo_frames");
+    });
   }
 
   void Transform(uint64_t s, hipStream_t st, bool timing) {
     if (!sh.pairs || !c.dct_block_w) return;
     const int b = Set(s);
     const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
-    if (one_bgr_pass) {  // the records left at the front of step s; what is still missing are the region ids of its foreground tiles
-      Run(Stage::kTypePatch, st, timing, [&] {
-        Abi(svc_hip_wire_patch_types_frames(types[b].p, sh.pairs, pw, ph, ph, c.dct_block_w, c.mv_block, c.mv_block, Records(s).p,
-                                            record_bytes, 0, st), "svc_hip_wire_patch_types_frames");
-      });
+    if (OnePassStep(s)) {  // the transform ran at the front of the step; its finish follows the segmentation (pipelined: on that stream, Lat)
+      if (c.schedule != Schedule::kPipelined) FinishOnePass(s, st, timing);
       return;
     }
     Run(Stage::kTransform, st, timing, [&] {
@@ -248,12 +319,12 @@ struct ClipEncoder::Impl {
         Abi(svc_hip_dct_records_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block,
                                        0, 0, ph, records[0].p, record_bytes, st), "svc_hip_dct_records_frames");
       else if (c.wire) {  // any other transform block: Dct, then SerializeEncodedFrame
-        Abi(svc_hip_dct_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, coeffs.p, st), "svc_hip_dct_frames");
-        Abi(svc_hip_serialize_frames(coeffs.p, plane_elems, sh.pairs, types[b].p, pw, ph, c.dct_block_w, c.dct_block_h, mfw, mfh,
+        Abi(svc_hip_dct_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, coeffs[0].p, st), "svc_hip_dct_frames");
+        Abi(svc_hip_serialize_frames(coeffs[0].p, plane_elems, sh.pairs, types[b].p, pw, ph, c.dct_block_w, c.dct_block_h, mfw, mfh,
                                      c.mv_block, c.mv_block, records[0].p, record_bytes, st), "svc_hip_serialize_frames");
       } else
         Abi(svc_hip_dct_quant_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, types[b].p, c.mv_block,
-                                     c.mv_block, c.fg_step, c.bg_step, coeffs.p, st), "svc_hip_dct_quant_frames");
+                                     c.mv_block, c.fg_step, c.bg_step, Coeffs(s).p, st), "svc_hip_dct_quant_frames");
     });
   }
 
@@ -406,10 +477,20 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   // one pass over the BGR clip: the tuned record emitter (8x8 / 16x16 on widths that are whole 16-pixel segments) also leaves the luma plane
   m.one_bgr_pass = m.fused_records && !c.two_bgr_passes && transform && (c.dct_block_w == 8 || c.dct_block_w == 16) && m.pw % 16 == 0 &&
                    c.mv_block % c.dct_block_w == 0 && P > 0;
+  m.spec_quant = !c.wire && transform && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) &&
+                 m.pw % 16 == 0 && c.mv_block % 16 == 0 && c.mv_block % c.dct_block_w == 0 && c.fg_step > 0 && c.bg_step > 0 && P > 0;
+  m.rec_sets = (m.one_bgr_pass || m.spec_quant) && pipelined ? m.nsets + 1 : 1;
   if (transform) {
     if (c.wire)
-      for (int b = 0; b < (m.rec_sets = m.one_bgr_pass && pipelined ? m.nsets + 1 : 1); ++b) m.records[b].Alloc((size_t)P * m.record_bytes);
-    if (!c.wire || !m.fused_records) m.coeffs.Alloc((size_t)P * 3 * m.plane_elems);
+      for (int b = 0; b < m.rec_sets; ++b) m.records[b].Alloc((size_t)P * m.record_bytes);
+    if (!c.wire || !m.fused_records)
+      for (int b = 0; b < (m.spec_quant ? m.rec_sets : 1); ++b) m.coeffs[b].Alloc((size_t)P * 3 * m.plane_elems);
+    if (m.spec_quant) {
+      for (int k = 0; k < m.depth; ++k) m.redo_ws[k].Alloc(svc_hip_dct_redo_workspace_bytes(P, m.pw, m.ph, c.mv_block, c.mv_block));
+      m.fg_dev.Alloc(Impl::kFgSlots);
+      Hip(hipHostMalloc(reinterpret_cast<void**>(&m.fg_host), Impl::kFgSlots * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+      for (hipEvent_t& e : m.e_fg) Hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    }
   }
   // RANSAC draws: distinct within an iteration, a function of (seed, clip frame, iteration) only --
   // the generator of stream_encoder.cpp / pipeline.ransac_samples, indexed by the CLIP-wide pair
@@ -504,7 +585,7 @@ void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
     case Buffer::kInlierMask: ptr = m.mask[par].p; n = m.mask[par].bytes(); break;
     case Buffer::kInlierCount: ptr = m.count[par].p; n = m.count[par].bytes(); break;
     case Buffer::kBlockTypes: ptr = m.types[par].p; n = m.types[par].bytes(); break;
-    case Buffer::kCoeffs: ptr = m.coeffs.p; n = m.coeffs.bytes(); break;
+    case Buffer::kCoeffs: { auto& q = m.n_dct ? m.Coeffs(m.n_dct - 1) : m.coeffs[0]; ptr = q.p; n = q.bytes(); break; }
     case Buffer::kRecords: { auto& r = m.n_dct ? m.Records(m.n_dct - 1) : m.records[0]; ptr = r.p; n = r.bytes(); break; }
     case Buffer::kPyramids: ptr = m.pyr[ppar].p; n = m.pyr[ppar].bytes(); break;
     case Buffer::kBgr: ptr = m.bgr.p; n = m.bgr.bytes(); break;
@@ -564,7 +645,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
                                std::to_string(sizeof(svc_clip_config)) + " bytes (set struct_size = sizeof(svc_clip_config))");
     constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
-                                   SVC_CLIP_TUNE_TWO_BGR_PASSES;
+                                   SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -582,6 +663,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.narrow_attempts = (k->tuning & SVC_CLIP_TUNE_NARROW_ATTEMPTS) != 0;
     c.inline_rmse = (k->tuning & SVC_CLIP_TUNE_INLINE_RMSE) != 0;
     c.two_bgr_passes = (k->tuning & SVC_CLIP_TUNE_TWO_BGR_PASSES) != 0;
+    c.always_speculate = (k->tuning & SVC_CLIP_TUNE_ALWAYS_SPECULATE) != 0;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
     h->enc.reset(new svc::ClipEncoder(c));

@@ -165,6 +165,63 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t b, uint32_t g, uint32_t r) 
   return (1868u * b + 9617u * g + 4899u * r + 8192u) >> 14;
 }
 
+// The 5x5 pass from a luma tile in LDS (LDS column kOff + c <-> x = x0 + c, row r <-> y = y0 - 2 + r) to the next level's plane.
+template <int TW, int TH, int RPT>
+__device__ __forceinline__ void next_level_from_tile(const LumaPyr1Args& a, const uint8_t* tile, int x0, int y0, int w, int h, uint8_t* y_plane) {
+  constexpr int kTW = TW, kTH = TH, kPitch = TW + 2 * kOff;
+  const uint32_t tid = threadIdx.x;
+  // (c) next level: a task = a quad of 4 output columns x RPT consecutive output rows.  The output rows of a task share source rows (2 RPT + 3
+  // of them instead of 5 RPT) and the four horizontal 5-tap sums of a source row are formed once: per quad of outputs 100 vector
+  // instructions and 15 LDS reads at RPT = 1, 62 / 11 at 2, 53 / 8 at 4.  Measured on the plane-to-plane pass (profiles/r05_ab_plane_rpt.txt,
+  // C3 wire pyramid stage = Y -> level 1 -> level 2): RPT 1 0.273-0.282 ms, 2 0.266-0.275, 4 0.324-0.326 (one long task per lane hides its
+  // LDS latency worse than two short ones): the pass is not bound by its instruction count.  The BGR pass keeps 1, the plane pass takes 2.
+  constexpr int kQuads = kTW / 8;  // quads of output columns per tile row
+  constexpr int kGroups = kTH / 2 / RPT;
+  static_assert(kTH / 2 % RPT == 0, "row groups tile the output rows");
+  constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
+  constexpr int taps[5] = {1, 4, 6, 4, 1};
+  for (int task = (int)tid; task < kQuads * kGroups; task += 256) {
+    const int q = task % kQuads, oy0 = (task / kQuads) * RPT;
+    const int gx = (x0 >> 1) + 4 * q, gy0 = (y0 >> 1) + oy0;  // output-level coordinates
+    if (gx >= (w >> 1) || gy0 >= (h >> 1)) continue;
+    uint32_t acc[RPT][4];
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0;
+#pragma unroll
+    for (int r = 0; r < 2 * RPT + 3; ++r) {
+      // centre of output column 4q + o is LDS column kOff + 8q + 2o; taps span kOff + 8q - 2 .. + 8
+      const uint8_t* rowp = &tile[(2 * oy0 + r) * kPitch + kOff + 8 * q];
+      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
+      const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
+      const uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
+      // taps 1 4 6 4 of an output are one 4 x u8 dot product over the dword that starts at its first tap;
+      // the fifth tap (weight 1) enters as the accumulator
+      const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.x, w0, 2), kTaps, (mid.x >> 16) & 0xFFu, false);
+      const uint32_t h1 = __builtin_amdgcn_udot4(mid.x, kTaps, mid.y & 0xFFu, false);
+      const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), kTaps, (mid.y >> 16) & 0xFFu, false);
+      const uint32_t h3 = __builtin_amdgcn_udot4(mid.y, kTaps, w3 & 0xFFu, false);
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) {
+        const int t5 = r - 2 * o;  // which tap of output row o this source row is
+        if (t5 >= 0 && t5 < 5) {
+          acc[o][0] += (uint32_t)taps[t5] * h0;
+          acc[o][1] += (uint32_t)taps[t5] * h1;
+          acc[o][2] += (uint32_t)taps[t5] * h2;
+          acc[o][3] += (uint32_t)taps[t5] * h3;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) {
+      if (gy0 + o >= (h >> 1)) break;
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out |= ((acc[o][k] + 128u) >> 8) << (8 * k);
+      *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)(gy0 + o) * (w >> 1) + gx) = out;
+    }
+  }
+}
+
 // FROM_BGR: luma from the B,G,R frame -> level 0 (stored) -> level 1.  !FROM_BGR: the same tile machinery on an
 // existing pyramid plane (level l -> l + 1): aligned 16-byte loads of the source rows into LDS, the 5x5 pass out of
 // LDS -- instead of pyr_down_kernel's 7 unaligned dwordx4 loads per 8 outputs straight from L2 (2.3 TB/s).
@@ -247,56 +304,76 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
   }  // FROM_BGR
   __syncthreads();
 
-  // (c) next level: a task = a quad of 4 output columns x RPT consecutive output rows.  The output rows of a task share source rows (2 RPT + 3
-  // of them instead of 5 RPT) and the four horizontal 5-tap sums of a source row are formed once: per quad of outputs 100 vector
-  // instructions and 15 LDS reads at RPT = 1, 62 / 11 at 2, 53 / 8 at 4.  Measured on the plane-to-plane pass (profiles/r05_ab_plane_rpt.txt,
-  // C3 wire pyramid stage = Y -> level 1 -> level 2): RPT 1 0.273-0.282 ms, 2 0.266-0.275, 4 0.324-0.326 (one long task per lane hides its
-  // LDS latency worse than two short ones): the pass is not bound by its instruction count.  The BGR pass keeps 1, the plane pass takes 2.
-  constexpr int kQuads = kTW / 8;  // quads of output columns per tile row
-  constexpr int kGroups = kTH / 2 / RPT;
-  static_assert(kTH / 2 % RPT == 0, "row groups tile the output rows");
-  constexpr uint32_t kTaps = 1u | (4u << 8) | (6u << 16) | (4u << 24);
-  constexpr int taps[5] = {1, 4, 6, 4, 1};
-  for (int task = (int)tid; task < kQuads * kGroups; task += 256) {
-    const int q = task % kQuads, oy0 = (task / kQuads) * RPT;
-    const int gx = (x0 >> 1) + 4 * q, gy0 = (y0 >> 1) + oy0;  // output-level coordinates
-    if (gx >= (w >> 1) || gy0 >= (h >> 1)) continue;
-    uint32_t acc[RPT][4];
+  next_level_from_tile<TW, TH, RPT>(a, tile, x0, y0, w, h, y_plane);
+}
+
+// ---- the BGR pass with its rows brought in by LDS-DMA ------------------------------------------------------------------------
+// Same tile, same arithmetic, same bytes as luma_pyr1_kernel<true, 128, 32>; what changes is how the B,G,R bytes arrive: every 16-byte chunk of
+// the tile's 36 rows (24 chunks of pixels + one chunk on each side that holds the two halo pixels: 936 chunks) is fetched by
+// global_load_lds_dwordx4 -- no register holds a load result, a lane issues its three or four chunk loads back to back, and the workgroup
+// waits ONCE (the register form waits three times in a row: first round of segment tasks, the 32 lanes of the second round, halo pixels).
+// Y is then computed LDS -> LDS.  
+constexpr int kDmaCPR = kTWBgr * 3 / 16 + 2, kDmaRows = kTHBgr + 4, kDmaChunks = kDmaCPR * kDmaRows;
+constexpr int kDmaRounds = (kDmaChunks + 255) / 256, kDmaBytes = (kDmaChunks + 63) / 64 * 1024, kDmaRowBytes = kDmaCPR * 16;
+
+__global__ __launch_bounds__(256) void luma_pyr1_dma_kernel(LumaPyr1Args a) {
+  constexpr int kTW = kTWBgr, kTH = kTHBgr, kPitch = kTW + 2 * kOff;
+  __shared__ __attribute__((aligned(16))) uint8_t raw[kDmaBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(kTH + 4) * kPitch];
+  const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (t >= a.total_tiles) return;  // workgroup-uniform
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t frame = t / a.tiles_per_frame, tr = t - frame * a.tiles_per_frame;
+  const uint32_t ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+  const int x0 = (int)tx * kTW, y0 = (int)ty * kTH, w = (int)a.w, h = (int)a.h;
+  const int segs = min(kTW, w - x0) / 16, xe = x0 + segs * 16;
+  const uint8_t* src = a.bgr + (size_t)frame * a.frame_stride;  // uniform over the workgroup: the DMA's scalar base
+  uint8_t* y_plane = a.pyr + (size_t)frame * a.pyr_stride;
+  const int rows = min(kTH + 4, h - y0 + 3);
+
+  // chunk i of the raw tile (row-major, kDmaCPR chunks per row) is fetched by lane i % 64 of the wave instruction that covers chunks
+  // [i & ~63, + 64): LDS-DMA writes a wave's 64 x 16 bytes contiguously from the wave-uniform LDS address in M0.  A chunk the tile does
+  // not need (a row past the plane, the side chunk of a tile at the frame's edge) comes from a clamped, valid address and is never read.
+  const uint32_t raw0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)raw;
 #pragma unroll
-    for (int o = 0; o < RPT; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0;
-#pragma unroll
-    for (int r = 0; r < 2 * RPT + 3; ++r) {
-      // centre of output column 4q + o is LDS column kOff + 8q + 2o; taps span kOff + 8q - 2 .. + 8
-      const uint8_t* rowp = &tile[(2 * oy0 + r) * kPitch + kOff + 8 * q];
-      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rowp - 4);
-      const uint2 mid = *reinterpret_cast<const uint2*>(rowp);
-      const uint32_t w3 = *reinterpret_cast<const uint32_t*>(rowp + 8);
-      // taps 1 4 6 4 of an output are one 4 x u8 dot product over the dword that starts at its first tap;
-      // the fifth tap (weight 1) enters as the accumulator
-      const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.x, w0, 2), kTaps, (mid.x >> 16) & 0xFFu, false);
-      const uint32_t h1 = __builtin_amdgcn_udot4(mid.x, kTaps, mid.y & 0xFFu, false);
-      const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), kTaps, (mid.y >> 16) & 0xFFu, false);
-      const uint32_t h3 = __builtin_amdgcn_udot4(mid.y, kTaps, w3 & 0xFFu, false);
-#pragma unroll
-      for (int o = 0; o < RPT; ++o) {
-        const int t5 = r - 2 * o;  // which tap of output row o this source row is
-        if (t5 >= 0 && t5 < 5) {
-          acc[o][0] += (uint32_t)taps[t5] * h0;
-          acc[o][1] += (uint32_t)taps[t5] * h1;
-          acc[o][2] += (uint32_t)taps[t5] * h2;
-          acc[o][3] += (uint32_t)taps[t5] * h3;
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 0; o < RPT; ++o) {
-      if (gy0 + o >= (h >> 1)) break;
-      uint32_t out = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) out |= ((acc[o][k] + 128u) >> 8) << (8 * k);
-      *reinterpret_cast<uint32_t*>(y_plane + a.dst_off + (size_t)(gy0 + o) * (w >> 1) + gx) = out;
+  for (int r = 0; r < kDmaRounds; ++r) {
+    const uint32_t slice = (uint32_t)r * 4u + wave;
+    if (slice * 64u < (uint32_t)kDmaChunks) {  // wave-uniform
+      const int i = min((int)(slice * 64u + (tid & 63u)), kDmaChunks - 1);
+      const int row = i / kDmaCPR, c = i - row * kDmaCPR;
+      const int y = reflect101(min(y0 - 2 + row, h), h);
+      const int xb = min(max(3 * x0 - 16 + 16 * c, 0), 3 * w - 16);
+      const uint32_t voff = (uint32_t)y * (uint32_t)(3 * w) + (uint32_t)xb;
+      const uint32_t m0v = __builtin_amdgcn_readfirstlane(raw0 + slice * 1024u);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(src) : "memory", "m0");
     }
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed ...
+  asm volatile("" ::: "memory");
+  __syncthreads();                      // ... and every other wave's
+
+  // (a) segment tasks: 48 bytes of the raw row -> 16 luma bytes in the tile (+ the level-0 store)
+  for (int task = (int)tid; task < rows * segs; task += 256) {
+    const int r = task / segs, sgm = task - r * segs;
+    const uint4* p = reinterpret_cast<const uint4*>(&raw[r * kDmaRowBytes + 16 + 48 * sgm]);
+    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+    uint32_t out[4];
+    luma16(wd, out);
+    const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;
+    const int y = y0 - 2 + r;
+    if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x0 + sgm * 16) = o4;
+  }
+  // (b) halo pixels: two columns on each side; at the frame's edge they mirror pixels of this tile (BORDER_REFLECT_101)
+  for (int task = (int)tid; task < rows * 4; task += 256) {
+    const int r = task >> 2, k = task & 3;
+    const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
+    const uint8_t* px = &raw[r * kDmaRowBytes + 16 + 3 * (reflect101(x, w) - x0)];
+    tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(px[0], px[1], px[2]);
+  }
+  __syncthreads();
+  next_level_from_tile<kTW, kTH, 1>(a, tile, x0, y0, w, h, y_plane);
 }
 
 #ifndef SVC_PLANE_RPT
@@ -370,7 +447,11 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
     if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many tiles for one launch");
     fa.total_tiles = (uint32_t)tt;
+#ifdef SVC_LUMA_DMA
+    hipLaunchKernelGGL(luma_pyr1_dma_kernel, dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+#else
     hipLaunchKernelGGL((luma_pyr1_kernel<true, kTWBgr, kTHBgr>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
+#endif
     if ((rc = check_launch("luma_pyr1_kernel"))) return rc;
     first_plain_level = 1;
   } else {

@@ -83,6 +83,10 @@ SIGNATURES = {
     "svc_hip_pyramid_levels_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp]),
     "svc_hip_dct_records_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _vp]),
     "svc_hip_wire_patch_types_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u64, C.c_int, _vp]),
+    "svc_hip_dct_quant_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u64, _vp]),
+    "svc_hip_dct_redo_workspace_bytes": (_u64, [_u32, _u32, _u32, _u32, _u32]),
+    "svc_hip_count_foreground": (C.c_int, [_vp, _u64, _vp, _vp]),
+    "svc_hip_dct_quant_redo_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _u64, _vp]),
     "svc_hip_hbma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32]),
     "svc_hip_ebma_host": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "svc_hip_ransac_host": (C.c_int, [_vp, _u32, RansacParams, _vp, _u32, _vp, _vp, _vp, _vp]),
@@ -405,6 +409,33 @@ def pyramid_levels_frames(pyr: torch.Tensor, stride: int, n: int, w: int, h: int
     """Levels 1 .. levels - 1 of `n` packed pyramids whose level-0 planes are in place (cv::buildPyramid, libs/encoder.cpp:470)."""
     _check(load().svc_hip_pyramid_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels, _stream()))
     return pyr
+
+
+def dct_quant_luma_frames(bgr: torch.Tensor, block: int, levels: int, bg_step: int = 640, planes: Optional[torch.Tensor] = None,
+                          pyr: Optional[torch.Tensor] = None, stride: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """ONE pass over bgr: coefficient planes with EVERY tile quantised as background AND level 0 of each frame's pyramid (then its other
+    levels).  -> (planes (frames, 3, H, W) f32, flat pyramid buffer, stride); dct_quant_redo_frames finishes the foreground tiles."""
+    n, h, w, _ = bgr.shape
+    if planes is None:
+        planes = torch.empty((n, 3, h, w), dtype=torch.float32, device=bgr.device)
+    stride = pyramid_stride(w, h, levels) if stride is None else stride
+    if pyr is None:
+        pyr = torch.empty(n * stride, dtype=torch.uint8, device=bgr.device)
+    _check(load().svc_hip_dct_quant_luma_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, bg_step, _dev(planes, torch.float32),
+                                                _dev(pyr, torch.uint8), stride, _stream()))
+    _check(load().svc_hip_pyramid_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels, _stream()))
+    return planes, pyr, stride
+
+
+def dct_quant_redo_frames(bgr: torch.Tensor, planes: torch.Tensor, block: int, block_types: torch.Tensor, mv_block: int = 16,
+                          fg_step: int = 1) -> torch.Tensor:
+    """The tiles of every foreground MV block (region id != 0) transformed again and quantised with fg_step, in place."""
+    n, h, w, _ = bgr.shape
+    nbytes = load().svc_hip_dct_redo_workspace_bytes(n, w, h, mv_block, mv_block)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=bgr.device)
+    _check(load().svc_hip_dct_quant_redo_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, _dev(block_types, torch.int32), mv_block,
+                                                mv_block, fg_step, _dev(planes, torch.float32), _dev(ws, torch.uint8), nbytes, _stream()))
+    return planes
 
 
 def wire_patch_types_frames(records: torch.Tensor, block_types: torch.Tensor, w: int, h: int, block: int, mv_block: int = 16,

@@ -72,8 +72,10 @@ def test_schedules_equal_stagewise_calls(native, schedule, steps):
     enc.sync()
     _assert_same(enc.outputs(), ref, enc.read("coeffs"))
     t = enc.stage_times_ms()
-    assert set(t) == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
-    assert all(ms > 0 and launches == steps for ms, launches in t.values())
+    # type_patch (the foreground tiles redone) shows on the steps that speculated: none before a foreground share has arrived (adaptive policy)
+    assert set(t) - {"type_patch"} == {"luma_pyramid", "hbma", "ransac", "segment", "dct_quant"}
+    assert all(ms > 0 and launches == steps for k, (ms, launches) in t.items() if k != "type_patch")
+    assert "type_patch" not in t or 0 < t["type_patch"][1] <= steps
     enc.close()
 
 
@@ -367,12 +369,15 @@ def test_eight_pixel_mv_blocks_on_a_frame_not_16_wide(native, oracle):
     enc.close()
 
 
+@pytest.mark.parametrize("wire", [True, False])
 @pytest.mark.parametrize("dct", [8, 16])
 @pytest.mark.parametrize("schedule,steps,rank", [(clipmod.SERIAL, 2, 0), (clipmod.PIPELINED, 1, 0), (clipmod.PIPELINED, 6, 0), (clipmod.PIPELINED, 7, 1)])
-def test_wire_one_bgr_pass_equals_two_passes(native, dct, schedule, steps, rank):
-    """Wire output reads the BGR clip once per step by default (records + luma plane from one kernel at the front of the step, type
-    words stored once the segmentation has the region ids); SVC_CLIP_TUNE_TWO_BGR_PASSES keeps the two-pass order.  Same bytes in every
-    buffer, on an unsharded clip (frame 0 tracked only: its pyramid comes from the plain luma kernel) and on a shard behind a halo."""
+def test_one_bgr_pass_equals_two_passes(native, wire, dct, schedule, steps, rank):
+    """Both output forms read the BGR clip once per step by default: the transform runs at the front of the step and leaves the luma
+    plane; what needs the region ids follows once the segmentation has them -- the type words of the records (wire), the foreground
+    tiles' quantisation (planes: every tile is quantised as background first, the tiles of foreground MV blocks are redone with fg_step).
+    SVC_CLIP_TUNE_TWO_BGR_PASSES keeps the two-pass order.  Same bytes in every buffer, on an unsharded clip (frame 0 tracked only: its
+    pyramid comes from the plain luma kernel) and on a shard behind a halo."""
     dev = torch.device("cuda")
     n = 9
     cfg = configs.CodecConfig("t-360p-3L", 41, 640, 360, n, levels=3, dct_block=dct)
@@ -387,10 +392,10 @@ def test_wire_one_bgr_pass_equals_two_passes(native, dct, schedule, steps, rank)
         whole.sync()
         halo_src = whole.read("pyramids", device=dev)
     got = {}
-    for name, tuning in (("two", clipmod.TUNE_TWO_BGR_PASSES), ("one", 0)):
+    for name, tuning in (("two", clipmod.TUNE_TWO_BGR_PASSES), ("one", 0 if wire else clipmod.TUNE_ALWAYS_SPECULATE)):
         # a tight inlier threshold: the moving rectangles become foreground regions (at 7.5 px this clip has none, and the type words would
         # all stay 0)
-        enc = clipmod.Clip(cfg, n, rank=rank, world=world, schedule=schedule, wire=True, tuning=tuning, ransac=dict(inlier_thresh=1.5))
+        enc = clipmod.Clip(cfg, n, rank=rank, world=world, schedule=schedule, wire=wire, tuning=tuning, ransac=dict(inlier_thresh=1.5))
         enc.load_frames(frames[first:first + cnt].contiguous())
         if rank:
             stride = enc.info.pyramid_stride
@@ -398,7 +403,7 @@ def test_wire_one_bgr_pass_equals_two_passes(native, dct, schedule, steps, rank)
         for _ in range(steps):
             enc.step(timed=True)
         enc.sync()
-        got[name] = (enc.outputs(), enc.read("records"), enc.read("pyramids"), enc.stage_times_ms())
+        got[name] = (enc.outputs(), enc.read("records" if wire else "coeffs"), enc.read("pyramids"), enc.stage_times_ms())
         enc.close()
     for k in got["two"][0]:
         assert torch.equal(got["one"][0][k], got["two"][0][k]), k
@@ -433,3 +438,37 @@ def test_wire_one_bgr_pass_record_sets_never_serve_stale_steps(native):
                 enc.step()
             assert torch.equal(enc.read("records"), want[name]), (lat_depth, burst)
         enc.close()
+
+
+def test_speculation_follows_the_foreground_share(native):
+    """Planes + quant: a step speculates (transform at the front, every tile as background, foreground tiles redone) only if the newest
+    foreground share that has ARRIVED is at most 2 % (none has before the first steps are through) and the shard is big enough to pay
+    (50 M pixels x frames).  A clip without foreground switches over once its first measurement is in; a clip with a fifth of its blocks
+    foreground never does; a small shard never does; the bytes never depend on it."""
+    dev = torch.device("cuda")
+    big = configs.CodecConfig("t-1080p-3L", 43, 1920, 1080, 26, levels=3, dct_block=8)  # 25 encoded frames x 1920 x 1088 = 52 M
+    outs = {}
+    for name, cfg, ransac, tuning in (("calm", big, None, 0), ("calm_plain", big, None, clipmod.TUNE_TWO_BGR_PASSES),
+                                      ("busy", big, dict(inlier_thresh=0.01), 0), ("busy_always", big, dict(inlier_thresh=0.01), clipmod.TUNE_ALWAYS_SPECULATE),
+                                      ("small", CFG, None, 0)):
+        n = cfg.frames if cfg is big else 7
+        frames = _frames(cfg, n, dev)
+        enc = clipmod.Clip(cfg, n, ransac=ransac, tuning=tuning)
+        enc.load_frames(frames)
+        for _ in range(3):
+            for _ in range(5):
+                enc.step(timed=True)
+            enc.sync()  # every measurement enqueued so far has arrived
+        t = enc.stage_times_ms()
+        outs[name] = (enc.outputs(), enc.read("coeffs"), t.get("type_patch", (0.0, 0))[1], t["dct_quant"][1])
+        enc.close()
+        del frames
+    share = lambda o: float((o[0]["block_types"] != 0).float().mean())  # noqa: E731
+    assert share(outs["calm"]) <= 0.02 < 0.1 < share(outs["busy"]) and share(outs["small"]) <= 0.02
+    assert outs["calm"][3] == outs["busy"][3] == outs["small"][3] == 15
+    assert outs["calm"][2] >= 9 and outs["calm_plain"][2] == 0  # the steps after the first sync speculated
+    assert outs["busy"][2] == 0 and outs["busy_always"][2] == 15 and outs["small"][2] == 0
+    for a, b in (("calm", "calm_plain"), ("busy", "busy_always")):
+        for k in outs[a][0]:
+            assert torch.equal(outs[a][0][k], outs[b][0][k]), (a, k)
+        assert torch.equal(outs[a][1], outs[b][1]), a

@@ -196,3 +196,39 @@ def test_random_transform_shapes(native, oracle):
         fg, bg = int(rng.choice([1, 2, 5])), int(rng.choice([16, 640]))
         exp = oracle.quant_frame(got, mvw, mvh, types, fg, bg)
         assert native.dct_quant_host(bgr, (bw, bh), types, (mvw, mvh), fg, bg).tobytes() == exp.tobytes(), (bw, bh, w, h, mvw, mvh)
+
+
+@pytest.mark.parametrize("block,w,h,levels,mvb", [(8, 160, 96, 3, 16), (16, 160, 96, 3, 16), (8, 1920, 64, 2, 16), (16, 352, 288, 4, 16), (8, 256, 128, 3, 32),
+                                                   (16, 256, 128, 2, 32)])
+@pytest.mark.parametrize("fg_share", [0.0, 0.03, 0.5, 1.0])
+def test_speculative_quant_plus_redo_equals_dct_quant(native, block, w, h, levels, mvb, fg_share):
+    """One pass over the BGR bytes (every tile quantised as background + the luma plane) followed by the redo of the foreground MV
+    blocks' tiles leaves exactly the planes of svc_hip_dct_quant_frames with the region ids up front (libs/encoder.cpp:323-339,
+    libs/decoder.cpp:130-144) and the pyramid of svc_hip_luma_pyramid_frames -- for no, few, many and only foreground blocks."""
+    rng = np.random.default_rng(block + w + int(fg_share * 100))
+    n = 3
+    bgr = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+    mfw, mfh = w // mvb, h // mvb
+    ids = rng.integers(1, 40, (n, mfw * mfh)) * (rng.random((n, mfw * mfh)) < fg_share)
+    types = torch.from_numpy(ids.astype(np.int32)).cuda()
+    for fg, bg in ((1, 640), (3, 17)):
+        want = native.dct_quant_frames(bgr, block, types, mvb, fg, bg)
+        want_pyr, stride = native.luma_pyramid_frames(bgr, levels)
+        planes, pyr, stride2 = native.dct_quant_luma_frames(bgr, block, levels, bg_step=bg)
+        torch.cuda.synchronize()
+        assert torch.equal(planes, native.dct_quant_frames(bgr, block, torch.zeros_like(types), mvb, fg, bg))  # all background so far
+        used = sum((w >> l) * (h >> l) for l in range(levels))
+        for f in range(n):
+            assert torch.equal(pyr[f * stride:f * stride + used], want_pyr[f * stride:f * stride + used]), f
+        native.dct_quant_redo_frames(bgr, planes, block, types, mvb, fg_step=fg)
+        torch.cuda.synchronize()
+        assert torch.equal(planes, want), (fg, bg)
+
+
+def test_speculative_quant_refuses_what_it_does_not_cover(native):
+    bgr = torch.zeros((1, 64, 160, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="speculative form"):
+        native.dct_quant_luma_frames(bgr, 4, 1)
+    planes = torch.zeros((1, 3, 64, 160), dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError, match="whole"):
+        native.dct_quant_redo_frames(bgr, planes, 8, torch.zeros((1, 160), dtype=torch.int32, device="cuda"), mv_block=8)
