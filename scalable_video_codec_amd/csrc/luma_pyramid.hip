@@ -307,75 +307,6 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
   next_level_from_tile<TW, TH, RPT>(a, tile, x0, y0, w, h, y_plane);
 }
 
-// ---- the BGR pass with its rows brought in by LDS-DMA ------------------------------------------------------------------------
-// Same tile, same arithmetic, same bytes as luma_pyr1_kernel<true, 128, 32>; what changes is how the B,G,R bytes arrive: every 16-byte chunk of
-// the tile's 36 rows (24 chunks of pixels + one chunk on each side that holds the two halo pixels: 936 chunks) is fetched by
-// global_load_lds_dwordx4 -- no register holds a load result, a lane issues its three or four chunk loads back to back, and the workgroup
-// waits ONCE (the register form waits three times in a row: first round of segment tasks, the 32 lanes of the second round, halo pixels).
-// Y is then computed LDS -> LDS.  
-constexpr int kDmaCPR = kTWBgr * 3 / 16 + 2, kDmaRows = kTHBgr + 4, kDmaChunks = kDmaCPR * kDmaRows;
-constexpr int kDmaRounds = (kDmaChunks + 255) / 256, kDmaBytes = (kDmaChunks + 63) / 64 * 1024, kDmaRowBytes = kDmaCPR * 16;
-
-__global__ __launch_bounds__(256) void luma_pyr1_dma_kernel(LumaPyr1Args a) {
-  constexpr int kTW = kTWBgr, kTH = kTHBgr, kPitch = kTW + 2 * kOff;
-  __shared__ __attribute__((aligned(16))) uint8_t raw[kDmaBytes];
-  __shared__ __attribute__((aligned(16))) uint8_t tile[(kTH + 4) * kPitch];
-  const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  if (t >= a.total_tiles) return;  // workgroup-uniform
-  const uint32_t tid = threadIdx.x, wave = tid >> 6;
-  const uint32_t frame = t / a.tiles_per_frame, tr = t - frame * a.tiles_per_frame;
-  const uint32_t ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-  const int x0 = (int)tx * kTW, y0 = (int)ty * kTH, w = (int)a.w, h = (int)a.h;
-  const int segs = min(kTW, w - x0) / 16, xe = x0 + segs * 16;
-  const uint8_t* src = a.bgr + (size_t)frame * a.frame_stride;  // uniform over the workgroup: the DMA's scalar base
-  uint8_t* y_plane = a.pyr + (size_t)frame * a.pyr_stride;
-  const int rows = min(kTH + 4, h - y0 + 3);
-
-  // chunk i of the raw tile (row-major, kDmaCPR chunks per row) is fetched by lane i % 64 of the wave instruction that covers chunks
-  // [i & ~63, + 64): LDS-DMA writes a wave's 64 x 16 bytes contiguously from the wave-uniform LDS address in M0.  A chunk the tile does
-  // not need (a row past the plane, the side chunk of a tile at the frame's edge) comes from a clamped, valid address and is never read.
-  const uint32_t raw0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)raw;
-#pragma unroll
-  for (int r = 0; r < kDmaRounds; ++r) {
-    const uint32_t slice = (uint32_t)r * 4u + wave;
-    if (slice * 64u < (uint32_t)kDmaChunks) {  // wave-uniform
-      const int i = min((int)(slice * 64u + (tid & 63u)), kDmaChunks - 1);
-      const int row = i / kDmaCPR, c = i - row * kDmaCPR;
-      const int y = reflect101(min(y0 - 2 + row, h), h);
-      const int xb = min(max(3 * x0 - 16 + 16 * c, 0), 3 * w - 16);
-      const uint32_t voff = (uint32_t)y * (uint32_t)(3 * w) + (uint32_t)xb;
-      const uint32_t m0v = __builtin_amdgcn_readfirstlane(raw0 + slice * 1024u);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(src) : "memory", "m0");
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed ...
-  asm volatile("" ::: "memory");
-  __syncthreads();                      // ... and every other wave's
-
-  // (a) segment tasks: 48 bytes of the raw row -> 16 luma bytes in the tile (+ the level-0 store)
-  for (int task = (int)tid; task < rows * segs; task += 256) {
-    const int r = task / segs, sgm = task - r * segs;
-    const uint4* p = reinterpret_cast<const uint4*>(&raw[r * kDmaRowBytes + 16 + 48 * sgm]);
-    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-    const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-    uint32_t out[4];
-    luma16(wd, out);
-    const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;
-    const int y = y0 - 2 + r;
-    if (r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x0 + sgm * 16) = o4;
-  }
-  // (b) halo pixels: two columns on each side; at the frame's edge they mirror pixels of this tile (BORDER_REFLECT_101)
-  for (int task = (int)tid; task < rows * 4; task += 256) {
-    const int r = task >> 2, k = task & 3;
-    const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
-    const uint8_t* px = &raw[r * kDmaRowBytes + 16 + 3 * (reflect101(x, w) - x0)];
-    tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(px[0], px[1], px[2]);
-  }
-  __syncthreads();
-  next_level_from_tile<kTW, kTH, 1>(a, tile, x0, y0, w, h, y_plane);
-}
-
 #ifndef SVC_PLANE_RPT
 #define SVC_PLANE_RPT 2
 #endif
@@ -447,11 +378,9 @@ int launch_luma_pyramid(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_
     const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
     if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "luma: too many tiles for one launch");
     fa.total_tiles = (uint32_t)tt;
-#ifdef SVC_LUMA_DMA
-    hipLaunchKernelGGL(luma_pyr1_dma_kernel, dim3(fa.total_tiles), dim3(256), 0, stream, fa);
-#else
+    // (the same tile with its B,G,R rows brought in by LDS-DMA -- one wait per workgroup instead of three -- measured level: serial 0.551-0.558
+    // against 0.557-0.565 ms, pipelined 0.590-0.600 against 0.575-0.582 at C3, level at C5; profiles/r05_ab_luma_dma.txt; removed)
     hipLaunchKernelGGL((luma_pyr1_kernel<true, kTWBgr, kTHBgr>), dim3(fa.total_tiles), dim3(256), 0, stream, fa);
-#endif
     if ((rc = check_launch("luma_pyr1_kernel"))) return rc;
     first_plain_level = 1;
   } else {
