@@ -248,6 +248,28 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
   // row h) and must not be touched: reflect101 folds once, so a row further out would index
   // outside the frame (short frames: found by tests/test_gpu_misc_property.py).
   const int rows = min(kTH + 4, h - y0 + 3);  // LDS rows 0 .. rows-1 <-> y = y0 - 2 .. min(y0 + 33, h)
+  if constexpr (!FROM_BGR) {
+    // plane to plane: a lane's four or five segment loads AND its halo bytes are all issued before the first is waited for -- no branch
+    // (clamped addresses; idle tasks store into 16 spare bytes behind the tile): as a loop of load -> LDS store rounds this pass paid the
+    // memory latency once per round, 4.5 round trips per tile (profiles/r05_ab_pyr2.txt)
+    constexpr int kSegsMax = kTW / 16, kRounds = ((kTH + 4) * kSegsMax + 255) / 256, kSpare = (kTH + 4) * kPitch;
+    uint4 v[kRounds];
+    int at[kRounds];
+#pragma unroll
+    for (int it = 0; it < kRounds; ++it) {
+      const int task = (int)tid + 256 * it, r = task / kSegsMax, sgm = task - r * kSegsMax;
+      const bool ok = r < rows && sgm < segs;
+      at[it] = ok ? r * kPitch + kOff + sgm * 16 : kSpare;
+      v[it] = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(min(y0 - 2 + r, h), h) * w + min(x0 + sgm * 16, w - 16));
+    }
+    static_assert((kTH + 4) * 4 <= 256, "one round of halo tasks");
+    const int hr = (int)tid >> 2, hk = (int)tid & 3, hx = hk < 2 ? x0 - 2 + hk : xe + (hk - 2);
+    const int hat = hr < rows ? hr * kPitch + kOff + (hx - x0) : kSpare;
+    const uint8_t hv = src[(size_t)reflect101(min(y0 - 2 + hr, h), h) * w + reflect101(hx, w)];
+#pragma unroll
+    for (int it = 0; it < kRounds; ++it) *reinterpret_cast<uint4*>(&tile[at[it]]) = v[it];
+    tile[hat] = hv;
+  } else {
   // (a) segment tasks: 16 pixels of one row -> 4 dwords of LDS (+ the level-0 store)
   for (int task = (int)tid; task < rows * segs; task += 256) {
     const int r = task / segs, sgm = task - r * segs;
@@ -279,95 +301,10 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
       tile[r * kPitch + kOff + (x - x0)] = src[(size_t)yr * w + reflect101(x, w)];
     }
   }
+  }  // FROM_BGR
   __syncthreads();
 
   next_level_from_tile<TW, TH, RPT>(a, tile, x0, y0, w, h, y_plane);
-}
-
-// ---- plane to plane (level l -> l + 1), the tiles of a fixed grid's workgroup SOFTWARE-PIPELINED -------------------------------------
-// A workgroup walks the tiles of its XCD's share (launch_pyr_down_levels).  What a tile needs from memory -- (TH + 4) rows of TW / 16
-// aligned 16-byte segments and four halo bytes per row -- is held in REGISTERS between its loads and its LDS stores: the loads of tile
-// k + 1 are issued before tile k is reduced from LDS, so a workgroup's memory round trip runs beside its own arithmetic instead of in
-// front of it.  Every load is unconditional from a clamped (always valid) address and an idle task stores into 16 spare bytes behind
-// the tile: a load or store under a divergent condition is sunk to its use by the compiler and waited for there, one by one (that is how
-// this pass first ran: 4.5 round trips per tile).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// Tile t's place (TilePlace) is recomputed where it is needed; what is carried from the loads to the LDS stores is only the data.
-struct TilePlace { int x0, y0, segs, xe, rows; uint32_t frame; };
-template <int TW, int TH>
-__device__ __forceinline__ TilePlace plane_tile_place(const LumaPyr1Args& a, uint32_t t) {
-  TilePlace p;
-  p.frame = t / a.tiles_per_frame;
-  const uint32_t tr = t - p.frame * a.tiles_per_frame, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-  p.x0 = (int)tx * TW; p.y0 = (int)ty * TH;
-  p.segs = min(TW, (int)a.w - p.x0) / 16; p.xe = p.x0 + p.segs * 16;
-  p.rows = min(TH + 4, (int)a.h - p.y0 + 3);  // rows past y = h are never needed and must not be mirrored twice (short planes)
-  return p;
-}
-
-template <int TW, int TH, int N>
-__device__ __forceinline__ void plane_tile_load(const LumaPyr1Args& a, const TilePlace& p, u32x4 (&v)[N], uint32_t& hv) {
-  constexpr int kSegsMax = TW / 16;
-  const uint32_t tid = threadIdx.x;
-  const int w = (int)a.w, h = (int)a.h;
-  const uint8_t* src = a.pyr + (size_t)p.frame * a.pyr_stride + a.src_off;
-#pragma unroll
-  for (int it = 0; it < N; ++it) {
-    const int task = (int)tid + 256 * it, r = task / kSegsMax, sgm = task - r * kSegsMax;
-    v[it] = *reinterpret_cast<const u32x4*>(src + (size_t)reflect101(min(p.y0 - 2 + r, h), h) * w + min(p.x0 + sgm * 16, w - 16));
-  }
-  const int hr = (int)tid >> 2, hk = (int)tid & 3, hx = hk < 2 ? p.x0 - 2 + hk : p.xe + (hk - 2);
-  hv = src[(size_t)reflect101(min(p.y0 - 2 + hr, h), h) * w + reflect101(hx, w)];
-}
-
-template <int TW, int TH, int N>
-__device__ __forceinline__ void plane_tile_to_lds(const TilePlace& p, const u32x4 (&v)[N], uint32_t hv, uint8_t* tile) {
-  constexpr int kPitch = TW + 2 * kOff, kSegsMax = TW / 16, kSpare = (TH + 4) * kPitch;
-  const uint32_t tid = threadIdx.x;
-#pragma unroll
-  for (int it = 0; it < N; ++it) {
-    const int task = (int)tid + 256 * it, r = task / kSegsMax, sgm = task - r * kSegsMax;
-    *reinterpret_cast<u32x4*>(&tile[(r < p.rows && sgm < p.segs) ? r * kPitch + kOff + sgm * 16 : kSpare]) = v[it];
-  }
-  static_assert((TH + 4) * 4 <= 256, "one round of halo tasks");
-  const int hr = (int)tid >> 2, hk = (int)tid & 3, hx = hk < 2 ? p.x0 - 2 + hk : p.xe + (hk - 2);
-  tile[hr < p.rows ? hr * kPitch + kOff + (hx - p.x0) : kSpare] = (uint8_t)hv;  // (a halo byte never lies in a segment that was brought in)
-}
-
-// A workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also releases the wave's global
-// stores -- and, vmcnt retiring in order, waits for every global load issued before them: the prefetch of the next tile would be waited for
-// at the end of each round.  The two barriers of a round only guard the tile buffer.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int TW, int TH, int RPT>
-__global__ __launch_bounds__(256) void pyr_plane_kernel(LumaPyr1Args a) {
-  constexpr int kPitch = TW + 2 * kOff, kRounds = ((TH + 4) * (TW / 16) + 255) / 256;
-  __shared__ __attribute__((aligned(16))) uint8_t tile[(TH + 4) * kPitch + 16];
-  // XCD x (workgroups x, x + 8, ...) walks the x-th eighth of the tiles, its workgroups interleaved: neighbouring tiles at the same time
-  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const uint32_t share = (a.total_tiles + 7u) / 8u, t0 = xcd * share, t1 = min(a.total_tiles, t0 + share);
-  if (t0 + k >= t1) return;  // workgroup-uniform
-  // two register sets, the loop unrolled by two: with one set the compiler copies the freshly loaded registers into the loop-carried ones
-  // right behind the loads -- and waits for them there
-  u32x4 va[kRounds], vb[kRounds];
-  uint32_t ha, hb;
-  plane_tile_load<TW, TH>(a, plane_tile_place<TW, TH>(a, t0 + k), va, ha);
-#define SVC_PLANE_ROUND(VC, HC, VN, HN, T)                                                                                             \
-  {                                                                                                                                    \
-    const TilePlace cur = plane_tile_place<TW, TH>(a, (T));                                                                            \
-    plane_tile_to_lds<TW, TH>(cur, VC, HC, tile);                                                                                      \
-    lds_barrier();                                                                                                                     \
-    /* the next tile's loads go out now and land while this one is reduced (the walk's last tile is fetched once more: no branch) */   \
-    plane_tile_load<TW, TH>(a, plane_tile_place<TW, TH>(a, min((T) + per, t1 - 1)), VN, HN);                                           \
-    next_level_from_tile<TW, TH, RPT>(a, tile, cur.x0, cur.y0, (int)a.w, (int)a.h, a.pyr + (size_t)cur.frame * a.pyr_stride);          \
-    lds_barrier(); /* the tile buffer is rewritten by the next round */                                                               \
-  }
-  for (uint32_t t = t0 + k; t < t1; t += 2 * per) {
-    SVC_PLANE_ROUND(va, ha, vb, hb, t)
-    if (t + per >= t1) break;  // workgroup-uniform
-    SVC_PLANE_ROUND(vb, hb, va, ha, t + per)
-  }
-#undef SVC_PLANE_ROUND
 }
 
 #ifndef SVC_PLANE_RPT
@@ -375,11 +312,21 @@ __global__ __launch_bounds__(256) void pyr_plane_kernel(LumaPyr1Args a) {
 #endif
 // One tile per workgroup (the BGR pass: 76 500 workgroups at C3), or -- PERSIST, the plane-to-plane pass, whose tiles take 1 - 2 us
 // each -- a fixed grid whose workgroups walk the tiles of their XCD's share: see launch_pyr_down_levels.
-template <bool FROM_BGR, int TW, int TH>
+template <bool FROM_BGR, int TW, int TH, bool PERSIST = false>
 __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[(TH + 4) * (TW + 2 * kOff)];
-  const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  if (t < a.total_tiles) luma_pyr1_tile<FROM_BGR, TW, TH>(a, t, tile);
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(TH + 4) * (TW + 2 * kOff) + 16];  // + 16 spare bytes (idle load tasks of the plane pass)
+  if (!PERSIST) {
+    const uint32_t t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if (t < a.total_tiles) luma_pyr1_tile<FROM_BGR, TW, TH>(a, t, tile);
+  } else {
+    // XCD x (workgroups x, x + 8, ...) walks the x-th eighth of the tiles, its workgroups interleaved: neighbouring tiles at the same time
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const uint32_t share = (a.total_tiles + 7u) / 8u, t0 = xcd * share, t1 = min(a.total_tiles, t0 + share);
+    for (uint32_t t = t0 + k; t < t1; t += per) {
+      luma_pyr1_tile<FROM_BGR, TW, TH, SVC_PLANE_RPT>(a, t, tile);
+      __syncthreads();  // the tile buffer is rewritten by the next round
+    }
+  }
 }
 // any frame width: one pixel per lane
 __global__ __launch_bounds__(256) void luma_any_kernel(const uint8_t* bgr, uint64_t frame_stride, uint8_t* pyr, uint64_t pyr_stride,
@@ -479,13 +426,10 @@ int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frame
       {
         // a fixed grid whose workgroups walk the tiles: 0.062 -> 0.054 ms per launch at C3 (profiles/r04_ab_pyr_persist.txt; 1024 workgroups
         // are too few, 2048 and 4096 level).  A double-buffered LDS-DMA form of the same walk measured no better (r04_ab_pyr_stream.txt).
-#ifndef SVC_PLANE_GRID
-#define SVC_PLANE_GRID 1536  // 78 VGPRs: six workgroups per CU are resident, and a fixed grid should not outnumber them
-#endif
-        const uint32_t grid = std::min<uint32_t>((fa.total_tiles + 7u) / 8u * 8u, (uint32_t)SVC_PLANE_GRID);
-        hipLaunchKernelGGL((pyr_plane_kernel<kTWPlane, kTHPlane, SVC_PLANE_RPT>), dim3(grid), dim3(256), 0, stream, fa);
+        const uint32_t grid = std::min<uint32_t>((fa.total_tiles + 7u) / 8u * 8u, 2048u);
+        hipLaunchKernelGGL((luma_pyr1_kernel<false, kTWPlane, kTHPlane, true>), dim3(grid), dim3(256), 0, stream, fa);
       }
-      if ((rc = check_launch("pyr_plane_kernel"))) return rc;
+      if ((rc = check_launch("luma_pyr1_kernel<false>"))) return rc;
       continue;
     }
     if (pa.dw < 1 || pa.dh < 1 || pa.sw < 3 || pa.sh < 3)  // reflect-101 folds once: a source side below 3 cannot be mirrored
