@@ -447,13 +447,15 @@ def test_speculation_follows_the_foreground_share(native):
     foreground never does; a small shard never does; the bytes never depend on it."""
     dev = torch.device("cuda")
     big = configs.CodecConfig("t-1080p-3L", 43, 1920, 1080, 26, levels=3, dct_block=8)  # 25 encoded frames x 1920 x 1088 = 52 M
+    other = configs.CodecConfig("t-1080p-3L-other", 44, 1920, 1080, 26, levels=3, dct_block=8)
+    calm = _frames(big, big.frames, dev)
+    busy = calm.clone()
+    busy[1::2] = _frames(other, big.frames, dev)[1::2]  # every second frame from another scene: a clip of scene cuts
+    small = _frames(CFG, 7, dev)
     outs = {}
-    for name, cfg, ransac, tuning in (("calm", big, None, 0), ("calm_plain", big, None, clipmod.TUNE_TWO_BGR_PASSES),
-                                      ("busy", big, dict(inlier_thresh=0.01), 0), ("busy_always", big, dict(inlier_thresh=0.01), clipmod.TUNE_ALWAYS_SPECULATE),
-                                      ("small", CFG, None, 0)):
-        n = cfg.frames if cfg is big else 7
-        frames = _frames(cfg, n, dev)
-        enc = clipmod.Clip(cfg, n, ransac=ransac, tuning=tuning)
+    for name, cfg, frames, tuning in (("calm", big, calm, 0), ("calm_plain", big, calm, clipmod.TUNE_TWO_BGR_PASSES), ("busy", big, busy, 0),
+                                      ("busy_always", big, busy, clipmod.TUNE_ALWAYS_SPECULATE), ("small", CFG, small, 0)):
+        enc = clipmod.Clip(cfg, frames.shape[0], tuning=tuning)
         enc.load_frames(frames)
         for _ in range(3):
             for _ in range(5):
@@ -462,7 +464,6 @@ def test_speculation_follows_the_foreground_share(native):
         t = enc.stage_times_ms()
         outs[name] = (enc.outputs(), enc.read("coeffs"), t.get("type_patch", (0.0, 0))[1], t["dct_quant"][1])
         enc.close()
-        del frames
     share = lambda o: float((o[0]["block_types"] != 0).float().mean())  # noqa: E731
     assert share(outs["calm"]) <= 0.02 < 0.1 < share(outs["busy"]) and share(outs["small"]) <= 0.02
     assert outs["calm"][3] == outs["busy"][3] == outs["small"][3] == 15

@@ -51,7 +51,16 @@ path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 db = json.load(open(path))
 rec = db.setdefault(a.config, {})
 on = rec.setdefault("collected_on", {"kernels": {}, "source_sha16": {}})
-dct = pick(lambda k: "dct_kernel" in k)
+def pick_dct():
+    """The step's big transform launch: not the redo of the foreground tiles (SPEC = 2: the last template argument), the one that moves
+    the most bytes (a speculating step has both; so has a run that switched order half-way)."""
+    ks = [k for k in rows if "dct_kernel" in k and not k.rstrip(">").rstrip().endswith(", 2")]
+    if not ks:
+        sys.exit("no dct_kernel in the summary")
+    return max(ks, key=hbm_bytes)
+
+
+dct = pick_dct()
 if a.wire:
     rec["dct_records_bytes_per_launch"] = hbm_bytes(dct)
     rec["dct_records_note"] = f"bench.py --wire, {dct} ({src})"
@@ -59,12 +68,18 @@ if a.wire:
         sys.exit("the plane-form figure of this config was collected on other dct sources: re-collect it first")
 else:
     hb = pick(lambda k: "hbma_" in k)
-    lu = pick(lambda k: "luma_pyr1_kernel<true" in k)
+    lus = [k for k in rows if "luma_pyr1_kernel<true" in k]
     rec.update({"source": src, "pairs": a.pairs, "hbma_bytes_per_launch": hbm_bytes(hb), "dct_bytes_per_launch": hbm_bytes(dct),
-                "luma_pyr1_bytes_per_launch": hbm_bytes(lu), "hbma_note": f"{hb}; L2 memory-side request counters by size"})
+                "hbma_note": f"{hb}; L2 memory-side request counters by size", "dct_note": dct})
+    # a step that reads the BGR clip once runs the BGR luma kernel on the clip's first frame only: its figure is not a clip's
+    rec.pop("luma_pyr1_bytes_per_launch", None)
+    if lus and not any(", true, 1>" in k for k in rows if "dct_kernel" in k):
+        rec["luma_pyr1_bytes_per_launch"] = hbm_bytes(lus[0])
     rec.pop("dct_records_bytes_per_launch", None)  # tied to the dct sources of an older collection
     rec.pop("dct_records_note", None)
-    on["kernels"] = {"hbma": [hb], "dct": [dct], "luma_pyr1": [lu]}
+    for k in ("round3", "hbma_bytes_per_launch_pair_major_order"):
+        rec.pop(k, None)
+    on["kernels"] = {"hbma": [hb], "dct": [dct], **({"luma_pyr1": lus[:1]} if lus else {})}
     on["source_sha16"] = dict(meta["source_sha16"])
     on["collected_utc"] = meta["collected_utc"]
 json.dump(db, open(path, "w"), indent=1)
