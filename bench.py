@@ -229,7 +229,9 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
         except Exception as e:  # noqa: BLE001
             out["stream_encoder_fps"] = None
             out["stream_encoder_note"] = f"not measured: {e}"
-        # (c) the reference's own application
+        # (c) the reference's own application.  Both application rows run with SVC_KEEP_LARGE_BLOCKS=1: the opt-in by which a host process
+        # asks these libraries to keep frame-sized blocks on the heap (nothing is tuned unasked)
+        tuned_env = dict(os.environ, SVC_KEEP_LARGE_BLOCKS="1")
         sse2 = cfg.levels == 4 and cfg.mv_block == 16
         exe = os.path.join(bin_dir, "ref_encoder_sse2" if sse2 else "ref_encoder_generic")
         try:
@@ -247,7 +249,7 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
                         src[:min(len(src), n - lo)].tofile(f)
                 t0 = time.perf_counter()
                 with open(os.devnull, "wb") as sink:
-                    r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600)
+                    r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600, env=tuned_env)
                 times[n] = time.perf_counter() - t0
                 os.remove(path)
                 if r.returncode != 0:
@@ -257,7 +259,7 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
                 raise RuntimeError(f"{n2 - n1} more frames took {t2 - t1:.3f} s more: too short to tell")
             out["reference_application_fps"] = (n2 - n1) / (t2 - t1)
             out["reference_application_sample"] = (f"{os.path.basename(exe)} {' '.join(args)}: {n1} and {n2} frame clips, stdout to /dev/null; "
-                                                   f"({n2} - {n1}) frames / ({t2:.2f} - {t1:.2f}) s, so process start-up and GPU initialisation cancel")
+                                                   f"({n2} - {n1}) frames / ({t2:.2f} - {t1:.2f}) s, so process start-up and GPU initialisation cancel; SVC_KEEP_LARGE_BLOCKS=1")
         except Exception as e:  # noqa: BLE001
             out["reference_application_fps"] = None
             out["reference_application_note"] = f"not measured: {e}"
@@ -277,7 +279,7 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
                     src[:min(len(src), n - lo)].tofile(f)
             t0 = time.perf_counter()
             with open(os.devnull, "wb") as sink:  # SVC_ENCODER_REPORT: this repo's Encoder prints its loop's own clock (set-up apart)
-                r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, SVC_ENCODER_REPORT="1"))
+                r = subprocess.run([exe, *args, path], stdout=sink, stderr=subprocess.PIPE, timeout=600, env=dict(tuned_env, SVC_ENCODER_REPORT="1"))
             wall = time.perf_counter() - t0
             os.remove(path)
             if r.returncode != 0:
@@ -286,7 +288,7 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
             out["reference_application_batched_encoder_fps"] = float(line.split("(")[1].split(" frames/s")[0])
             out["reference_application_batched_encoder_sample"] = (
                 f"{os.path.basename(exe)} (the reference's unchanged apps/encoder.cpp + libs/cli.cpp, class Encoder = csrc/host/encoder_hip.cpp on "
-                f"svc::StreamEncoder), a {n}-frame clip (the sample frames repeated), stdout to /dev/null: '{line}'; whole process {wall:.2f} s")
+                f"svc::StreamEncoder), a {n}-frame clip (the sample frames repeated), stdout to /dev/null, SVC_KEEP_LARGE_BLOCKS=1: '{line}'; whole process {wall:.2f} s")
         except Exception as e:  # noqa: BLE001
             out["reference_application_batched_encoder_fps"] = None
             out["reference_application_batched_encoder_note"] = f"not measured: {e}"
