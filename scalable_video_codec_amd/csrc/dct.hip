@@ -626,13 +626,18 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
 
 // How many MV blocks of a batch are foreground (region id != 0): the feedback the driver's speculation policy runs on.
 __global__ __launch_bounds__(256) void fg_count_kernel(const uint32_t* types, uint32_t total_blocks, uint32_t* count) {
+  __shared__ uint32_t part[4];
   uint32_t n = 0;
   for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total_blocks; g += gridDim.x * 256u) n += types[g] != 0 ? 1u : 0u;
-  const uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
-  if (m == 0) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
-  if ((threadIdx.x & 63u) == 0) atomicAdd(count, n);
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  // one atomic per workgroup with anything to add (a few hundred per launch: 38 k same-address atomics, one per wave, took 50 us at C3b)
+  if (threadIdx.x == 0) {
+    const uint32_t s = part[0] + part[1] + part[2] + part[3];
+    if (s) atomicAdd(count, s);
+  }
 }
 
 int launch_count_foreground(const uint32_t* d_types, uint64_t n, uint32_t* d_count, hipStream_t stream) {
@@ -640,7 +645,7 @@ int launch_count_foreground(const uint32_t* d_types, uint64_t n, uint32_t* d_cou
   if (e != hipSuccess) return fail(SVC_ERR_HIP, "count_foreground: hipMemsetAsync: %s", hipGetErrorString(e));
   if (n == 0) return SVC_OK;
   if (n > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "count_foreground: too many MV blocks for one launch");
-  hipLaunchKernelGGL(fg_count_kernel, dim3(std::min<uint32_t>(div_up((uint32_t)n, 256), 1024u)), dim3(256), 0, stream, d_types, (uint32_t)n, d_count);
+  hipLaunchKernelGGL(fg_count_kernel, dim3(std::min<uint32_t>(div_up((uint32_t)n, 1024), 512u)), dim3(256), 0, stream, d_types, (uint32_t)n, d_count);
   return check_launch("fg_count_kernel");
 }
 

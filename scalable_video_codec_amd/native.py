@@ -438,6 +438,14 @@ def dct_quant_redo_frames(bgr: torch.Tensor, planes: torch.Tensor, block: int, b
     return planes
 
 
+def count_foreground(block_types: torch.Tensor) -> int:
+    """How many of the region ids are not 0."""
+    out = torch.zeros(1, dtype=torch.int32, device=block_types.device)
+    _check(load().svc_hip_count_foreground(_dev(block_types, torch.int32) if block_types.numel() else None, block_types.numel(),
+                                           _dev(out, torch.int32), _stream()))
+    return int(out.item())
+
+
 def wire_patch_types_frames(records: torch.Tensor, block_types: torch.Tensor, w: int, h: int, block: int, mv_block: int = 16,
                             emit_h: Optional[int] = None, all_tiles: bool = False) -> torch.Tensor:
     """Stores the region id of every foreground MV block into the type words of its tiles' records (in place)."""

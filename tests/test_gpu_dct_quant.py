@@ -232,3 +232,13 @@ def test_speculative_quant_refuses_what_it_does_not_cover(native):
     planes = torch.zeros((1, 3, 64, 160), dtype=torch.float32, device="cuda")
     with pytest.raises(RuntimeError, match="whole"):
         native.dct_quant_redo_frames(bgr, planes, 8, torch.zeros((1, 160), dtype=torch.int32, device="cuda"), mv_block=8)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 1000, 8160 * 7, 2439840])
+def test_count_foreground(native, n):
+    """svc_hip_count_foreground: how many region ids of a batch are not 0 (what the driver's speculation policy runs on)."""
+    rng = np.random.default_rng(n)
+    ids = torch.from_numpy((rng.integers(1, 300, n) * (rng.random(n) < 0.13)).astype(np.int32)).cuda()
+    assert native.count_foreground(ids) == int((ids != 0).sum())
+    assert native.count_foreground(torch.zeros_like(ids)) == 0
+    assert native.count_foreground(torch.ones_like(ids)) == n

@@ -82,5 +82,6 @@ else:
     on["kernels"] = {"hbma": [hb], "dct": [dct], **({"luma_pyr1": lus[:1]} if lus else {})}
     on["source_sha16"] = dict(meta["source_sha16"])
     on["collected_utc"] = meta["collected_utc"]
+    on.pop("note", None)
 json.dump(db, open(path, "w"), indent=1)
 print(json.dumps(rec, indent=1))
