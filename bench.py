@@ -772,7 +772,10 @@ def main() -> None:
                 dct_bytes = (cfg.dct_bytes_per_frame() + (pw * ph if one_pass else 0)) * info.pairs
                 dct_ms = kt["dct_quant"] / nl["dct_quant"]
                 dct_gbps = dct_bytes / (dct_ms * 1e-3) / 1e9
-                dct_key = "dct_records_bytes_per_launch" if args.wire else "dct_bytes_per_launch"
+                # one figure per kernel variant: records (+ luma plane) with --wire read once, planes + luma plane when the step speculated,
+                # the plain transform in the two-pass order (none was collected for --wire --two-bgr-passes)
+                dct_key = ("dct_records_bytes_per_launch" if one_pass else "dct_records_two_passes_bytes_per_launch") if args.wire else \
+                    ("dct_luma_bytes_per_launch" if one_pass else "dct_bytes_per_launch")
                 dct_traffic, dct_traffic_source = traffic("dct", dct_key, info.pairs)
                 out["roofline_dct"] = {
                     "kernel": (f"dct_kernel<{cfg.dct_block}, quant, luma, speculative> (every tile quantised as background + the luma plane from one pass over the BGR clip; "

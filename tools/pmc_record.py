@@ -18,6 +18,9 @@ ap.add_argument("summary")
 ap.add_argument("pairs", type=int)
 ap.add_argument("--wire", action="store_true", help="the run was bench.py --wire: only the record-emitting transform's figure is taken")
 ap.add_argument("--as", dest="dest", default=None, help="copy the summary (+ meta) to this path under profiles/ and cite that")
+ap.add_argument("--only-dct-as", default=None, metavar="KEY",
+                help="record ONLY the transform's figure, under KEY (dct_bytes_per_launch: the two-pass order's kernel; dct_luma_bytes_per_launch: the "
+                     "front-of-step kernel that also stores the luma plane) -- for a second collection of the same configuration in the other order")
 a = ap.parse_args()
 
 rows = {}
@@ -61,7 +64,12 @@ def pick_dct():
 
 
 dct = pick_dct()
-if a.wire:
+if a.only_dct_as:
+    rec[a.only_dct_as] = hbm_bytes(dct)
+    rec[a.only_dct_as.replace("_bytes_per_launch", "_note")] = f"{dct} ({src})"
+    if on["source_sha16"].get("dct") not in (None, meta["source_sha16"]["dct"]):
+        sys.exit("the other figures of this config were collected on other dct sources: re-collect them first")
+elif a.wire:
     rec["dct_records_bytes_per_launch"] = hbm_bytes(dct)
     rec["dct_records_note"] = f"bench.py --wire, {dct} ({src})"
     if on["source_sha16"].get("dct") not in (None, meta["source_sha16"]["dct"]):
@@ -69,8 +77,12 @@ if a.wire:
 else:
     hb = pick(lambda k: "hbma_" in k)
     lus = [k for k in rows if "luma_pyr1_kernel<true" in k]
-    rec.update({"source": src, "pairs": a.pairs, "hbma_bytes_per_launch": hbm_bytes(hb), "dct_bytes_per_launch": hbm_bytes(dct),
-                "hbma_note": f"{hb}; L2 memory-side request counters by size", "dct_note": dct})
+    spec = dct.rstrip(">").rstrip().endswith(", true, 1")  # the front-of-step kernel (also stores the luma plane): a figure of its own
+    for k in ("dct_bytes_per_launch", "dct_note", "dct_luma_bytes_per_launch", "dct_luma_note"):
+        rec.pop(k, None)
+    rec.update({"source": src, "pairs": a.pairs, "hbma_bytes_per_launch": hbm_bytes(hb),
+                "dct_luma_bytes_per_launch" if spec else "dct_bytes_per_launch": hbm_bytes(dct),
+                "hbma_note": f"{hb}; L2 memory-side request counters by size", "dct_luma_note" if spec else "dct_note": dct})
     # a step that reads the BGR clip once runs the BGR luma kernel on the clip's first frame only: its figure is not a clip's
     rec.pop("luma_pyr1_bytes_per_launch", None)
     if lus and not any(", true, 1>" in k for k in rows if "dct_kernel" in k):
