@@ -96,7 +96,7 @@ struct ClipEncoder::Impl {
   uint32_t lat_flags = 0;
   bool fused_records = false;  // wire output straight from the transform kernel (square transform blocks)
   bool one_bgr_pass = false;   // wire, tuned transform blocks: records + luma plane from ONE kernel at the front of the step, type words
-                               // stored once the step's region ids exist (clip_encoder.hpp); records then exist in `nsets` sets
+                               // stored once the step's region ids exist (clip_encoder.hpp); records then exist in `rec_sets` sets
   // nsets + 1 of them: the front of step s + nsets + 1 rewrites the set in the iteration AFTER the one whose last launch completed step s's
   // records (with nsets it would be the same iteration, and the front runs first)
   int rec_sets = 1;
@@ -112,6 +112,8 @@ struct ClipEncoder::Impl {
   // blocks in pinned host memory; nobody waits for it -- a step decides on the newest count that has arrived by then.
   static constexpr int kFgSlots = 8;
   static constexpr double kSpecMaxShare = 0.02;
+  // small shards do not pay: the front-of-step transform costs a fixed ~10 us more than it saves below ~25 frames of 1080p
+  // (profiles/r05_ab_speculative_quant.txt: 1080p shards of 150 / 75 / 38 / 19 frames -6 / -4 / -2 / +-1 %; C2's 29 frames of 720p +5 %)
   static constexpr uint64_t kSpecMinPixels = 50000000ull;  // encoded frames x padded pixels of the shard
   DevBuf<uint32_t> fg_dev;
   uint32_t* fg_host = nullptr;
@@ -132,9 +134,6 @@ struct ClipEncoder::Impl {
   bool DecideSpeculation() {
     if (!spec_quant || c.two_bgr_passes) return false;
     if (c.always_speculate) return true;
-    // small shards do not pay: the front-of-step transform costs a fixed ~10 us more than it saves below ~25 frames of 1080p
-    // (profiles/r05_ab_speculative_quant.txt: 1080p shards of 150 / 75 / 38 / 19 frames -6 / -4 / -2 / +-1 %; C2's 29 frames of 720p +5 %)
-    if ((uint64_t)sh.pairs * pw * ph < kSpecMinPixels) return false;
     for (uint64_t k = n_fg; k > 0 && k + kFgSlots > n_fg; --k) {  // newest first
       const int slot = (int)((k - 1) % kFgSlots);
       if (!fg_pending[slot]) continue;
@@ -477,8 +476,11 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   // one pass over the BGR clip: the tuned record emitter (8x8 / 16x16 on widths that are whole 16-pixel segments) also leaves the luma plane
   m.one_bgr_pass = m.fused_records && !c.two_bgr_passes && transform && (c.dct_block_w == 8 || c.dct_block_w == 16) && m.pw % 16 == 0 &&
                    c.mv_block % c.dct_block_w == 0 && P > 0;
-  m.spec_quant = !c.wire && transform && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) &&
-                 m.pw % 16 == 0 && c.mv_block % 16 == 0 && c.mv_block % c.dct_block_w == 0 && c.fg_step > 0 && c.bg_step > 0 && P > 0;
+  // can this shard ever speculate?  (not when told never to; not -- unless told always to -- when it is too small to pay: then it keeps
+  // one set of coefficients and measures nothing)
+  m.spec_quant = !c.wire && !c.two_bgr_passes && transform && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) &&
+                 m.pw % 16 == 0 && c.mv_block % 16 == 0 && c.mv_block % c.dct_block_w == 0 && c.fg_step > 0 && c.bg_step > 0 && P > 0 &&
+                 (c.always_speculate || (uint64_t)P * m.pw * m.ph >= Impl::kSpecMinPixels);
   m.rec_sets = (m.one_bgr_pass || m.spec_quant) && pipelined ? m.nsets + 1 : 1;
   if (transform) {
     if (c.wire)
