@@ -414,29 +414,33 @@ def test_one_bgr_pass_equals_two_passes(native, wire, dct, schedule, steps, rank
     assert all(launches == steps for _, launches in got["one"][3].values())
 
 
-def test_wire_one_bgr_pass_record_sets_never_serve_stale_steps(native):
-    """A step's records are emitted at its front and completed (type words) 2 + depth iterations later, in a set of their own; the clip
-    changes between bursts, so records of a stale set -- or region ids patched into another step's records -- would show."""
+@pytest.mark.parametrize("wire", [True, False])
+def test_one_bgr_pass_output_sets_never_serve_stale_steps(native, wire):
+    """A step's records / coefficients are written at its front and completed (type words / foreground tiles) 2 + depth iterations later,
+    in a set of their own; the clip changes between bursts, so the output of a stale set -- or region ids finished into another step's
+    output -- would show."""
     dev = torch.device("cuda")
     n = 7
     cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
     fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    buf = "records" if wire else "coeffs"
     want = {}
     for name, f in (("a", fa), ("b", fb)):
-        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, wire=True, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, wire=wire, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
         s.load_frames(f)
         s.step()
         s.sync()
-        want[name] = s.read("records")
+        want[name] = s.read(buf)
         s.close()
     assert not torch.equal(want["a"], want["b"])
     for lat_depth in (0, 1, 3):
-        enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, wire=True, lat_depth=lat_depth, ransac=dict(inlier_thresh=1.5))
+        enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, wire=wire, lat_depth=lat_depth, ransac=dict(inlier_thresh=1.5),
+                           tuning=0 if wire else clipmod.TUNE_ALWAYS_SPECULATE)
         for burst, (name, f, k) in enumerate((("a", fa, 8), ("b", fb, 1), ("a", fa, 2), ("b", fb, 3), ("a", fa, 5), ("b", fb, 6))):
             enc.load_frames(f)
             for _ in range(k):
                 enc.step()
-            assert torch.equal(enc.read("records"), want[name]), (lat_depth, burst)
+            assert torch.equal(enc.read(buf), want[name]), (lat_depth, burst)
         enc.close()
 
 
