@@ -323,20 +323,15 @@ int svc_hip_dct_records_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes
 /* The record emitter with the luma plane as a by-product: ONE pass over the BGR bytes feeds both the transform (records of the RAW
  * coefficients, what the reference's encoder emits: libs/encoder.cpp:638-650) and cv::cvtColor + extractChannel (:468-469) -- Y is
  * pointwise, so the lane that holds 16 pixels of a row for the transform stores their 16 luma bytes into level 0 of the frame's packed
- * pyramid (frame f at d_pyr + f * pyr_stride_bytes) -- and level 1 where svc_hip_dct_luma_levels says 2; the levels above are then
- * svc_hip_pyramid_upper_levels_frames.  The clip is read once per
+ * pyramid (frame f at d_pyr + f * pyr_stride_bytes; levels 1.. are then svc_hip_pyramid_levels_frames).  The clip is read once per
  * step instead of twice.  Region ids do not exist yet when this runs (they need the pyramid it produces): every record's type word
  * is written as 0 (background, libs/codec.hpp:6) and svc_hip_wire_patch_types_frames stores the foreground ids afterwards -- the two
  * calls together leave exactly the bytes of svc_hip_dct_records_frames(fg_step = bg_step = 0).  block: 8 or 16; frame_w a multiple of
  * 16; UNSUPPORTED otherwise (call svc_hip_luma_pyramid_frames + svc_hip_dct_records_frames). */
-/* How many pyramid levels the two luma-producing transform calls below leave in d_pyr (a packed pyramid of level_count levels): 1 (level
- * 0), or 2 (levels 0 and 1) when level_count >= 2 on frames of whole 128 x 32 luma tiles (frame_w % 128 == 0, frame_h % 32 == 0) -- there the 5x5 pass of cv::buildPyramid's first step runs on the
- * transform workgroup's own luma tile and the plane is never re-read.  The remaining levels: svc_hip_pyramid_upper_levels_frames. */
-uint32_t svc_hip_dct_luma_levels(uint32_t frame_w, uint32_t frame_h, uint32_t block, uint32_t level_count);
 int svc_hip_dct_records_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames,
                                     uint32_t frame_w, uint32_t frame_h, uint32_t block, uint32_t emit_frame_h,
                                     uint8_t* d_records, uint64_t records_stride_bytes, uint8_t* d_pyr,
-                                    uint64_t pyr_stride_bytes, uint32_t level_count, void* stream);
+                                    uint64_t pyr_stride_bytes, void* stream);
 /* Type words of records that were emitted before the region ids were known (libs/encoder.cpp:243-249: the id of the MV block that
  * holds the tile).  Stores the word of every tile of a FOREGROUND block (id != 0); all_tiles != 0 stores the zeros too (records whose
  * type words hold anything else than 0). */
@@ -358,7 +353,7 @@ int svc_hip_wire_patch_types_frames(const uint32_t* d_block_types, uint32_t n_fr
  * block: 8 or 16; frame_w a multiple of 16; MV blocks whole 16-pixel segments wide and whole transform blocks tall; else UNSUPPORTED. */
 int svc_hip_dct_quant_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                                   uint32_t frame_h, uint32_t block, uint32_t bg_step, float* d_planes, uint8_t* d_pyr,
-                                  uint64_t pyr_stride_bytes, uint32_t level_count, void* stream);
+                                  uint64_t pyr_stride_bytes, void* stream);
 /* *d_count = how many of the n region ids are not 0 (foreground MV blocks): the feedback a driver decides on whether the next step
  * speculates (svc::ClipEncoder does: speculation pays while the share of foreground blocks is a few per cent). */
 int svc_hip_count_foreground(const uint32_t* d_block_types, uint64_t n, uint32_t* d_count, void* stream);
@@ -408,9 +403,6 @@ int svc_hip_luma_pyramid_frames(const uint8_t* d_bgr, uint64_t frame_stride_byte
  * pyramids (same layout, same kernels as the levels svc_hip_luma_pyramid_frames produces past its first). */
 int svc_hip_pyramid_levels_frames(uint8_t* d_pyr, uint64_t pyr_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                                   uint32_t frame_h, uint32_t level_count, void* stream);
-/* The same from pyramids whose levels 0 .. have_levels - 1 are in place (have_levels >= 1; svc_hip_pyramid_levels_frames is have_levels = 1). */
-int svc_hip_pyramid_upper_levels_frames(uint8_t* d_pyr, uint64_t pyr_stride_bytes, uint32_t n_frames, uint32_t frame_w,
-                                        uint32_t frame_h, uint32_t level_count, uint32_t have_levels, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-frame global motion: the three estimators of libs/motion.hpp:38-59.  No caller in the

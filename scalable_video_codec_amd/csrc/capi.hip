@@ -513,58 +513,36 @@ int svc_hip_pyramid_levels_frames(uint8_t* d_pyr, uint64_t pyr_stride_bytes, uin
   return launch_pyr_down_levels(d_pyr, pyr_stride_bytes, n_frames, frame_w, frame_h, level_count, 0, static_cast<hipStream_t>(stream));
 }
 
-uint32_t svc_hip_dct_luma_levels(uint32_t frame_w, uint32_t frame_h, uint32_t block, uint32_t level_count) {
-  return dct_luma_levels(frame_w, frame_h, block, level_count);
-}
-
-int svc_hip_pyramid_upper_levels_frames(uint8_t* d_pyr, uint64_t pyr_stride_bytes, uint32_t n_frames, uint32_t frame_w, uint32_t frame_h,
-                                        uint32_t level_count, uint32_t have_levels, void* stream) {
-  SVC_REQUIRE(have_levels >= 1, "pyramid_upper_levels: level 0 must be in place (have_levels >= 1)");
-  if (have_levels >= level_count) return SVC_OK;
-  if (n_frames == 0) return SVC_OK;
-  SVC_REQUIRE(d_pyr, "pyramid_upper_levels: null pointer");
-  SVC_REQUIRE(level_count > 0 && level_count <= 16, "pyramid_upper_levels: level_count %u out of range", level_count);
-  const uint32_t f = 1u << (level_count - 1);
-  SVC_REQUIRE(frame_w > 0 && frame_h > 0 && frame_w % f == 0 && frame_h % f == 0,
-              "pyramid_upper_levels: frame %ux%u must be divisible by 2^(levels-1) = %u", frame_w, frame_h, f);
-  SVC_REQUIRE(n_frames <= 1 || pyr_stride_bytes >= pyramid_bytes(frame_w, frame_h, level_count), "pyramid_upper_levels: pyramid stride too small");
-  return launch_pyr_down_levels(d_pyr, pyr_stride_bytes, n_frames, frame_w, frame_h, level_count, have_levels - 1, static_cast<hipStream_t>(stream));
-}
-
 int svc_hip_dct_records_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                                     uint32_t frame_h, uint32_t block, uint32_t emit_frame_h, uint8_t* d_records,
-                                    uint64_t records_stride_bytes, uint8_t* d_pyr, uint64_t pyr_stride_bytes, uint32_t level_count, void* stream) {
+                                    uint64_t records_stride_bytes, uint8_t* d_pyr, uint64_t pyr_stride_bytes, void* stream) {
   if (n_frames == 0) return SVC_OK;
   int rc = validate_dct(d_bgr, d_records, frame_w, frame_h, block, block);
   if (rc) return rc;
   SVC_REQUIRE(d_pyr, "dct_records_luma: null pyramid");
-  SVC_REQUIRE(level_count > 0 && level_count <= 16, "dct_records_luma: level_count %u out of range", level_count);
   SVC_REQUIRE(emit_frame_h > 0 && emit_frame_h <= frame_h, "dct_records_luma: emit_frame_h %u outside (0, %u]", emit_frame_h, frame_h);
   SVC_REQUIRE(aligned(d_bgr, 16) && frame_stride_bytes % 16 == 0 && aligned(d_records, 4) && records_stride_bytes % 4 == 0 &&
                   records_stride_bytes >= svc_hip_serialized_frame_bytes(frame_w, emit_frame_h, block, block),
               "dct_records_luma: frames must be 16-byte aligned; records 4-byte aligned with a stride of at least one frame");
-  SVC_REQUIRE(aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0 &&
-                  (n_frames <= 1 || pyr_stride_bytes >= pyramid_bytes(frame_w, frame_h, dct_luma_levels(frame_w, frame_h, block, level_count))),
-              "dct_records_luma: pyramids must be 16-byte aligned (stride too), a stride of at least the levels this call leaves (svc_hip_dct_luma_levels)");
+  SVC_REQUIRE(aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0 && (n_frames <= 1 || pyr_stride_bytes >= (uint64_t)frame_w * frame_h),
+              "dct_records_luma: pyramids must be 16-byte aligned (stride too), a stride of at least one luma plane");
   return launch_dct(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block, block, nullptr, block, block, 1, 1, false, nullptr,
-                    static_cast<hipStream_t>(stream), d_records, records_stride_bytes, emit_frame_h, d_pyr, pyr_stride_bytes, level_count);
+                    static_cast<hipStream_t>(stream), d_records, records_stride_bytes, emit_frame_h, d_pyr, pyr_stride_bytes);
 }
 
 int svc_hip_dct_quant_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                                   uint32_t frame_h, uint32_t block, uint32_t bg_step, float* d_planes, uint8_t* d_pyr,
-                                  uint64_t pyr_stride_bytes, uint32_t level_count, void* stream) {
+                                  uint64_t pyr_stride_bytes, void* stream) {
   if (n_frames == 0) return SVC_OK;
   int rc = validate_dct(d_bgr, d_planes, frame_w, frame_h, block, block);
   if (rc) return rc;
   SVC_REQUIRE(d_pyr, "dct_quant_luma: null pyramid");
-  SVC_REQUIRE(level_count > 0 && level_count <= 16, "dct_quant_luma: level_count %u out of range", level_count);
   SVC_REQUIRE(bg_step > 0, "dct_quant_luma: quant step must be positive (libs/decoder.cpp:35-47)");
   if ((rc = validate_dct_alignment(d_bgr, frame_stride_bytes, d_planes, frame_w, block, block))) return rc;
-  SVC_REQUIRE(aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0 &&
-                  (n_frames <= 1 || pyr_stride_bytes >= pyramid_bytes(frame_w, frame_h, dct_luma_levels(frame_w, frame_h, block, level_count))),
-              "dct_quant_luma: pyramids must be 16-byte aligned (stride too), a stride of at least the levels this call leaves (svc_hip_dct_luma_levels)");
+  SVC_REQUIRE(aligned(d_pyr, 16) && pyr_stride_bytes % 16 == 0 && (n_frames <= 1 || pyr_stride_bytes >= (uint64_t)frame_w * frame_h),
+              "dct_quant_luma: pyramids must be 16-byte aligned (stride too), a stride of at least one luma plane");
   return launch_dct_quant_speculative(d_bgr, frame_stride_bytes, n_frames, frame_w, frame_h, block, bg_step, d_planes, d_pyr,
-                                      pyr_stride_bytes, level_count, static_cast<hipStream_t>(stream));
+                                      pyr_stride_bytes, static_cast<hipStream_t>(stream));
 }
 
 int svc_hip_count_foreground(const uint32_t* d_block_types, uint64_t n, uint32_t* d_count, void* stream) {

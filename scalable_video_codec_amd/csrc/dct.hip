@@ -193,9 +193,9 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // luma plane; once the ids exist, SPEC = 2 redoes exactly the tiles of foreground MV blocks (fg_list, built by fg_list_kernel) with fg_step:
 // a fixed grid whose workgroups walk the list.  Same arithmetic, same bytes as SPEC = 0 with the ids up front.  The redo costs 15 bytes per
 // foreground pixel; the saving is 3 bytes per pixel of every frame: ahead while less than ~17 % of the MV blocks are foreground (C3: 0.5 %).
-template <int N, bool QUANT, bool WIRE, int LUMA = 0, int SPEC = 0>
+template <int N, bool QUANT, bool WIRE, bool LUMA = false, int SPEC = 0>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
-  static_assert(LUMA == 0 || (WIRE && !QUANT) || (QUANT && !WIRE && SPEC == 1), "the luma by-product rides on the raw-coefficient record emitter or on the speculative quantiser");
+  static_assert(!LUMA || (WIRE && !QUANT) || (QUANT && !WIRE && SPEC == 1), "the luma by-product rides on the raw-coefficient record emitter or on the speculative quantiser");
   static_assert(SPEC == 0 || (QUANT && !WIRE), "speculation is about the quantiser's step");
   constexpr int kSegPerWg = 256 / N;  // 512- and 1024-lane workgroups (longer runs per row) measured level or worse: profiles/r03_ab_dct_lanes.txt
   constexpr int kSlab = WIRE ? (N == 8 ? kSlabWire8 : kSlabWire16) : (N == 8 ? kSlab8 : kSlab16);
@@ -219,16 +219,6 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
     const uint32_t b = item - frame * a.mv_blocks, by = b / a.mfw, bx = b - by * a.mfw;
     band = by * (a.mv_bh / N) + sub / a.segs_per_block_x;
     seg = bx * a.segs_per_block_x + sub % a.segs_per_block_x;
-  } else if (LUMA == 2) {
-    // a workgroup = one 128 x 32 luma tile (8 segments x 32 / N bands; the grid is exactly the clip's tiles): a wave still owns consecutive
-    // segment columns of ONE band, so its stores -- and the record stretch of WIRE -- are the plain mapping's
-    const uint32_t tile = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const uint32_t tiles_x = a.w / 128u, tiles_per_frame = tiles_x * (a.h / 32u);
-    frame = tile / tiles_per_frame;
-    const uint32_t tr = tile - frame * tiles_per_frame, ty = tr / tiles_x, tx = tr - ty * tiles_x;
-    band = ty * (32u / N) + sc_local / 8u;
-    seg = tx * 8u + sc_local % 8u;
-    gsc = (frame * a.bands_per_frame + band) * a.segs_per_band + seg;
   } else {
     // a workgroup's place in the clip follows the XCD it runs on: the 2 KiB row pieces that neighbouring
     // workgroups write land in the same L2 and leave it as longer runs (stores alone: 1.33 -> 1.25 ms)
@@ -256,38 +246,7 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   if (LUMA) {
     uint32_t y16[4];
     luma16(wds, y16);
-    const uint4 y4 = make_uint4(y16[0], y16[1], y16[2], y16[3]);
-    uint8_t* y_plane = a.luma + (size_t)frame * a.luma_stride;
-    *reinterpret_cast<uint4*>(y_plane + (size_t)(y_pix + j) * a.w + x_pix) = y4;
-    if (LUMA == 2) {
-      // LEVEL 1 too (cv::buildPyramid's first step, libs/encoder.cpp:470): the workgroup's 128 x 32 luma tile goes to LDS -- over the slabs, which
-      // are first written behind the second barrier -- with the 2-pixel BORDER_REFLECT_101 halo luma_pyr1_kernel<true,128,32> gives it (four more
-      // rows of eight segments, four more pixels per row: 15 % more B,G,R loads, served by the L2), and the 5x5 pass runs from there: the
-      // pyramid pass that re-read the whole luma plane (0.21 ms per C3 clip, VALU- and LDS-bound) is gone for frames of whole tiles.
-      constexpr int kPitch = 128 + 2 * kOff;
-      static_assert(36 * kPitch <= kSegPerWg * kSlab, "the luma tile fits over the slabs");
-      const int w = (int)a.w, h = (int)a.h;
-      const int x0 = (int)(x_pix & ~127u), y0 = (int)(y_pix & ~31u);
-      const uint8_t* bgr = a.bgr + (size_t)frame * a.frame_stride;
-      *reinterpret_cast<uint4*>(&lds[((int)(y_pix + j) - y0 + 2) * kPitch + kOff + ((int)x_pix - x0)]) = y4;
-      if (tid < 32u) {  // halo rows -2, -1, 32, 33: eight segments each
-        const int hr = (int)tid >> 3, r = hr < 2 ? hr : 32 + hr, sgm = (int)tid & 7;
-        const uint4* p = reinterpret_cast<const uint4*>(bgr + ((size_t)reflect101(y0 - 2 + r, h) * w + x0 + 16 * sgm) * 3);
-        const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-        const uint32_t wd[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-        uint32_t o[4];
-        luma16(wd, o);
-        *reinterpret_cast<uint4*>(&lds[r * kPitch + kOff + 16 * sgm]) = make_uint4(o[0], o[1], o[2], o[3]);
-      } else if (tid < 32u + 36u * 4u) {  // halo pixels: two columns on each side, all 36 rows
-        const int task = (int)tid - 32, r = task >> 2, k = task & 3;
-        const int x = k < 2 ? x0 - 2 + k : x0 + 128 + (k - 2);
-        const uint8_t* p = bgr + ((size_t)reflect101(y0 - 2 + r, h) * w + reflect101(x, w)) * 3;
-        lds[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
-      }
-      __syncthreads();
-      next_level_from_tile<128, 32, 1>((uint64_t)a.w * a.h, lds, x0, y0, w, h, y_plane);
-      __syncthreads();  // the tile's bytes become slabs
-    }
+    *reinterpret_cast<uint4*>(a.luma + (size_t)frame * a.luma_stride + (size_t)(y_pix + j) * a.w + x_pix) = make_uint4(y16[0], y16[1], y16[2], y16[3]);
   }
 
   uint8_t* slab = lds + sc_local * kSlab;
@@ -295,7 +254,7 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
 
   float step = 1.f, inv_step = 1.f;
   uint32_t t = SPEC == 2 ? 1u : 0u;  // SPEC 1: everything as background; SPEC 2: the list holds foreground blocks only
-  if ((QUANT || WIRE) && LUMA == 0 && SPEC == 0) {
+  if ((QUANT || WIRE) && !LUMA && SPEC == 0) {
     // tile type = type of the MV block that holds it (libs/encoder.cpp:243-249);
     // background (0, libs/codec.hpp:6) takes bg_step (libs/decoder.cpp:130-135)
     const uint32_t col = N == 8 ? x_pix + 2 * j : x_pix + j;
@@ -449,17 +408,6 @@ __global__ __launch_bounds__(256) void fg_list_kernel(const uint32_t* types, uin
   if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, n);
   base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
   if (fg) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = g;
-}
-
-// How many pyramid levels the transform kernels that leave the luma plane produce: level 0 always; level 1 too on frames of whole 128 x 32
-// luma tiles (dct_kernel, LUMA = 2).
-uint32_t dct_luma_levels(uint32_t w, uint32_t h, uint32_t block, uint32_t level_count) {
-#ifdef SVC_NO_LUMA_L1
-  (void)w; (void)h; (void)block; (void)level_count;
-  return 1;
-#else
-  return (level_count >= 2 && (block == 8 || block == 16) && w % 128 == 0 && h % 32 == 0 && h >= 32) ? 2u : 1u;
-#endif
 }
 
 // ---- any transform block the reference's Validate admits (libs/encoder.cpp:62-142) ---------------
@@ -623,7 +571,7 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
                uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
                hipStream_t stream, uint8_t* d_records, uint64_t records_stride, uint32_t emit_h, uint8_t* d_luma,
-               uint64_t luma_stride, uint32_t pyr_levels) {
+               uint64_t luma_stride) {
   const bool wire = d_records != nullptr;
   const bool fast = bw == bh && (bw == 8 || bw == 16) && w % 16 == 0;
   if (d_luma && !(fast && wire && !quant))
@@ -663,12 +611,8 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
   const dim3 grid(div_up(a.total_segcols, seg_per_wg)), block(256);
 #define SVC_DCT_LAUNCH(N_, Q_, W_) hipLaunchKernelGGL((dct_kernel<N_, Q_, W_>), grid, block, 0, stream, a)
   if (d_luma) {
-    if (dct_luma_levels(w, h, bw, pyr_levels) == 2) {  // frames of whole 128 x 32 tiles: level 1 comes out of this launch too
-      const dim3 tgrid((w / 128) * (h / 32) * n_frames);
-      if (bw == 8) hipLaunchKernelGGL((dct_kernel<8, false, true, 2>), tgrid, block, 0, stream, a);
-      else hipLaunchKernelGGL((dct_kernel<16, false, true, 2>), tgrid, block, 0, stream, a);
-    } else if (bw == 8) hipLaunchKernelGGL((dct_kernel<8, false, true, 1>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((dct_kernel<16, false, true, 1>), grid, block, 0, stream, a);
+    if (bw == 8) hipLaunchKernelGGL((dct_kernel<8, false, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((dct_kernel<16, false, true, true>), grid, block, 0, stream, a);
   } else if (bw == 8) {
     if (wire) { if (quant) SVC_DCT_LAUNCH(8, true, true); else SVC_DCT_LAUNCH(8, false, true); }
     else { if (quant) SVC_DCT_LAUNCH(8, true, false); else SVC_DCT_LAUNCH(8, false, false); }
@@ -710,7 +654,7 @@ static bool spec_shape_ok(uint32_t w, uint32_t block) { return (block == 8 || bl
 
 // planes quantised with bg_step EVERYWHERE (every tile taken for background) + the luma plane, at the front of a step
 int launch_dct_quant_speculative(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t block,
-                                 uint32_t bg_step, float* d_planes, uint8_t* d_luma, uint64_t luma_stride, uint32_t pyr_levels, hipStream_t stream) {
+                                 uint32_t bg_step, float* d_planes, uint8_t* d_luma, uint64_t luma_stride, hipStream_t stream) {
   if (!spec_shape_ok(w, block))
     return fail(SVC_ERR_UNSUPPORTED, "dct_quant_luma: the speculative form needs the tuned transform (8x8 / 16x16 blocks, width a multiple of 16)");
   DctArgs a{};
@@ -727,12 +671,8 @@ int launch_dct_quant_speculative(const uint8_t* d_bgr, uint64_t frame_stride, ui
   a.fg_step = a.bg_step = (float)bg_step;
   a.fg_inv = a.bg_inv = 1.0f / a.bg_step;
   const dim3 grid(div_up(a.total_segcols, 256 / block)), blk(256);
-  if (dct_luma_levels(w, h, block, pyr_levels) == 2) {  // frames of whole 128 x 32 tiles: level 1 comes out of this launch too
-    const dim3 tgrid((w / 128) * (h / 32) * n_frames);
-    if (block == 8) hipLaunchKernelGGL((dct_kernel<8, true, false, 2, 1>), tgrid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((dct_kernel<16, true, false, 2, 1>), tgrid, blk, 0, stream, a);
-  } else if (block == 8) hipLaunchKernelGGL((dct_kernel<8, true, false, 1, 1>), grid, blk, 0, stream, a);
-  else hipLaunchKernelGGL((dct_kernel<16, true, false, 1, 1>), grid, blk, 0, stream, a);
+  if (block == 8) hipLaunchKernelGGL((dct_kernel<8, true, false, true, 1>), grid, blk, 0, stream, a);
+  else hipLaunchKernelGGL((dct_kernel<16, true, false, true, 1>), grid, blk, 0, stream, a);
   return check_launch("dct_kernel<speculative>");
 }
 

@@ -197,17 +197,16 @@ struct ClipEncoder::Impl {
       Run(Stage::kTransform, st, timing, [&] {
         if (!one_bgr_pass)
           Abi(svc_hip_dct_quant_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.bg_step,
-                                            Coeffs(s).p, slots, pyr_stride, c.levels, st), "svc_hip_dct_quant_luma_frames");
+                                            Coeffs(s).p, slots, pyr_stride, st), "svc_hip_dct_quant_luma_frames");
         else
           Abi(svc_hip_dct_records_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, ph,
-                                              Records(s).p, record_bytes, slots, pyr_stride, c.levels, st), "svc_hip_dct_records_luma_frames");
+                                              Records(s).p, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
       });
       Run(Stage::kLumaPyramid, st, timing, [&] {
         if (skip)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
           Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, 1, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
               "svc_hip_luma_pyramid_frames");
-        Abi(svc_hip_pyramid_upper_levels_frames(slots, pyr_stride, sh.pairs, pw, ph, c.levels, svc_hip_dct_luma_levels(pw, ph, c.dct_block_w, c.levels), st),
-            "svc_hip_pyramid_upper_levels_frames");
+        Abi(svc_hip_pyramid_levels_frames(slots, pyr_stride, sh.pairs, pw, ph, c.levels, st), "svc_hip_pyramid_levels_frames");
       });
       return;
     }

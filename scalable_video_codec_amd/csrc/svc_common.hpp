@@ -95,10 +95,9 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
                uint32_t h, uint32_t bw, uint32_t bh, const uint32_t* d_types, uint32_t mv_bw,
                uint32_t mv_bh, uint32_t fg_step, uint32_t bg_step, bool quant, float* d_planes,
                hipStream_t stream, uint8_t* d_records = nullptr, uint64_t records_stride = 0,
-               uint32_t emit_h = 0, uint8_t* d_luma = nullptr, uint64_t luma_stride = 0, uint32_t pyr_levels = 1);
-uint32_t dct_luma_levels(uint32_t w, uint32_t h, uint32_t block, uint32_t level_count);
+               uint32_t emit_h = 0, uint8_t* d_luma = nullptr, uint64_t luma_stride = 0);
 int launch_dct_quant_speculative(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t block,
-                                 uint32_t bg_step, float* d_planes, uint8_t* d_luma, uint64_t luma_stride, uint32_t pyr_levels, hipStream_t stream);
+                                 uint32_t bg_step, float* d_planes, uint8_t* d_luma, uint64_t luma_stride, hipStream_t stream);
 uint64_t dct_redo_workspace_bytes(uint32_t n_frames, uint32_t mv_blocks);
 int launch_count_foreground(const uint32_t* d_types, uint64_t n, uint32_t* d_count, hipStream_t stream);
 int launch_dct_quant_redo_foreground(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t block,

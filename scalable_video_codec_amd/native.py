@@ -81,11 +81,9 @@ SIGNATURES = {
     "svc_hip_quant_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _vp]),
     "svc_hip_luma_pyramid_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
     "svc_hip_pyramid_levels_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp]),
-    "svc_hip_pyramid_upper_levels_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp]),
-    "svc_hip_dct_luma_levels": (_u32, [_u32, _u32, _u32, _u32]),
-    "svc_hip_dct_records_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _u32, _vp]),
+    "svc_hip_dct_records_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _vp]),
     "svc_hip_wire_patch_types_frames": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u64, C.c_int, _vp]),
-    "svc_hip_dct_quant_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u64, _u32, _vp]),
+    "svc_hip_dct_quant_luma_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u64, _vp]),
     "svc_hip_dct_redo_workspace_bytes": (_u64, [_u32, _u32, _u32, _u32, _u32]),
     "svc_hip_count_foreground": (C.c_int, [_vp, _u64, _vp, _vp]),
     "svc_hip_dct_quant_redo_frames": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _u64, _vp]),
@@ -402,9 +400,8 @@ def dct_records_luma_frames(bgr: torch.Tensor, block: int, levels: int, emit_h: 
     if pyr is None:
         pyr = torch.empty(n * stride, dtype=torch.uint8, device=bgr.device)
     _check(load().svc_hip_dct_records_luma_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, emit_h, _dev(records, torch.uint8),
-                                                  records.stride(0), _dev(pyr, torch.uint8), stride, levels, _stream()))
-    _check(load().svc_hip_pyramid_upper_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels,
-                                                      load().svc_hip_dct_luma_levels(w, h, block, levels), _stream()))
+                                                  records.stride(0), _dev(pyr, torch.uint8), stride, _stream()))
+    _check(load().svc_hip_pyramid_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels, _stream()))
     return records, pyr, stride
 
 
@@ -425,9 +422,8 @@ def dct_quant_luma_frames(bgr: torch.Tensor, block: int, levels: int, bg_step: i
     if pyr is None:
         pyr = torch.empty(n * stride, dtype=torch.uint8, device=bgr.device)
     _check(load().svc_hip_dct_quant_luma_frames(_dev(bgr, torch.uint8), h * w * 3, n, w, h, block, bg_step, _dev(planes, torch.float32),
-                                                _dev(pyr, torch.uint8), stride, levels, _stream()))
-    _check(load().svc_hip_pyramid_upper_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels,
-                                                      load().svc_hip_dct_luma_levels(w, h, block, levels), _stream()))
+                                                _dev(pyr, torch.uint8), stride, _stream()))
+    _check(load().svc_hip_pyramid_levels_frames(_dev(pyr, torch.uint8), stride, n, w, h, levels, _stream()))
     return planes, pyr, stride
 
 

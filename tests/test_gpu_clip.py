@@ -380,8 +380,7 @@ def test_one_bgr_pass_equals_two_passes(native, wire, dct, schedule, steps, rank
     pyramid comes from the plain luma kernel) and on a shard behind a halo."""
     dev = torch.device("cuda")
     n = 9
-    # 640 x 352: whole 128 x 32 luma tiles -- the front-of-step transform leaves level 1 too; 640 x 360 (padded to 368): it does not
-    cfg = configs.CodecConfig("t-3L", 41, 640, 352 if steps % 2 else 360, n, levels=3, dct_block=dct)
+    cfg = configs.CodecConfig("t-360p-3L", 41, 640, 360, n, levels=3, dct_block=dct)
     frames = _frames(cfg, n, dev)
     world = 2 if rank else 1
     first, cnt, pairs, _ = clipmod.plan_shard(n, world, rank)

@@ -199,7 +199,7 @@ def test_random_transform_shapes(native, oracle):
 
 
 @pytest.mark.parametrize("block,w,h,levels,mvb", [(8, 160, 96, 3, 16), (16, 160, 96, 3, 16), (8, 1920, 64, 2, 16), (16, 352, 288, 4, 16), (8, 256, 128, 3, 32),
-                                                   (16, 256, 128, 2, 32), (8, 128, 32, 2, 16)])  # the last four: whole 128 x 32 luma tiles (level 1 from the same launch)
+                                                   (16, 256, 128, 2, 32)])
 @pytest.mark.parametrize("fg_share", [0.0, 0.03, 0.5, 1.0])
 def test_speculative_quant_plus_redo_equals_dct_quant(native, block, w, h, levels, mvb, fg_share):
     """One pass over the BGR bytes (every tile quantised as background + the luma plane) followed by the redo of the foreground MV
