@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <initializer_list>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -49,39 +50,54 @@ extern "C" void SvcEncoderSeed(unsigned long long seed) {
   g_seeded = true;
 }
 
-// ---- the configuration rules of libs/encoder.cpp:20-142, rule for rule ------------------------------------------------
-Error Validate(const RansacParams& p) {
-  if (p.inlier_thresh < 0) return Invalid("RANSAC inlier threshold below 0");
-  if (p.success_prob < 0) return Invalid("RANSAC success probability below 0");
-  if (p.inlier_ratio < 0) return Invalid("RANSAC inlier ratio below 0");
+// ---- the configuration rules of libs/encoder.cpp:20-142: rule for rule, in the reference's order, with the reference's MESSAGES -- the
+// application prints them (apps/encoder.cpp:185-190), so they are part of what a drop-in answers with
+// (tests/test_compat_host.py::test_both_encoder_builds_refuse_a_configuration_with_the_same_words holds the two builds to each other).
+namespace {
+struct Rule { bool broken; const char* what; const char* must; };
+Error FirstBroken(std::initializer_list<Rule> rules) {
+  for (const Rule& r : rules)
+    if (r.broken) return Invalid(std::string("invalid ") + r.what + ": " + r.must);
   return Error{ErrorCode::kOk};
+}
+}  // namespace
+
+Error Validate(const RansacParams& p) {
+  return FirstBroken({{p.inlier_thresh < 0, "inlier threshold", "must be >= 0"},
+                      {p.success_prob < 0, "success probability", "must be >= 0"},
+                      {p.inlier_ratio < 0, "inlier ratio", "must be >= 0"}});
 }
 
 Error Validate(const KMeansParams& p) {
-  if (p.cluster_count == 0) return Invalid("k-means cluster count must be positive");
-  if (p.attempt_count == 0) return Invalid("k-means attempt count must be positive");
-  if (p.max_iter_count == 0) return Invalid("k-means iteration limit must be positive");
-  if (p.epsilon <= 0) return Invalid("k-means epsilon must be positive");
-  return Error{ErrorCode::kOk};
+  return FirstBroken({{p.cluster_count == 0, "cluster count", "must be > 0"},
+                      {p.attempt_count == 0, "attempt count", "must be > 0"},
+                      {p.max_iter_count == 0, "maximum iteration count", "must be > 0"},
+                      {p.epsilon <= 0, "epsilon", "must be > 0"}});
 }
 
 Error Validate(const EncoderConfig& c) {
-  if (c.mv_block_w < 1 || c.mv_block_h < 1) return Invalid("MV block sides must be positive");
-  if (c.pyr_lvl_count < 1) return Invalid("pyramid level count must be positive");
+  Error e = FirstBroken({{c.mv_block_w < 1, "mv block width", "must be > 0"},
+                         {c.mv_block_h < 1, "mv block height", "must be > 0"},
+                         {c.pyr_lvl_count < 1, "pyramid level count", "must be > 0"}});
+  if (e.code != ErrorCode::kOk) return e;
   if (c.mv_search_range / Pow2(c.pyr_lvl_count - 1) == 0)
-    return Invalid("MV search range divided by 2^(levels - 1) must be positive");
-  Error e = Validate(c.ransac);
-  if (e.code != ErrorCode::kOk) return Error{e.code, "RANSAC parameters: " + e.message};
+    return Invalid("invalid mv search and pyramid level count: the quotient from dividing the mv search range by the pyramid level reduction "
+                   "factor must be > 0");
+  e = Validate(c.ransac);
+  if (e.code != ErrorCode::kOk) return Error{e.code, "validating RANSAC parameters: " + e.message};
   e = Validate(c.kmeans);
-  if (e.code != ErrorCode::kOk) return Error{e.code, "k-means parameters: " + e.message};
-  if (c.connected_components_connectivity != 4 && c.connected_components_connectivity != 8)
-    return Invalid("connected-components connectivity must be 4 or 8");
-  if (c.transform_block_w < 1 || c.transform_block_h < 1) return Invalid("transform block sides must be positive");
-  if (c.transform_block_w > c.mv_block_w || c.transform_block_h > c.mv_block_h)
-    return Invalid("the transform block must not exceed the MV block");
-  if (c.mv_block_w % c.transform_block_w != 0 || c.mv_block_h % c.transform_block_h != 0)
-    return Invalid("the MV block must be a whole number of transform blocks");
-  return Error{ErrorCode::kOk};
+  if (e.code != ErrorCode::kOk) return Error{e.code, "validating k-means parameters: " + e.message};
+  const uint cc = c.connected_components_connectivity;
+  // transform blocks larger than, or not dividing, the MV block would overlap several MV blocks: a tile's region id would be ambiguous
+  return FirstBroken({{cc != 4 && cc != 8, "connected components connectivity", "must be either 4 or 8"},
+                      {c.transform_block_w < 1, "transform block width", "must be > 0"},
+                      {c.transform_block_h < 1, "transform block height", "must be > 0"},
+                      {c.transform_block_w > c.mv_block_w, "transform block width and mv block width", "transform block width must be <= mv block width"},
+                      {c.transform_block_h > c.mv_block_h, "transform block height and mv block height", "transform block height must be <= mv block height"},
+                      {c.transform_block_w >= 1 && c.mv_block_w % c.transform_block_w != 0, "mv block width and transform block width",
+                       "mv block width must be divisible by transform block width"},
+                      {c.transform_block_h >= 1 && c.mv_block_h % c.transform_block_h != 0, "mv block height and transform block height",
+                       "mv block height must be divisible by transform block height"}});
 }
 
 Encoder::Encoder(const EncoderConfig& cfg, const VideoProperties& vidprops, CircularQueue<cv::Mat3b>& in_queue,

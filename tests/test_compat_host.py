@@ -114,3 +114,28 @@ def test_loading_the_adapter_leaves_the_host_allocator_alone(compat_lib):
     assert probe({"SVC_KEEP_LARGE_BLOCKS": "0"}) == "mmapped"
     assert probe({"SVC_KEEP_LARGE_BLOCKS": "1"}) == "heap"      # asked through the environment
     assert probe({}, build.LIB_HIP) == "heap"                   # asked through the C ABI
+
+
+def test_both_encoder_builds_refuse_a_configuration_with_the_same_words(tmp_path):
+    """apps/encoder.cpp prints what Validate returns (apps/encoder.cpp:185-190) before it opens the clip or touches a GPU.  The build with the
+    reference's own libs/encoder.cpp and the build with this repo's class Encoder (csrc/host/encoder_hip.cpp) must answer every rule of
+    libs/encoder.cpp:20-142 with the same exit code and the same words, in the same precedence."""
+    here = os.path.join(ROOT, "tests", "dropin")
+    ref, ours = os.path.join(here, "ref_encoder_generic"), os.path.join(here, "ref_app_svc_encoder_generic")
+    if not (os.path.exists(ref) and os.path.exists(ours)):
+        pytest.skip("tests/dropin/ref_encoder_generic / ref_app_svc_encoder_generic not built (need /root/reference at build time)")
+    cases = [["--mv-block-w", "0"], ["--mv-block-h", "0"], ["--pyr-lvl-count", "0"], ["--pyr-lvl-count", "5"], ["--mv-search-range", "3", "--pyr-lvl-count", "3"],
+             ["--ransac-inlier-thresh", "-1"], ["--ransac-success-prob", "-0.5"], ["--ransac-inlier-ratio", "-2"],
+             ["--kmeans-cluster-count", "0"], ["--kmeans-attempt-count", "0"], ["--kmeans-max-iter-count", "0"], ["--kmeans-epsilon", "0"],
+             ["--connected-components-connectivity", "6"], ["--transform-block-w", "0"], ["--transform-block-h", "0"],
+             ["--transform-block-w", "32"], ["--transform-block-h", "32"], ["--transform-block-w", "6"], ["--transform-block-h", "6", "--transform-block-w", "4"],
+             # precedence: several rules broken at once -- the first in the reference's order answers
+             ["--mv-block-w", "0", "--kmeans-epsilon", "0", "--transform-block-h", "0"], ["--kmeans-cluster-count", "0", "--ransac-inlier-ratio", "-1"],
+             ["--transform-block-w", "32", "--transform-block-h", "0"]]
+    for args in cases:
+        out = []
+        for exe in (ref, ours):
+            r = subprocess.run([exe, *args, str(tmp_path / "no_such_clip.svcbgr")], capture_output=True, text=True, timeout=60)
+            out.append((r.returncode, r.stderr, r.stdout))
+        assert out[0] == out[1], (args, out)
+        assert out[0][0] != 0 and out[0][1].startswith("validating configuration: invalid ") or "validating" in out[0][1], (args, out[0])
