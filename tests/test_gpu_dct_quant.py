@@ -242,3 +242,55 @@ def test_count_foreground(native, n):
     assert native.count_foreground(ids) == int((ids != 0).sum())
     assert native.count_foreground(torch.zeros_like(ids)) == 0
     assert native.count_foreground(torch.ones_like(ids)) == n
+
+
+def test_one_pass_forms_on_random_shapes(native):
+    """Seeded random sweep of the calls that read a frame's bytes once (round 5): widths of whole 16-pixel segments, heights of whole MV
+    blocks, 1-4 pyramid levels where the size divides, 8 / 16 transform blocks, MV blocks 16 / 32 / 48 / 64 wide and 8 ... 64 tall, any
+    foreground share, emitted heights below the frame's -- records + type patch == svc_hip_dct_records_frames, speculative planes + redo ==
+    svc_hip_dct_quant_frames, and both leave svc_hip_luma_pyramid_frames' pyramid."""
+    rng = np.random.default_rng(20261005)
+    done = 0
+    while done < 30:
+        block = int(rng.choice([8, 16]))
+        mvw = int(rng.choice([16, 32, 48, 64]))
+        mvh = int(rng.choice([m for m in (8, 16, 32, 48, 64) if m % block == 0]))
+        levels = int(rng.integers(1, 5))
+        f = 1 << (levels - 1)
+        w = mvw * int(rng.integers(1, 9))
+        h = mvh * int(rng.integers(1, 7))
+        if w % f or h % f or (w >> (levels - 1)) < 3 or (h >> (levels - 1)) < 3 or mvw % block:
+            continue
+        n = int(rng.integers(1, 4))
+        bgr = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        mfw, mfh = w // mvw, h // mvh
+        share = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
+        types = torch.from_numpy((rng.integers(1, 500, (n, mfw * mfh)) * (rng.random((n, mfw * mfh)) < share)).astype(np.int32)).cuda()
+        fg, bg = int(rng.integers(1, 9)), int(rng.integers(2, 900))
+        emit_h = h - int(rng.integers(0, 2)) * min(block, h - 1)
+        lib = native.load()
+        want_pyr, stride = native.luma_pyramid_frames(bgr, levels)
+        used = sum((w >> l) * (h >> l) for l in range(levels))
+        # records
+        per = native.serialized_frame_bytes(w, emit_h, block, block)
+        want_rec = torch.empty((n, per), dtype=torch.uint8, device="cuda")
+        native._check(lib.svc_hip_dct_records_frames(bgr.data_ptr(), h * w * 3, n, w, h, block, types.data_ptr(), mvw, mvh, 0, 0, emit_h,
+                                                     want_rec.data_ptr(), per, None))
+        rec, pyr, _ = native.dct_records_luma_frames(bgr, block, levels, emit_h=emit_h)
+        native._check(lib.svc_hip_wire_patch_types_frames(types.data_ptr(), n, w, h, emit_h, block, mvw, mvh, rec.data_ptr(), per, 0, None))
+        # planes
+        want = torch.empty((n, 3, h, w), dtype=torch.float32, device="cuda")
+        native._check(lib.svc_hip_dct_quant_frames(bgr.data_ptr(), h * w * 3, n, w, h, block, block, types.data_ptr(), mvw, mvh, fg, bg, want.data_ptr(), None))
+        planes, pyr2, _ = native.dct_quant_luma_frames(bgr, block, levels, bg_step=bg)
+        nbytes = lib.svc_hip_dct_redo_workspace_bytes(n, w, h, mvw, mvh)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        native._check(lib.svc_hip_dct_quant_redo_frames(bgr.data_ptr(), h * w * 3, n, w, h, block, types.data_ptr(), mvw, mvh, fg, planes.data_ptr(),
+                                                        ws.data_ptr(), nbytes, None))
+        torch.cuda.synchronize()
+        tag = (block, mvw, mvh, levels, w, h, n, share, fg, bg, emit_h)
+        assert torch.equal(rec, want_rec), tag
+        assert torch.equal(planes, want), tag
+        for f_ in range(n):
+            assert torch.equal(pyr[f_ * stride:f_ * stride + used], want_pyr[f_ * stride:f_ * stride + used]), tag
+            assert torch.equal(pyr2[f_ * stride:f_ * stride + used], want_pyr[f_ * stride:f_ * stride + used]), tag
+        done += 1
