@@ -166,9 +166,9 @@ def test_luma_pyramid(native, oracle, w, h, levels):
             assert np.array_equal(got, p), f"frame {i} level {l}: {(got != p).sum()} px differ"
 
 
-# two levels per pass (pyr_down2_kernel: 256 x 64 source tiles) wherever two more are wanted and the plane is whole 16-byte segments wide:
-# one tile, partial tiles in x / in y / both, planes whose edge falls exactly on a tile boundary, 1080p and 4K level-0 shapes, small planes
-# whose mirrored middle samples all come from one tile, an odd number of levels left (two at once, then one), widths that fall back
+# cv::buildPyramid from planes that exist (the steps that read the BGR clip once leave level 0 from the transform kernel): one tile, partial tiles
+# in x / in y / both, planes whose edge falls exactly on a tile boundary, 1080p and 4K level-0 shapes, small planes whose mirrored samples all
+# come from one tile, widths that are not whole 16-byte segments (the gather kernel), 1 - 5 levels
 @pytest.mark.parametrize("w,h,levels", [(256, 64, 3), (512, 128, 3), (272, 72, 3), (1920, 1088, 3), (1920, 1088, 4), (3840, 2160, 4), (3840, 2160, 5),
                                         (16, 8, 3), (32, 16, 3), (48, 12, 3), (240, 68, 3), (768, 192, 5), (1008, 500, 3), (264, 64, 3),
                                         (128, 8, 2), (720, 576, 4)])
