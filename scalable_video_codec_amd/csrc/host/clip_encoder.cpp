@@ -526,6 +526,10 @@ void ClipEncoder::LoadFrames(const uint8_t* src, uint32_t first_local, uint32_t 
   Impl& m = *p_;
   if (!src || (uint64_t)first_local + n > m.sh.frames) throw std::runtime_error("svc::ClipEncoder: LoadFrames out of range");
   Sync();
+  // other frames: what the speculation policy knew about the clip's foreground share is void (every measurement has landed: Sync above)
+  m.fg_share = -1.0;
+  m.n_fg = 0;
+  for (bool& p : m.fg_pending) p = false;
   Hip(hipMemcpy(m.bgr.p + (size_t)first_local * m.frame_bytes, src, (size_t)n * m.frame_bytes,
                 src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "hipMemcpy");
   // a device-to-device hipMemcpy returns before the copy has run, and the streams of Step() do not order behind the
