@@ -5,7 +5,7 @@ level count, 8 / 16 / 32-pixel MV blocks, any transform block that divides them,
 RANSAC, region ids bit for bit, coefficients within the parity tolerance.  Prints one line per configuration and a summary;
 anything it finds becomes a fix plus a named test.
 
-usage (GPU box): python tests/helpers/shape_sweep.py [--count 60] [--seed 1] [--max-side 420]
+usage (GPU box): python tests/helpers/shape_sweep.py [--count 60] [--seed 1] [--max-side 420] [--always-speculate]
 """
 import argparse
 import os
@@ -41,14 +41,14 @@ def random_config(rng, i, max_side):
                                mv_block=mv_block, search_range=search, dct_block=dct_block)
 
 
-def check(cfg, oracle, dev):
+def check(cfg, oracle, dev, tuning=0):
     pw, ph = cfg.padded
     src = synth.SynthClip(cfg.width, cfg.height, cfg.frames, cfg.seed, device=dev)
     frames = torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(cfg.frames)]).contiguous()
-    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED)
+    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED, tuning=tuning)
     try:
         enc.load_frames(frames)
-        for _ in range(3):
+        for _ in range(3 if not tuning else 6):  # speculating: long enough for every coefficient set to have been a front AND a finish
             enc.step()
         enc.sync()
         out = enc.outputs()
@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--count", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-side", type=int, default=420)
+    ap.add_argument("--always-speculate", action="store_true",
+                    help="planes + quant by the speculative one-pass form on every step of every configuration it covers (8 / 16 transform blocks, "
+                         "padded width of whole 16-pixel segments, MV blocks of whole segments); the others take the two-pass order as ever")
     ap.add_argument("--shape", action="append", default=[], help="WxH:levels:mv_block:search_range:dct_block -- run these instead of random ones")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -117,7 +120,7 @@ def main():
         cfg = fixed[i] if fixed else random_config(rng, i, args.max_side)
         t0 = time.perf_counter()
         try:
-            verdict = check(cfg, oracle, dev)
+            verdict = check(cfg, oracle, dev, clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0)
         except Exception as e:  # noqa: BLE001
             verdict = f"EXCEPTION {type(e).__name__}: {str(e)[:200]}"
             if os.environ.get("SWEEP_TRACE"):

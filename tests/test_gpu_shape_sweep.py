@@ -11,14 +11,16 @@ from tests.helpers import shape_sweep
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [3, 11])
-def test_random_validate_admitted_configurations_equal_the_oracle(native, oracle, seed):
+@pytest.mark.parametrize("seed,speculate", [(3, False), (11, False), (5, True)])
+def test_random_validate_admitted_configurations_equal_the_oracle(native, oracle, seed, speculate):
+    """speculate: the same sweep with the speculative one-pass transform forced on wherever it applies (round 5)."""
+    from scalable_video_codec_amd import clip as clipmod
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda")
     failures = []
     for i in range(20):
         cfg = shape_sweep.random_config(rng, i, 360)
-        verdict = shape_sweep.check(cfg, oracle, dev)
+        verdict = shape_sweep.check(cfg, oracle, dev, clipmod.TUNE_ALWAYS_SPECULATE if speculate else 0)
         if verdict is not None:
             failures.append((cfg.name, verdict))
     assert not failures, failures
