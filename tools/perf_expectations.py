@@ -21,7 +21,9 @@ def expectations(d: dict):
     if "roofline_dct" in d:
         yield "transform kernel >= 0.70 of peak", d["roofline_dct"]["frac"] >= 0.70
     if "roofline_step" in d:
-        yield "whole step >= 0.65 of peak", d["roofline_step"]["frac"] >= 0.65
+        # a step that reads the BGR clip once moves 14 % fewer (algorithmic) bytes in 6 % less time: its fraction is the LOWER one by construction
+        one = str(d.get("config", {}).get("bgr_passes_per_step", "")).startswith("one")
+        yield f"whole step >= {0.62 if one else 0.68} of peak ({'one BGR pass' if one else 'two BGR passes'})", d["roofline_step"]["frac"] >= (0.62 if one else 0.68)
     k = d.get("kernel_ms_per_step") or {}
     if k:
         yield "main-stream kernels fit inside the step (sum <= 1.02 ms_per_step)", sum(k.values()) <= 1.02 * d["ms_per_step"]
