@@ -223,8 +223,12 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
             if r.returncode != 0:
                 raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
             out["stream_encoder_fps"] = float(r.stdout.split("encoded frames,")[1].split("frames/s")[0])
-            out["stream_encoder_sample"] = (f"{n - 1} encoded frames ({min(len(src), n)} distinct sample frames"
-                                            f"{', repeated' if len(src) < n else ''}), batch 16, second pass over the clip (first pass = warm-up)")
+            ph = [ln for ln in r.stdout.splitlines() if ln.startswith("phases ")]
+            # the encoder's own clocks (svc::EncodeStats): per batch of 16, host phases of the calling thread and HIP-event time per stream --
+            # which of H2D / kernels / D2H / staging bounds this box's figure, and how many cores the copy crew had
+            out["stream_encoder_phases"] = json.loads(ph[-1][len("phases "):]) if ph else None
+            out["stream_encoder_sample"] = (f"{n - 1} encoded frames per pass ({min(len(src), n)} distinct sample frames"
+                                            f"{', repeated' if len(src) < n else ''}), batch 16, passes over the clip repeated for >= 1 s after one warm-up pass")
             os.remove(raw)
         except Exception as e:  # noqa: BLE001
             out["stream_encoder_fps"] = None
@@ -406,12 +410,17 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
              (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0) | (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
-                       lat_depth=args.lat_depth, tuning=tuning)
+                       lat_depth=args.lat_depth, tuning=tuning, chunk_pairs=args.chunk_pairs)
     info = enc.info
     src = synth.SynthClip(cfg.width, cfg.height, clip_frames, cfg.seed, device=dev)
     pw, ph = cfg.padded
+    want_first = world == 1 and mode == "strong" and args.first_encode_reps > 0
+    held = []  # N = 1: the padded clip stays on the device (1.9 GB at C3) so that first_encode can load it again
     for j in range(info.frames):
-        enc.load_frames(synth.pad_frame(src.frame_bgr(info.first_frame + j), pw, ph).unsqueeze(0).contiguous(), j)
+        f = synth.pad_frame(src.frame_bgr(info.first_frame + j), pw, ph).unsqueeze(0).contiguous()
+        enc.load_frames(f, j)
+        if want_first:
+            held.append(f)
     sample_frames = [synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(min(info.frames, 129))] \
         if (rank == 0 and mode == "strong" and world == 1 and not (args.no_cpu_baseline and args.no_end_to_end)) else None
     del src
@@ -458,6 +467,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
         del pyr
     barrier()
     enc.reset_timers()
+    pol0 = enc.policy_info()
     barrier()
     t0 = time.perf_counter()
     # HIP events around every stage cost 20-45 us per step (tools/diag_step_overhead.py): they are recorded on every
@@ -468,6 +478,10 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     enc.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    pol1 = enc.policy_info()
+    chunks = enc.info.chunks_per_step
+    policy = {"chunk_launches": args.steps * chunks, "had_the_choice": pol1["chunks_decided"] - pol0["chunks_decided"],
+              "speculated": pol1["chunks_speculated"] - pol0["chunks_speculated"], "foreground_share_known": pol1["foreground_share"]}
 
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -477,7 +491,8 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     if world > 1:
         # every rank's own clock and halo time: a straggler or a slow link shows up by rank in the line
         halo_ms = st["halo_exchange"][0] / st["halo_exchange"][1] if "halo_exchange" in st else -1.0
-        mine_row = torch.tensor([elapsed / args.steps * 1e3, halo_ms, float(info.frames), float(info.pairs)], dtype=torch.float64, device=red_dev)
+        mine_row = torch.tensor([elapsed / args.steps * 1e3, halo_ms, float(info.frames), float(info.pairs), float(policy["had_the_choice"]),
+                                 float(policy["speculated"])], dtype=torch.float64, device=red_dev)
         rows = [torch.zeros_like(mine_row) for _ in range(world)]
         dist.all_gather(rows, mine_row)
         per_rank = [[float(v) for v in r_.tolist()] for r_ in rows]
@@ -489,9 +504,11 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
         # every stage is one launch sequence per step: its per-step time is the average over the launches that were
         # timed (in the pipelined schedule a timed call covers stages of four different steps, and the first call
         # after a drain times fewer of them, so the counts differ from stage to stage)
-        "stage_ms_per_step": {k: v[0] / v[1] for k, v in st.items()},
-        "launches_per_step": {k: 1.0 for k in st},
+        # a stage is launched once per chunk and step (chunks = 1: whole-shard launches); its per-step time is the launches' average x chunks
+        "stage_ms_per_step": {k: v[0] / v[1] * (1 if k == "halo_exchange" else chunks) for k, v in st.items()},
+        "launches_per_step": {k: (1.0 if k == "halo_exchange" else float(chunks)) for k in st},
         "launches_timed": {k: v[1] for k, v in st.items()},
+        "chunks": chunks, "policy": policy, "output_sets": enc.output_sets(),
         "timed_steps": timed_steps,
         "sample_frames": sample_frames, "clip_frames": clip_frames,
         "per_rank": per_rank, "halo_check": halo_check,
@@ -507,12 +524,62 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
             n_sus += 50
         dt_sus = time.perf_counter() - t_sus
         res["sustained"] = {"ms_per_step": dt_sus / n_sus * 1e3, "steps": n_sus, "seconds": dt_sus}
+    if want_first and info.pairs:
+        res["first_encode"] = first_encode(args, enc, torch.cat(held), info, chunks)
+        del held
     if info.pairs:
         # what the speculative transform had to redo: the share of MV blocks whose region id is not 0 (outside the timed region)
         res["foreground_share"] = float((enc.read("block_types", device=dev) != 0).float().mean().item())
     enc.close()
     torch.cuda.empty_cache()
     return res
+
+
+def first_encode(args, enc, clip_dev, info, chunks: int) -> dict:
+    """What a clip that is encoded ONCE costs, next to `value` (K steps over a resident clip, back to back, the speculation policy taught by
+    the warm-up steps -- the steady state of a stream of such clips).  Outside the timed region, N = 1:
+      once_through   R x { load_frames of the whole clip (outside the clock; it voids what the policy knew, the driver's default),
+                           ONE step(), sync() } -- the pipeline fills and drains inside the clock, nothing is known about the clip;
+      with_prior     R x { ONE step(), sync() } on the resident clip with the policy's last measurement kept: the next piece of a stream
+                           (what SVC_CLIP_KEEP_FOREGROUND_PRIOR gives a caller across load_frames);
+      policy_voided_steps  reset_policy(), then K back-to-back steps: the steady state while the policy learns again.
+    The reference encodes a clip once, frame by frame (libs/encoder.cpp:453-664)."""
+    import statistics
+    reps = args.first_encode_reps
+    out = {"unit": "frames/s", "reps": reps, "encoded_frames": info.pairs, "chunks_per_step": chunks}
+
+    def timed_once(reload: bool):
+        ms, spec = [], 0
+        for _ in range(reps):
+            if reload:
+                enc.load_frames(clip_dev)
+            torch.cuda.synchronize()
+            p0 = enc.policy_info()["chunks_speculated"]
+            t0 = time.perf_counter()
+            enc.step()
+            enc.sync()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            spec += enc.policy_info()["chunks_speculated"] - p0
+        med = statistics.median(ms)
+        return {"ms_median": med, "ms_min": min(ms), "ms_max": max(ms), "value": info.pairs / (med * 1e-3),
+                "chunk_launches_speculated": spec, "chunk_launches": reps * chunks}
+    enc.sync()
+    out["with_prior"] = timed_once(False)
+    out["once_through"] = timed_once(True)
+    enc.reset_policy()
+    torch.cuda.synchronize()
+    p0 = enc.policy_info()["chunks_speculated"]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.step()
+    enc.sync()
+    dt = time.perf_counter() - t0
+    out["policy_voided_steps"] = {"steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "value": info.pairs * args.steps / dt,
+                                  "chunk_launches_speculated": enc.policy_info()["chunks_speculated"] - p0, "chunk_launches": args.steps * chunks}
+    out["note"] = ("outside the timed region; wall clock around step() + sync() (the pipeline's fill and drain included).  once_through: "
+                   "load_frames before every repetition voids the speculation policy, so the step runs the two-pass order unless it can decide "
+                   "from its own first chunks; with_prior: the resident clip again with the last measurement kept")
+    return out
 
 
 def _launch_ranks(n: int) -> int:
@@ -553,6 +620,10 @@ def main() -> None:
     ap.add_argument("--always-speculate", action="store_true",
                     help="planes + quant: the speculative one-pass form on every step (default: only while the newest foreground share that has arrived "
                          "is at most 2 %%; A/B)")
+    ap.add_argument("--chunk-pairs", type=int, default=0,
+                    help="pipelined, one rank: frame pairs per chunk of a step (0 = the driver's choice; a number >= the clip's pairs = whole-shard "
+                         "launches, the schedule of rounds 2-5)")
+    ap.add_argument("--first-encode-reps", type=int, default=8, help="N = 1: repetitions of {load the clip, ONE step, sync} behind first_encode (0 = skip)")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-stage HIP events on every n-th timed step (every step when --steps < 8)")
     # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The
     # environment variables of the round-2 scripts under tools/ are honoured HERE as defaults, not inside the library.
@@ -666,6 +737,9 @@ def main() -> None:
         main_kt = {k: v for k, v in kt.items() if k not in side}
         side_kt = {k: v for k, v in kt.items() if k in side}
         elapsed = r["elapsed"]
+        pol = r["policy"]
+        # the share of the timed region's chunk launches that read the BGR clip once (wire: all of them where the tuned emitter applies)
+        one_pass_frac = (1.0 if "type_patch" in kt else 0.0) if args.wire or not pol["had_the_choice"] else pol["speculated"] / pol["chunk_launches"]
         out = {
             "metric": "encoded frames/sec (1080p, 16x16 HBMA+DCT)" if cfg.name.startswith("C3") else
                       f"encoded frames/sec ({cfg.name})",
@@ -687,16 +761,26 @@ def main() -> None:
                 "frames_per_gpu": info.frames if world == 1 else [clipmod.plan_shard(r["clip_frames"], world, q)[1] for q in range(world)],
                 "encoded_frames_per_step": r["encoded_per_step"],
                 "foreground_mv_blocks": r.get("foreground_share"),
-                "bgr_passes_per_step": ("two (luma + pyramid, later the transform)" if "type_patch" not in kt else
+                "value_is": ("steady state: K back-to-back steps over the resident clip, the speculation policy taught by the warm-up steps (the state a "
+                             "stream of such clips reaches; SVC_CLIP_KEEP_FOREGROUND_PRIOR carries it across load_frames).  What a clip encoded ONCE costs "
+                             "is first_encode.once_through"),
+                "bgr_passes_per_step": ("two (luma + pyramid, later the transform)" if one_pass_frac == 0 else
                                         "one (records + luma plane from one kernel; type words stored after the segmentation)" if args.wire else
                                         "one, speculative (every tile quantised as background + the luma plane at the front of the step; foreground tiles redone "
-                                        f"in type_patch); timed steps that speculated: {r['launches_timed'].get('type_patch', 0)} of {r['launches_timed'].get('dct_quant', 0)} timed"),
+                                        "in type_patch)" if one_pass_frac == 1 else
+                                        f"MIXED: {pol['speculated']} of the timed region's {pol['chunk_launches']} chunk launches speculated (one pass), the others ran "
+                                        "the two-pass order: the transform's time and bytes below are the launch-weighted mix"),
+                "speculation_policy": pol,
+                "chunks_per_step": r["chunks"],
+                "output_sets": r["output_sets"],
                 "pyr_levels": cfg.levels, "mv_block": cfg.mv_block, "search_range": cfg.search_range,
                 "dct_block": cfg.dct_block, "quant": {"fg": cfg.fg_step, "bg": cfg.bg_step},
-                "schedule": ("software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-4) back to back on one stream; "
-                             "RANSAC+segmentation(s-2) beside them for up to two iterations, consecutive steps on two alternating streams (forked behind the "
-                             "motion search when a whole long clip is on the GPU, at the start of the iteration on shards); halo(s) on its own stream" if args.schedule == "pipelined"
-                             else "one stream, stages back to back"),
+                "schedule": (("software pipeline over the CHUNKS of consecutive steps (a step = " + str(r["chunks"]) + " chunk(s) of frame pairs): luma+pyramid(m), motion "
+                              "search(m), transform(m-3) back to back on one stream; RANSAC+segmentation(m-1) beside them for up to two iterations on two "
+                              "alternating streams" if world == 1 else
+                              "software pipeline over consecutive steps: luma+pyramid(s), motion search(s-1), transform(s-4) back to back on one stream; "
+                              "RANSAC+segmentation(s-2) beside them for up to two iterations, consecutive steps on two alternating streams; halo(s) on its own stream")
+                             if args.schedule == "pipelined" else "one stream, stages back to back"),
                 "driver": "svc::ClipEncoder (C++, include/svc/clip_encoder.hpp)",
                 "parallelism": f"frame-sharded x{world}" + (f", halo = 1 pyramid/rank/step via {r['halo']}" if world > 1 else ""),
             },
@@ -723,6 +807,11 @@ def main() -> None:
                 "ms_per_step_min": min(x[0] for x in pr), "ms_per_step_max": max(x[0] for x in pr),
                 "halo_exchange_ms_by_rank": [x[1] if x[1] >= 0 else None for x in pr],
                 "frames_by_rank": [int(x[2]) for x in pr], "encoded_by_rank": [int(x[3]) for x in pr],
+                # which order each rank ran: the policy is per rank and involves no collective, so ranks may differ in order (never in bytes);
+                # a straggler that did not speculate shows here
+                "per_rank": [{"rank": q, "ms_per_step": x[0], "halo_exchange_ms": x[1] if x[1] >= 0 else None, "frames": int(x[2]), "encoded": int(x[3]),
+                              "launches_with_the_choice": int(x[4]), "launches_speculated": int(x[5]),
+                              "bgr_passes_per_step": "two" if x[5] == 0 else ("one" if x[5] == x[4] else "mixed")} for q, x in enumerate(pr)],
                 "note": "each rank's own wall clock over the timed steps / steps; `ms_per_step` of the line is the max over ranks "
                         "between barriers.  halo_exchange_ms: event-to-event on the communication stream (includes waiting for the "
                         "neighbour's pyramid kernel)",
@@ -749,10 +838,12 @@ def main() -> None:
                 if v is None:
                     return None, f"null: {why}"
                 return v * pairs / base, f"offline PMC ({why}), same {group} sources as this build, scaled from {base} to {pairs} frame pairs; not measured in this run"
-            hbma_bytes = cfg.hbma_bytes_per_frame() * info.pairs
-            hbma_ms = kt["hbma"] / nl["hbma"]
-            hbma_gbps = hbma_bytes / (hbma_ms * 1e-3) / 1e9
+            hbma_bytes = cfg.hbma_bytes_per_frame() * info.pairs   # per step; a launch covers 1 / chunks of it
+            hbma_ms = kt["hbma"] / nl["hbma"]                       # average launch
+            hbma_gbps = hbma_bytes / (kt["hbma"] * 1e-3) / 1e9
             hbma_traffic, hbma_traffic_source = traffic("hbma", "hbma_bytes_per_launch", info.pairs, kname)
+            if hbma_traffic is not None:
+                hbma_traffic /= nl["hbma"]
             out["roofline"] = {
                 "kernel": {"hbma_tiled16_kernel": "hbma_tiled16_kernel (MAD search, all pyramid levels, windows of levels 2 and 1 staged in LDS)",
                            "hbma_fused_kernel": "hbma_fused_kernel (MAD search, all pyramid levels, lane per block)",
@@ -761,24 +852,30 @@ def main() -> None:
                 "frac": hbma_gbps / HBM_PEAK_GBPS,
                 "traffic": hbma_traffic,
                 "traffic_source": hbma_traffic_source,
-                "algorithmic_bytes_per_launch": hbma_bytes,
+                "algorithmic_bytes_per_launch": hbma_bytes / nl["hbma"],
+                "pairs_per_launch": info.pairs / nl["hbma"],
                 "avg_launch_ms": hbma_ms,
                 "launches_per_step": nl["hbma"],
                 "note": "HBM is the stated bound; measured VALU busy ~86 % (byte-SAD ops issue at 4 cycles/wave): VALU time ~= HBM floor, DESIGN.md 4.1"
                         + ("; RANSAC + segmentation of an earlier step may still be running beside it (pipelined schedule)" if args.schedule == "pipelined" else ""),
             }
             if "dct_quant" in kt:
-                one_pass = "type_patch" in kt  # the transform kernel ran at the front of the step: --wire: the transform kernel also stores the luma plane (one pass over the BGR clip)
-                dct_bytes = (cfg.dct_bytes_per_frame() + (pw * ph if one_pass else 0)) * info.pairs
+                # one pass over the BGR clip: the transform kernel at the front of the step also stores the luma plane; a timed region that mixed both
+                # orders (the adaptive policy switching inside it) gets the launch-weighted bytes and says so in its label
+                one_pass = one_pass_frac > 0
+                dct_bytes = (cfg.dct_bytes_per_frame() + pw * ph * one_pass_frac) * info.pairs
                 dct_ms = kt["dct_quant"] / nl["dct_quant"]
-                dct_gbps = dct_bytes / (dct_ms * 1e-3) / 1e9
+                dct_gbps = dct_bytes / (kt["dct_quant"] * 1e-3) / 1e9
                 # one figure per kernel variant: records (+ luma plane) with --wire read once, planes + luma plane when the step speculated,
                 # the plain transform in the two-pass order (none was collected for --wire --two-bgr-passes)
                 dct_key = ("dct_records_bytes_per_launch" if one_pass else "dct_records_two_passes_bytes_per_launch") if args.wire else \
                     ("dct_luma_bytes_per_launch" if one_pass else "dct_bytes_per_launch")
-                dct_traffic, dct_traffic_source = traffic("dct", dct_key, info.pairs)
+                dct_traffic, dct_traffic_source = traffic("dct", dct_key, info.pairs) if one_pass_frac in (0.0, 1.0) else (None, "null: the timed region mixed both transform kernels")
+                if dct_traffic is not None:
+                    dct_traffic /= nl["dct_quant"]
                 out["roofline_dct"] = {
-                    "kernel": (f"dct_kernel<{cfg.dct_block}, quant, luma, speculative> (every tile quantised as background + the luma plane from one pass over the BGR clip; "
+                    "kernel": ((f"MIXED over the timed region ({pol['speculated']} of {pol['chunk_launches']} launches speculative): " if 0 < one_pass_frac < 1 else "") +
+                               f"dct_kernel<{cfg.dct_block}, quant, luma, speculative> (every tile quantised as background + the luma plane from one pass over the BGR clip; "
                                "the foreground tiles are redone in type_patch)" if one_pass and not args.wire else
                                f"dct_kernel<{cfg.dct_block}, records, luma> (records of the raw coefficients + the luma plane from one pass over the BGR clip)" if one_pass else
                                f"dct_kernel<{cfg.dct_block}, records> (raw coefficients, libs/encoder.cpp:638-650)" if args.wire else
@@ -787,13 +884,14 @@ def main() -> None:
                     "frac": dct_gbps / HBM_PEAK_GBPS,
                     "traffic": dct_traffic,
                     "traffic_source": dct_traffic_source,
-                    "algorithmic_bytes_per_launch": dct_bytes, "avg_launch_ms": dct_ms, "launches_per_step": nl["dct_quant"],
+                    "algorithmic_bytes_per_launch": dct_bytes / nl["dct_quant"], "frames_per_launch": info.pairs / nl["dct_quant"],
+                    "avg_launch_ms": dct_ms, "launches_per_step": nl["dct_quant"],
                 }
         if world == 1 and "hbma" in kt and "dct_quant" in kt:
             # the whole step against the same peak: the three main-stream kernels run back to back and are all
             # HBM-bound, so (their algorithmic bytes) / (step time) says how far the STEP is from the roofline
             step_bytes = cfg.luma_pyramid_bytes_per_frame() * info.frames + hbma_bytes + dct_bytes
-            if one_pass:
+            if one_pass_frac == 1:
                 # BGR in once, pyramid out, coefficients out: what the one-pass form must move (the transform's figure above already holds the BGR
                 # read and the luma plane's store; left of the pyramid stage are the first frame's own luma pass and the levels above 0)
                 step_bytes = hbma_bytes + dct_bytes + cfg.luma_pyramid_bytes_per_frame() * (info.frames - info.pairs) + \
@@ -805,6 +903,8 @@ def main() -> None:
                                              "tiles is not counted as algorithmic bytes); the same step as two passes moves 3 W H more per frame" if one_pass else
                                              "luma+pyramid, motion search and transform of one step / ms_per_step; "
                                              "RANSAC + segmentation move < 1 % of these bytes")}
+        if r.get("first_encode"):
+            out["first_encode"] = r["first_encode"]
         if r.get("sustained"):
             out["sustained_ms_per_step"] = r["sustained"]["ms_per_step"]
             out["sustained"] = {**r["sustained"], "value": r["encoded_per_step"] / (r["sustained"]["ms_per_step"] * 1e-3), "unit": "frames/s",

@@ -89,6 +89,10 @@ struct ClipEncoderConfig {
   bool narrow_attempts = false;         // segmentation: one workgroup per (frame, attempt) whatever the shard size (SVC_LAUNCH_NO_WIDE)
   bool two_bgr_passes = false;          // never the one-pass forms: luma + pyramid, later the transform, two passes over the BGR clip (A/B)
   bool always_speculate = false;        // planes + quant: the speculative one-pass form on every step, whatever the foreground share
+  // Not tuning but a statement about the input: LoadFrames() brings consecutive pieces of ONE stream, so the foreground share measured on the
+  // last piece stays the policy's prior for the next (default: a load voids it; the first step over new frames is then two passes)
+  bool keep_foreground_prior = false;
+  uint32_t chunk_pairs = 0;             // pipelined, one rank: frame pairs per chunk of a step; 0 = the driver's choice (see "Chunks" above)
 };
 
 enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kTypePatch, kCount };
@@ -133,6 +137,13 @@ class ClipEncoder {
   void StageTime(Stage s, double* total_ms, uint32_t* launches);
   void ResetTimers();
   uint32_t steps_submitted() const;
+  uint32_t chunks_per_step() const;  // launches of every stage per Step()
+  uint32_t output_sets() const;      // sets the coefficient planes / records exist in
+
+  // The speculation policy: forget what it has measured (Sync()s first); what it did so far -- chunk launches that had the choice, those that
+  // speculated, the newest foreground share known (-1: none).
+  void ResetPolicy();
+  void PolicyInfo(uint64_t* chunks_decided, uint64_t* chunks_speculated, double* foreground_share);
 
   // Device pointer + size of the NEWEST finished step's output; Sync()s first.
   void* Output(Buffer b, uint64_t* bytes);

@@ -65,6 +65,22 @@ struct EncodedBatch {
                                             // open the reference's stream (libs/codec.hpp:8-17, encoder.cpp:360-381)
 };
 
+// Where the time of one Encode() went (round 6: the PCIe-inclusive rate explains itself).  Host clocks are wall time of the CALLING thread;
+// the three device figures are HIP-event times summed over the batches (the streams overlap: they do not add up to the wall time, the
+// largest of them bounds it).
+struct EncodeStats {
+  uint32_t batches = 0, encoded_frames = 0;
+  uint32_t copy_threads = 0;  // threads that stage a source frame into the pinned buffer (the caller's included)
+  uint32_t host_cores = 0;    // cores this process may run on (sched_getaffinity)
+  double wall_ms = 0;
+  double staging_ms = 0;       // host: source frames -> pinned batch buffer (the copy crew), RANSAC draws
+  double slot_wait_ms = 0;     // host: waiting for a batch slot whose previous results are still on their way back
+  double deliver_wait_ms = 0;  // host: waiting for a batch's results before handing it to the sink
+  double sink_ms = 0;          // host: inside the caller's sink
+  double h2d_ms = 0, kernels_ms = 0, d2h_ms = 0;  // device, per stream
+  uint64_t h2d_bytes = 0, d2h_bytes = 0;
+};
+
 class StreamEncoder {
  public:
   using Sink = std::function<void(const EncodedBatch&)>;
@@ -89,6 +105,7 @@ class StreamEncoder {
 
   uint32_t padded_width() const;
   uint32_t padded_height() const;
+  const EncodeStats& last_stats() const;  // of the last Encode() that returned
 
  private:
   struct Impl;

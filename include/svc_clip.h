@@ -35,6 +35,10 @@ typedef struct svc_clip svc_clip;
                                               planes + quant speculates -- every tile quantised as background at the front of the step, the foreground
                                               tiles redone -- while the foreground share of recent steps is small (clip_encoder.hpp) */
 #define SVC_CLIP_TUNE_ALWAYS_SPECULATE 32u /* planes + quant: speculate on every step, whatever the foreground share (tests, A/B) */
+/* Not a tuning switch but a statement about the input (same field): the clips handed to svc_clip_load_frames are consecutive pieces of ONE
+ * stream, so the foreground share measured on the last piece stays the speculation policy's prior for the next (default: a load voids it and
+ * the first step over new frames runs the plain two-pass order).  Safe at any share: a stale prior costs one slow step, never a byte. */
+#define SVC_CLIP_KEEP_FOREGROUND_PRIOR 64u
 
 typedef struct svc_clip_config {
   uint32_t struct_size;   /* sizeof(svc_clip_config) of the caller's build: svc_clip_create refuses any other value, so a
@@ -52,8 +56,9 @@ typedef struct svc_clip_config {
   uint32_t clip_frames; /* frames of the whole clip */
   uint32_t rank, world; /* this handle holds shard `rank` of `world` */
   uint32_t schedule;    /* SVC_CLIP_SERIAL / SVC_CLIP_PIPELINED */
-  uint32_t reserved0;   /* 0 (was `graph` through round 3: replaying the iteration from a hipGraph measured slower than the eager
-                           pipelined schedule on every workload, profiles/r04_ab_graph.txt, and was removed) */
+  uint32_t chunk_pairs; /* pipelined, one rank: frame pairs per chunk of a step (a step's stages overlap each other chunk by chunk, so a
+                           clip encoded ONCE does not pay RANSAC + segmentation end to end; clip_encoder.hpp); 0 = the driver's choice.
+                           (Was `reserved0`, always 0, through round 5.) */
   /* Tuning; all zero = the defaults.  These are the A/B switches of the measurements under profiles/ -- they change
    * launch shapes and kernel choice, never results. */
   uint32_t hbma_flags;  /* SVC_HBMA_* passed to svc_hip_hbma_pairs (0 = SVC_HBMA_AUTO) */
@@ -65,6 +70,9 @@ typedef struct svc_clip_info {
   uint32_t padded_w, padded_h, mv_field_w, mv_field_h, blocks, ransac_iters;
   uint64_t pyramid_stride, frame_bytes, record_bytes;
   uint32_t first_frame, frames, pairs, first_encoded, needs_halo;
+  uint32_t chunks_per_step; /* launches of every stage per svc_clip_step (1 = whole-shard launches) */
+  uint32_t output_sets;     /* sets the coefficient planes / records exist in (memory: output_sets x pairs x frame's output) */
+  uint32_t reserved;
 } svc_clip_info;
 
 /* stage ids for svc_clip_stage_time */
@@ -107,6 +115,11 @@ int svc_clip_sync(svc_clip* clip);            /* flush + wait for the GPU */
 /* HIP-event time of a stage summed over the timed steps, and the launches it covers. */
 int svc_clip_stage_time(svc_clip* clip, uint32_t stage, double* total_ms, uint32_t* launches);
 int svc_clip_reset_timers(svc_clip* clip);
+
+/* The speculation policy (planes + quant, clip_encoder.hpp): forget what it has measured (syncs first) ... */
+int svc_clip_reset_policy(svc_clip* clip);
+/* ... and what it did so far: chunk launches that had the choice, those that speculated, the newest foreground share known (-1: none). */
+int svc_clip_policy_info(svc_clip* clip, uint64_t* chunks_decided, uint64_t* chunks_speculated, double* foreground_share);
 
 /* The newest finished step's output (syncs first). */
 int svc_clip_output(svc_clip* clip, uint32_t buffer, void** d_ptr, uint64_t* bytes);

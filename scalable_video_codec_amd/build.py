@@ -64,7 +64,7 @@ def _run(cmd: List[str]) -> None:
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "svc_common.hpp"), os.path.join(CSRC, "union_find.hpp"), os.path.join(CSRC, "hbma_search.hpp"), os.path.join(CSRC, "hbma_fused_kernel.hpp"), os.path.join(CSRC, "dct_tables.inc"), os.path.join(CSRC, "luma16.hpp"),
-               os.path.join(INCLUDE, "svc_hip.h")]
+               os.path.join(CSRC, "host", "copy_crew.hpp"), os.path.join(INCLUDE, "svc_hip.h")]
     jobs, objs = [], []
     for s in HIP_SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
@@ -89,7 +89,7 @@ def build_motion(force: bool = False) -> str:
     """The C++ layer above the C ABI: the reference's motion.hpp entry points (plain C++, g++) and the
     batched host-memory encoder (uses the HIP runtime for buffers, streams and events: hipcc, host only)."""
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
-    deps = srcs + [STREAM_SRC, CLIP_SRC, os.path.join(INCLUDE, "svc_hip.h"), os.path.join(INCLUDE, "svc_clip.h")] + \
+    deps = srcs + [STREAM_SRC, CLIP_SRC, os.path.join(CSRC, "host", "copy_crew.hpp"), os.path.join(INCLUDE, "svc_hip.h"), os.path.join(INCLUDE, "svc_clip.h")] + \
         [os.path.join(INCLUDE, "svc", h) for h in ("motion.hpp", "math.hpp", "types.hpp", "stream_encoder.hpp",
                                                     "clip_encoder.hpp")]
     if force or not _newer(LIB_MOTION, deps + [LIB_HIP]):
@@ -143,7 +143,7 @@ def build_compat(force: bool = False) -> str:
     """compat/opencv2: the slice of the OpenCV API the reference's encoder uses, every arithmetic call forwarding to
     include/svc_hip.h (a product-side adapter -- never an oracle).  Plain C++ on top of the C ABI."""
     srcs = [os.path.join(COMPAT, "src", f) for f in ("core.cpp", "imgproc.cpp", "videoio.cpp")]
-    hdrs = [os.path.join(COMPAT, "src", "internal.hpp"), os.path.join(INCLUDE, "svc_hip.h")] + \
+    hdrs = [os.path.join(COMPAT, "src", "internal.hpp"), os.path.join(CSRC, "host", "copy_crew.hpp"), os.path.join(INCLUDE, "svc_hip.h")] + \
         [os.path.join(COMPAT, "opencv2", f) for f in ("core.hpp", "imgproc.hpp", "videoio.hpp", os.path.join("core", "mat.hpp"))]
     if force or not _newer(LIB_COMPAT, srcs + hdrs + [LIB_HIP]):
         cxx = shutil.which("g++") or "g++"

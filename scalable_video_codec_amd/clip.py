@@ -20,6 +20,7 @@ _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
 
 SERIAL, PIPELINED = 0, 1
 TUNE_STANDALONE_SHAPES, TUNE_SEGMENT_FORK, TUNE_NARROW_ATTEMPTS, TUNE_INLINE_RMSE, TUNE_TWO_BGR_PASSES, TUNE_ALWAYS_SPECULATE = 1, 2, 4, 8, 16, 32  # svc_clip_config.tuning bits
+KEEP_FOREGROUND_PRIOR = 64  # same field: the clips loaded are consecutive pieces of one stream (the policy keeps its prior across load_frames)
 STAGES = ("luma_pyramid", "halo_exchange", "hbma", "ransac", "segment", "dct_quant", "type_patch")
 BUFFERS = {"mv": (0, torch.float32), "min_mad": (1, torch.float32), "global_motion": (2, torch.float32),
            "rmse": (3, torch.float32), "inlier_mask": (4, torch.uint8), "inlier_count": (5, torch.int32),
@@ -32,14 +33,14 @@ class ClipConfig(C.Structure):
     _fields_ = [("struct_size", _u32), ("width", _u32), ("height", _u32), ("levels", _u32), ("mv_block", _u32), ("search_range", _u32),
                 ("dct_block_w", _u32), ("dct_block_h", _u32), ("fg_step", _u32), ("bg_step", _u32), ("wire", _u32),
                 ("segmentation", _u32), ("seed", _u64), ("ransac", RansacParams), ("segment", SegmentParams),
-                ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("reserved0", _u32),
+                ("clip_frames", _u32), ("rank", _u32), ("world", _u32), ("schedule", _u32), ("chunk_pairs", _u32),
                 ("hbma_flags", _u32), ("lat_depth", _u32), ("tuning", _u32)]
 
 
 class ClipInfo(C.Structure):
     _fields_ = [(n, _u32) for n in ("padded_w", "padded_h", "mv_field_w", "mv_field_h", "blocks", "ransac_iters")] + \
                [(n, _u64) for n in ("pyramid_stride", "frame_bytes", "record_bytes")] + \
-               [(n, _u32) for n in ("first_frame", "frames", "pairs", "first_encoded", "needs_halo")]
+               [(n, _u32) for n in ("first_frame", "frames", "pairs", "first_encoded", "needs_halo", "chunks_per_step", "output_sets", "reserved")]
 
 
 HALO_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _u64, _vp, _vp)
@@ -59,6 +60,8 @@ SIGNATURES = {
     "svc_clip_sync": (C.c_int, [_vp]),
     "svc_clip_stage_time": (C.c_int, [_vp, _u32, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "svc_clip_reset_timers": (C.c_int, [_vp]),
+    "svc_clip_reset_policy": (C.c_int, [_vp]),
+    "svc_clip_policy_info": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(C.c_double)]),
     "svc_clip_output": (C.c_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u64)]),
     "svc_clip_read": (C.c_int, [_vp, _u32, _u64, _vp, _u64, C.c_int]),
 }
@@ -143,7 +146,7 @@ class Clip:
     def __init__(self, cfg: CodecConfig, clip_frames: int, rank: int = 0, world: int = 1, schedule: int = PIPELINED,
                  segmentation: bool = True, wire: bool = False, seed: Optional[int] = None,
                  ransac: Optional[dict] = None, segment: Optional[dict] = None, dct_block: Optional[Tuple[int, int]] = None,
-                 hbma_flags: int = 0, lat_depth: int = 0, tuning: int = 0):
+                 hbma_flags: int = 0, lat_depth: int = 0, tuning: int = 0, chunk_pairs: int = 0):
         self.cfg = cfg
         r = dict(subset_sz=1, inlier_thresh=7.5, success_prob=0.99, inlier_ratio=0.5)
         r.update(ransac or {})
@@ -153,7 +156,7 @@ class Clip:
         self.config = ClipConfig(C.sizeof(ClipConfig), cfg.width, cfg.height, cfg.levels, cfg.mv_block, cfg.search_range, bw, bh,
                                  cfg.fg_step, cfg.bg_step, int(wire), int(segmentation),
                                  cfg.seed if seed is None else seed, RansacParams(**r), SegmentParams(**s),
-                                 clip_frames, rank, world, schedule, 0, hbma_flags, lat_depth, tuning)
+                                 clip_frames, rank, world, schedule, chunk_pairs, hbma_flags, lat_depth, tuning)
         self._h = _vp()
         self._cb = None  # keeps the ctypes callback alive
         _check(load().svc_clip_create(C.byref(self.config), C.byref(self._h)))
@@ -218,6 +221,22 @@ class Clip:
 
     def reset_timers(self) -> None:
         _check(load().svc_clip_reset_timers(self._h))
+
+    def output_sets(self) -> int:
+        """Sets the coefficient planes / records exist in NOW (planes: the extra sets appear with the first speculative step)."""
+        i = ClipInfo()
+        _check(load().svc_clip_get_info(self._h, C.byref(i)))
+        return i.output_sets
+
+    def reset_policy(self) -> None:
+        """Forget what the speculation policy has measured (what load_frames does unless KEEP_FOREGROUND_PRIOR)."""
+        _check(load().svc_clip_reset_policy(self._h))
+
+    def policy_info(self) -> Dict[str, float]:
+        """Chunk launches that had the choice to speculate, those that did, the newest foreground share known (-1: none)."""
+        a, b, f = _u64(), _u64(), C.c_double()
+        _check(load().svc_clip_policy_info(self._h, C.byref(a), C.byref(b), C.byref(f)))
+        return {"chunks_decided": a.value, "chunks_speculated": b.value, "foreground_share": f.value}
 
     def stage_times_ms(self) -> Dict[str, Tuple[float, int]]:
         """stage -> (summed HIP-event ms over the timed steps, launches covered)."""

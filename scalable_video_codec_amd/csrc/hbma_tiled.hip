@@ -25,6 +25,10 @@
 
 #include "hbma_search.hpp"
 
+#ifndef SVC_HBMA_L0_CEILING
+#define SVC_HBMA_L0_CEILING 0
+#endif
+
 namespace svc {
 
 template <int B, int M, int RT, int TBX, int TBY>
@@ -199,6 +203,13 @@ __global__ __launch_bounds__((TBX * TBY + 63) / 64 * 64) void hbma_tiled16_kerne
   mvx *= 2; mvy *= 2;
   search_level_lds<8, RT, 2, G1>(lds0, x1, y1, a1r, w >> 1, h >> 1, bx, by, mvx, mvy, best);
   mvx *= 2; mvy *= 2;
+#if SVC_HBMA_L0_CEILING
+  // TIMING EXPERIMENT ONLY (wrong results; tools/ab_hbma_l0_ceiling.sh): what level 0 would cost if the field were coherent -- every lane's
+  // window on its block's own rows (1), and at its block's own columns as well (2).  The kernel's ceiling for any scheme that only reorders or
+  // stages level 0's reads: profiles/r06_ab_hbma_tiled_level0.txt.
+  mvy = 0;
+  if (SVC_HBMA_L0_CEILING >= 2) mvx = 0;
+#endif
   search_level<16, RT, false, 0>(trk, anc, w, h, bx, by, mvx, mvy, best);
 
   if (live) {

@@ -20,6 +20,14 @@ namespace {
 void Hip(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("svc::ClipEncoder: ") + what + ": " + hipGetErrorString(e));
 }
+// an event that has not completed yet is "not ready"; any other status is an error of an earlier launch and is reported HERE, where it
+// is first seen, not swallowed as "no news yet"
+bool Ready(hipEvent_t e) {
+  const hipError_t q = hipEventQuery(e);
+  if (q == hipErrorNotReady) return false;
+  Hip(q, "hipEventQuery");
+  return true;
+}
 void Abi(int rc, const char* what) {
   if (rc) throw std::runtime_error(std::string("svc::ClipEncoder: ") + what + ": " + svc_hip_last_error());
 }
@@ -74,6 +82,17 @@ struct ClipEncoder::Impl {
   // stream l % depth), and the small per-step buffers exist in depth + 2 sets (step s uses set s % nsets).
   static constexpr int kMaxDepth = 3, kSets = kMaxDepth + 2;
   int depth = 1, nsets = 1;
+  // Chunks (round 6).  A step's pass over the shard is cut into `nch` consecutive runs of `cp` frame pairs, and what the pipeline moves is a
+  // MICRO-STEP m = (step m / nch, chunk m % nch): every stage launch covers one chunk.  With nch = 1 this is the schedule of rounds 2-5 (a
+  // pipeline over consecutive whole-shard steps).  With nch > 1 the stages of ONE step overlap each other -- RANSAC + segmentation of chunk c
+  // run beside the motion search of chunk c + 1 and the transform of chunk c - 1 -- so a clip that is encoded ONCE (LoadFrames, Step, Sync)
+  // no longer pays the latency-bound stages end to end.  Buffers: chunk c of step s lives at offset p0(c) inside set s % nsets; events and
+  // "pending" flags are per micro-step slot m % nsets (at most depth + 2 micro-steps are in flight).
+  uint32_t nch = 1, cp = 0;
+  uint32_t StepOf(uint64_t m) const { return (uint32_t)(m / nch); }
+  uint32_t P0(uint64_t m) const { return (uint32_t)(m % nch) * cp; }                    // first pair of the micro-step's chunk
+  uint32_t Pn(uint64_t m) const { return std::min<uint32_t>(cp, sh.pairs - std::min(sh.pairs, P0(m))); }  // its pairs
+  int Slot(uint64_t m) const { return (int)(m % (uint64_t)nsets); }
   hipStream_t sM = nullptr, sL[kMaxDepth] = {nullptr, nullptr, nullptr}, sC = nullptr;
   DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records[kSets + 1];
   DevBuf<float> mv[kSets], mad[kSets], gm[kSets], rmse[kSets], coeffs[kSets + 1];
@@ -100,14 +119,36 @@ struct ClipEncoder::Impl {
   // nsets + 1 of them: the front of step s + nsets + 1 rewrites the set in the iteration AFTER the one whose last launch completed step s's
   // records (with nsets it would be the same iteration, and the front runs first)
   int rec_sets = 1;
-  DevBuf<uint8_t>& Records(uint64_t s) { return records[(int)(s % (uint64_t)rec_sets)]; }
+  DevBuf<uint8_t>& Records(uint64_t m) { return records[(int)(StepOf(m) % (uint32_t)rec_sets)]; }
   // The same for planes + quant: the transform runs at the front of the step with every tile quantised as background and leaves the luma
   // plane (svc_hip_dct_quant_luma_frames); the tiles of foreground MV blocks are redone with fg_step where the transform used to run
   // (svc_hip_dct_quant_redo_frames).  Coefficient planes then exist in rec_sets sets too.
   bool spec_quant = false;  // the configuration CAN speculate; whether a step does is spec_step[]
-  DevBuf<float>& Coeffs(uint64_t s) { return coeffs[spec_quant ? (int)(s % (uint64_t)rec_sets) : 0]; }
-  bool spec_step[kSets + 1] = {};  // step s speculated (indexed like the record / coefficient sets)
-  bool& SpecStep(uint64_t s) { return spec_step[(int)(s % (uint64_t)rec_sets)]; }
+  // The extra coefficient sets are allocated the first time the policy decides to speculate (a clip that never does -- C3b and C5 measure
+  // 13 % foreground -- keeps one set: 4 x 7.5 GB at C3, 4 x 6.3 GB at C5 that round 5 allocated for nothing); until then every step uses set 0.
+  int coeff_sets = 1;  // sets that exist
+  DevBuf<float>& Coeffs(uint64_t m) { return coeffs[coeff_sets > 1 ? (int)(StepOf(m) % (uint32_t)coeff_sets) : 0]; }
+  // Called at the top of an iteration that is about to speculate for the first time, before anything of it is enqueued: the pipeline is
+  // drained first (every earlier micro-step wrote, or will write, set 0 -- once their launches are all in the streams, stream order keeps
+  // the rotation that starts now behind them).  If the memory is not there, the shard simply never speculates.
+  bool GrowCoeffSets() {
+    if (coeff_sets == rec_sets) return true;
+    while (n_dct < n_luma) Iterate(false, last_timed);
+    for (int b = 1; b < rec_sets; ++b) {
+      float* q = nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&q), std::max<size_t>(coeffs[0].n, 1) * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: clear it
+        for (int k = 1; k < b; ++k) { (void)hipFree(coeffs[k].p); coeffs[k].p = nullptr; coeffs[k].n = 0; }
+        spec_quant = false;       // two passes from here on
+        return false;
+      }
+      coeffs[b].p = q; coeffs[b].n = coeffs[0].n;
+    }
+    coeff_sets = rec_sets;
+    return true;
+  }
+  bool spec_step[kSets + 1] = {};  // micro-step m speculated (a ring over the micro-steps in flight)
+  bool& SpecStep(uint64_t m) { return spec_step[(int)(m % (uint64_t)(kSets + 1))]; }
   // The policy's feedback: after the segmentation of a step a counting kernel + a 4-byte copy leave the step's number of foreground MV
   // blocks in pinned host memory; nobody waits for it -- a step decides on the newest count that has arrived by then.
   static constexpr int kFgSlots = 8;
@@ -115,33 +156,51 @@ struct ClipEncoder::Impl {
   // small shards do not pay: the front-of-step transform costs a fixed ~10 us more than it saves below ~25 frames of 1080p
   // (profiles/r05_ab_speculative_quant.txt: 1080p shards of 150 / 75 / 38 / 19 frames -6 / -4 / -2 / +-1 %; C2's 29 frames of 720p +5 %)
   static constexpr uint64_t kSpecMinPixels = 50000000ull;  // encoded frames x padded pixels of the shard
+  // a chunk: at least this many pixels x frames, and at most this many chunks per step.  Measured (profiles/r06_ab_chunks.txt): C3 in two
+  // chunks encodes a clip once in 2.49 instead of 2.63 ms at +0.5 % on the steady state; three and five chunks lose more in launches than
+  // they hide; C5's 63 frames of 4K lose 4 % of the steady state to two chunks (its kernels' tails) and stay whole
+  static constexpr uint64_t kChunkMinPixels = 300000000ull;
+  static constexpr uint32_t kMaxAutoChunks = 2;
   DevBuf<uint32_t> fg_dev;
   uint32_t* fg_host = nullptr;
   hipEvent_t e_fg[kFgSlots] = {};
   bool fg_pending[kFgSlots] = {};
+  uint64_t fg_blocks[kFgSlots] = {};  // MV blocks the slot's count was taken over (a chunk's)
   uint64_t n_fg = 0;
   double fg_share = -1.0;  // newest foreground share known (-1: none yet)
-  void MeasureForeground(int set, hipStream_t st) {
-    if (!spec_quant || c.two_bgr_passes || c.always_speculate || !sh.pairs) return;  // only the adaptive policy asks
+  uint64_t n_spec = 0, n_decided = 0;  // micro-steps that speculated / that had the choice (PolicyInfo)
+  void MeasureForeground(uint64_t m, hipStream_t st) {
+    if (!spec_quant || c.two_bgr_passes || c.always_speculate || !Pn(m)) return;  // only the adaptive policy asks
     const int slot = (int)(n_fg % kFgSlots);
-    if (fg_pending[slot] && hipEventQuery(e_fg[slot]) != hipSuccess) return;  // eight measurements in flight: skip this one
-    Abi(svc_hip_count_foreground(types[set].p, (uint64_t)sh.pairs * blocks, fg_dev.p + slot, st), "svc_hip_count_foreground");
+    if (fg_pending[slot] && !Ready(e_fg[slot])) return;  // eight measurements in flight: skip this one
+    Abi(svc_hip_count_foreground(types[Set(m)].p + (uint64_t)P0(m) * blocks, (uint64_t)Pn(m) * blocks, fg_dev.p + slot, st), "svc_hip_count_foreground");
     Hip(hipMemcpyAsync(fg_host + slot, fg_dev.p + slot, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
     Hip(hipEventRecord(e_fg[slot], st), "hipEventRecord");
     fg_pending[slot] = true;
+    fg_blocks[slot] = (uint64_t)Pn(m) * blocks;
     ++n_fg;
   }
   bool DecideSpeculation() {
     if (!spec_quant || c.two_bgr_passes) return false;
-    if (c.always_speculate) return true;
-    for (uint64_t k = n_fg; k > 0 && k + kFgSlots > n_fg; --k) {  // newest first
-      const int slot = (int)((k - 1) % kFgSlots);
-      if (!fg_pending[slot]) continue;
-      if (hipEventQuery(e_fg[slot]) != hipSuccess) continue;
-      fg_share = (double)fg_host[slot] / ((double)sh.pairs * blocks);
-      break;
+    ++n_decided;
+    bool yes = c.always_speculate;
+    if (!yes) {
+      for (uint64_t k = n_fg; k > 0 && k + kFgSlots > n_fg; --k) {  // newest first
+        const int slot = (int)((k - 1) % kFgSlots);
+        if (!fg_pending[slot]) continue;
+        if (!Ready(e_fg[slot])) continue;
+        fg_share = (double)fg_host[slot] / (double)fg_blocks[slot];
+        break;
+      }
+      yes = fg_share >= 0.0 && fg_share <= kSpecMaxShare;
     }
-    return fg_share >= 0.0 && fg_share <= kSpecMaxShare;
+    n_spec += yes;
+    return yes;
+  }
+  void ResetPolicy() {  // what the policy knew is void (the caller has Sync()ed: every measurement has landed)
+    fg_share = -1.0;
+    n_fg = 0;
+    for (bool& p : fg_pending) p = false;
   }
   bool last_timed = false;  // Flush() times the rest of a step that was submitted timed
   // timing
@@ -181,44 +240,56 @@ struct ClipEncoder::Impl {
     timed[(uint32_t)st].emplace_back(a, b);
   }
 
-  // pyramid set of step s: the pipelined schedule alternates two, the serial one has one
-  int Par(uint64_t s) const { return c.schedule == Schedule::kPipelined ? (int)(s & 1) : 0; }
-  // set of the small per-step buffers (motion field, RANSAC outputs, region ids) of step s
-  int Set(uint64_t s) const { return (int)(s % (uint64_t)nsets); }
+  // pyramid set of micro-step m's step: the pipelined schedule alternates two, the serial one has one
+  int Par(uint64_t m) const { return c.schedule == Schedule::kPipelined ? (int)(StepOf(m) & 1u) : 0; }
+  // set of the small per-step buffers (motion field, RANSAC outputs, region ids) of micro-step m's step
+  int Set(uint64_t m) const { return (int)(StepOf(m) % (uint32_t)nsets); }
 
-  // ---- the stages; `s` is the step index, its buffers are those of set Par(s) ---------------
-  void Luma(uint64_t s, hipStream_t st, bool timing) {
-    const int b = Par(s);
-    if (spec_quant) SpecStep(s) = DecideSpeculation();
-    if (one_bgr_pass || (spec_quant && SpecStep(s))) {
-      // own frame j lives in pyramid slot 1 + j; encoded frame p is own frame p (halo in slot 0) or p + 1 (frame 0 is tracked only)
-      const uint32_t skip = sh.needs_halo ? 0u : 1u;
-      uint8_t* slots = pyr[b].p + (uint64_t)(1 + skip) * pyr_stride;
+  // ---- the stages; `m` is the micro-step, its buffers are chunk P0(m) .. + Pn(m) of the sets Par(m) / Set(m) ---------------
+  // own frame j lives in pyramid slot 1 + j; encoded frame (pair) p is own frame p + skip (skip = 1: frame 0 of the clip is tracked only,
+  // skip = 0: the tracked frame of pair 0 is the halo in slot 0)
+  uint32_t Skip() const { return sh.needs_halo ? 0u : 1u; }
+  bool decided = false;  // this micro-step speculates
+  void Decide(uint64_t m) {
+    decided = spec_quant && Pn(m) && DecideSpeculation();
+    if (decided && !GrowCoeffSets()) decided = false;
+  }
+  void Luma(uint64_t m, hipStream_t st, bool timing) {
+    const int b = Par(m);
+    const uint32_t p0 = P0(m), pn = Pn(m), skip = Skip();
+    const bool first_chunk = m % nch == 0;
+    if (spec_quant) SpecStep(m) = pn ? decided : false;  // decided at the top of the iteration (Iterate / SerialStep)
+    if (pn && (one_bgr_pass || (spec_quant && SpecStep(m)))) {
+      const uint8_t* enc = bgr.p + (uint64_t)(skip + p0) * frame_bytes;
+      uint8_t* slots = pyr[b].p + (uint64_t)(1 + skip + p0) * pyr_stride;
       Run(Stage::kTransform, st, timing, [&] {
         if (!one_bgr_pass)
-          Abi(svc_hip_dct_quant_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.bg_step,
-                                            Coeffs(s).p, slots, pyr_stride, st), "svc_hip_dct_quant_luma_frames");
+          Abi(svc_hip_dct_quant_luma_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, c.bg_step,
+                                            Coeffs(m).p + (uint64_t)p0 * 3 * plane_elems, slots, pyr_stride, st), "svc_hip_dct_quant_luma_frames");
         else
-          Abi(svc_hip_dct_records_luma_frames(bgr.p + (uint64_t)skip * frame_bytes, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, ph,
-                                              Records(s).p, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
+          Abi(svc_hip_dct_records_luma_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, ph,
+                                              Records(m).p + (uint64_t)p0 * record_bytes, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
       });
       Run(Stage::kLumaPyramid, st, timing, [&] {
-        if (skip)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
+        if (skip && first_chunk)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
           Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, 1, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
               "svc_hip_luma_pyramid_frames");
-        Abi(svc_hip_pyramid_levels_frames(slots, pyr_stride, sh.pairs, pw, ph, c.levels, st), "svc_hip_pyramid_levels_frames");
+        Abi(svc_hip_pyramid_levels_frames(slots, pyr_stride, pn, pw, ph, c.levels, st), "svc_hip_pyramid_levels_frames");
       });
       return;
     }
+    // the chunk's own frames (the first chunk of a shard without a halo also holds the clip's tracked-only frame 0)
+    const uint32_t f0 = first_chunk ? 0u : p0 + skip, f1 = p0 + pn + skip;
+    if (f1 <= f0) return;
     Run(Stage::kLumaPyramid, st, timing, [&] {
-      Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, sh.frames, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
-          "svc_hip_luma_pyramid_frames");
+      Abi(svc_hip_luma_pyramid_frames(bgr.p + (uint64_t)f0 * frame_bytes, frame_bytes, f1 - f0, pw, ph, c.levels,
+                                      pyr[b].p + (uint64_t)(1 + f0) * pyr_stride, pyr_stride, st), "svc_hip_luma_pyramid_frames");
     });
   }
 
-  // my last pyramid -> rank + 1's slot 0; slot 0 <- rank - 1's last pyramid
-  void Halo(uint64_t s, bool timing) {
-    const int b = Par(s);
+  // my last pyramid -> rank + 1's slot 0; slot 0 <- rank - 1's last pyramid  (world > 1: one chunk per step)
+  void Halo(uint64_t m, bool timing) {
+    const int b = Par(m);
     Hip(hipEventRecord(e_pyr[b], sM), "hipEventRecord");
     Hip(hipStreamWaitEvent(sC, e_pyr[b], 0), "hipStreamWaitEvent");
     Run(Stage::kHalo, sC, timing, [&] {
@@ -231,30 +302,40 @@ struct ClipEncoder::Impl {
     halo_recorded[b] = true;
   }
 
-  void Hbma(uint64_t s, hipStream_t st, bool timing) {
-    if (!sh.pairs) return;
-    const int b = Par(s), q = Set(s);
-    const uint64_t t0 = sh.needs_halo ? 0 : 1;  // slot of the first tracked pyramid
-    if (rmse_pending[q]) {  // the deferred RMSE kernel of the set's previous step still reads the motion field this rewrites
-      Hip(hipStreamWaitEvent(st, e_rmse[q], 0), "hipStreamWaitEvent");
-      rmse_pending[q] = false;
+  void Hbma(uint64_t m, hipStream_t st, bool timing) {
+    const uint32_t p0 = P0(m), pn = Pn(m);
+    if (!pn) return;
+    const int b = Par(m), q = Set(m), k = Slot(m);
+    const uint64_t t0 = (sh.needs_halo ? 0 : 1) + p0;  // slot of the chunk's first tracked pyramid
+    if (rmse_pending[k]) {  // a deferred RMSE kernel may still read the motion field this rewrites: the slot's newest one is later on its
+      Hip(hipStreamWaitEvent(st, e_rmse[k], 0), "hipStreamWaitEvent");  // stream than the one of this chunk's previous step
+      rmse_pending[k] = false;
     }
     Run(Stage::kHbma, st, timing, [&] {
-      Abi(svc_hip_hbma_pairs(pyr[b].p + t0 * pyr_stride, pyr[b].p + (t0 + 1) * pyr_stride, pyr_stride, sh.pairs, c.levels, pw, ph,
-                             c.search_range, c.mv_block, c.mv_block, mv[q].p, mad[q].p, c.hbma_flags, st), "svc_hip_hbma_pairs");
+      Abi(svc_hip_hbma_pairs(pyr[b].p + t0 * pyr_stride, pyr[b].p + (t0 + 1) * pyr_stride, pyr_stride, pn, c.levels, pw, ph,
+                             c.search_range, c.mv_block, c.mv_block, mv[q].p + (uint64_t)p0 * blocks * 2, mad[q].p + (uint64_t)p0 * blocks,
+                             c.hbma_flags, st), "svc_hip_hbma_pairs");
     });
   }
 
   // RANSAC + region ids: one workgroup per frame, latency-bound
-  void Lat(uint64_t s, hipStream_t st, bool timing) {
-    if (!sh.pairs) return;
-    const int b = Set(s);
-    DevBuf<uint8_t>& ws = seg_ws[c.schedule == Schedule::kPipelined ? (int)(s % (uint64_t)depth) : 0];  // one per stream
-    const uint64_t g0 = sh.first_encoded - 1;  // clip-wide index of the shard's first pair
+  void Lat(uint64_t m, hipStream_t st, bool timing) {
+    const uint32_t p0 = P0(m), pn = Pn(m);
+    if (!pn) return;
+    const int b = Set(m), k = Slot(m);
+    DevBuf<uint8_t>& ws = seg_ws[c.schedule == Schedule::kPipelined ? (int)(m % (uint64_t)depth) : 0];  // one per stream
+    const uint64_t g0 = sh.first_encoded - 1 + p0;  // clip-wide index of the chunk's first pair
+    float* gm_c = gm[b].p + (uint64_t)p0 * 2;
+    float* rmse_c = rmse[b].p + p0;
+    const float* mv_c = mv[b].p + (uint64_t)p0 * blocks * 2;
+    uint8_t* mask_c = mask[b].p + (uint64_t)p0 * blocks;
+    uint32_t* count_c = count[b].p + p0;
+    uint32_t* types_c = types[b].p + (uint64_t)p0 * blocks;
+    const uint32_t* samples_c = samples.p + (uint64_t)p0 * iters * c.ransac.subset_sz;
     Run(Stage::kRansac, st, timing, [&] {
-      Hip(hipMemsetAsync(gm[b].p, 0, gm[b].bytes(), st), "hipMemsetAsync");  // in/out, libs/motion.cpp:241-242
-      Abi(svc_hip_ransac_frames_ex(mv[b].p, blocks, sh.pairs, c.ransac, samples.p, iters, gm[b].p, rmse[b].p, mask[b].p,
-                                   count[b].p, lat_flags | (defer_rmse ? SVC_LAUNCH_DEFER_RMSE : 0u), st), "svc_hip_ransac_frames");
+      Hip(hipMemsetAsync(gm_c, 0, (size_t)pn * 2 * sizeof(float), st), "hipMemsetAsync");  // in/out, libs/motion.cpp:241-242
+      Abi(svc_hip_ransac_frames_ex(mv_c, blocks, pn, c.ransac, samples_c, iters, gm_c, rmse_c, mask_c, count_c,
+                                   lat_flags | (defer_rmse ? SVC_LAUNCH_DEFER_RMSE : 0u), st), "svc_hip_ransac_frames");
     });
     if (defer_rmse && c.world == 1) {
       // the serial tail of RANSAC (one dependent f32 add per MV block) beside the segmentation: it reads what the launch
@@ -266,118 +347,129 @@ struct ClipEncoder::Impl {
       // NEIGHBOUR's receive with it (round 3's ADVICE) -- there the kernel goes behind the segmentation instead (ForkLat).
       Hip(hipEventRecord(e_rfork, st), "hipEventRecord");
       Hip(hipStreamWaitEvent(sC, e_rfork, 0), "hipStreamWaitEvent");
-      Abi(svc_hip_ransac_rmse_frames(mv[b].p, blocks, sh.pairs, c.ransac, gm[b].p, mask[b].p, count[b].p, rmse[b].p, sC),
-          "svc_hip_ransac_rmse_frames");
-      Hip(hipEventRecord(e_rmse[b], sC), "hipEventRecord");
-      rmse_pending[b] = true;
+      Abi(svc_hip_ransac_rmse_frames(mv_c, blocks, pn, c.ransac, gm_c, mask_c, count_c, rmse_c, sC), "svc_hip_ransac_rmse_frames");
+      Hip(hipEventRecord(e_rmse[k], sC), "hipEventRecord");
+      rmse_pending[k] = true;
     }
     Run(Stage::kSegment, st, timing, [&] {
       if (c.segmentation)
-        Abi(svc_hip_segment_frames_ex(mask[b].p, mv[b].p, mfw, mfh, sh.pairs, c.mv_block, c.mv_block, c.segment,
-                                      c.seed * 1000003ull + g0, ws.p, seg_ws_bytes, types[b].p, lat_flags, st),
+        Abi(svc_hip_segment_frames_ex(mask_c, mv_c, mfw, mfh, pn, c.mv_block, c.mv_block, c.segment,
+                                      c.seed * 1000003ull + g0, ws.p, seg_ws_bytes, types_c, lat_flags, st),
             "svc_hip_segment_frames");
       else
-        Abi(svc_hip_block_types_frames(mask[b].p, blocks, sh.pairs, types[b].p, st), "svc_hip_block_types_frames");
+        Abi(svc_hip_block_types_frames(mask_c, blocks, pn, types_c, st), "svc_hip_block_types_frames");
     });
-    MeasureForeground(b, st);
-    if (c.schedule == Schedule::kPipelined && OnePassStep(s)) FinishOnePass(s, st, timing);
+    MeasureForeground(m, st);
+    if (c.schedule == Schedule::kPipelined && OnePassStep(m)) FinishOnePass(m, st, timing);
   }
 
-  bool OnePassStep(uint64_t s) { return one_bgr_pass || (spec_quant && SpecStep(s)); }
+  bool OnePassStep(uint64_t m) { return Pn(m) && (one_bgr_pass || (spec_quant && SpecStep(m))); }
 
   // What a one-pass step still owes once its region ids exist: the type words of the records it emitted at its front (wire), or the tiles
   // of its foreground MV blocks once more with fg_step (planes).  Latency-bound (a list, a few thousand scattered tiles): in the pipelined
   // schedule it runs on the latency stream right behind the segmentation, beside the main stream's kernels, and the main stream only joins.
-  void FinishOnePass(uint64_t s, hipStream_t st, bool timing) {
-    if (!sh.pairs || !c.dct_block_w) return;
-    const int b = Set(s);
-    const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
-    DevBuf<uint8_t>& rws = redo_ws[c.schedule == Schedule::kPipelined ? (int)(s % (uint64_t)depth) : 0];
+  void FinishOnePass(uint64_t m, hipStream_t st, bool timing) {
+    const uint32_t p0 = P0(m), pn = Pn(m);
+    if (!pn || !c.dct_block_w) return;
+    const int b = Set(m);
+    const uint8_t* enc = bgr.p + (uint64_t)(Skip() + p0) * frame_bytes;  // encoded frame of pair p: own frame p + skip
+    const uint32_t* types_c = types[b].p + (uint64_t)p0 * blocks;
+    DevBuf<uint8_t>& rws = redo_ws[c.schedule == Schedule::kPipelined ? (int)(m % (uint64_t)depth) : 0];
     Run(Stage::kTypePatch, st, timing, [&] {
       if (one_bgr_pass)
-        Abi(svc_hip_wire_patch_types_frames(types[b].p, sh.pairs, pw, ph, ph, c.dct_block_w, c.mv_block, c.mv_block, Records(s).p,
-                                            record_bytes, 0, st), "svc_hip_wire_patch_types_frames");
+        Abi(svc_hip_wire_patch_types_frames(types_c, pn, pw, ph, ph, c.dct_block_w, c.mv_block, c.mv_block,
+                                            Records(m).p + (uint64_t)p0 * record_bytes, record_bytes, 0, st), "svc_hip_wire_patch_types_frames");
       else
-        Abi(svc_hip_dct_quant_redo_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block, c.fg_step,
-                                          Coeffs(s).p, rws.p, rws.bytes(), st), "svc_hip_dct_quant_redo_frames");
+        Abi(svc_hip_dct_quant_redo_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, types_c, c.mv_block, c.mv_block, c.fg_step,
+                                          Coeffs(m).p + (uint64_t)p0 * 3 * plane_elems, rws.p, rws.bytes(), st), "svc_hip_dct_quant_redo_frames");
     });
   }
 
-  void Transform(uint64_t s, hipStream_t st, bool timing) {
-    if (!sh.pairs || !c.dct_block_w) return;
-    const int b = Set(s);
-    const uint8_t* enc = bgr.p + (sh.needs_halo ? 0 : frame_bytes);  // encoded frame of pair p: own frame first_local + p
-    if (OnePassStep(s)) {  // the transform ran at the front of the step; its finish follows the segmentation (pipelined: on that stream, Lat)
-      if (c.schedule != Schedule::kPipelined) FinishOnePass(s, st, timing);
+  void Transform(uint64_t m, hipStream_t st, bool timing) {
+    const uint32_t p0 = P0(m), pn = Pn(m);
+    if (!pn || !c.dct_block_w) return;
+    const int b = Set(m);
+    const uint8_t* enc = bgr.p + (uint64_t)(Skip() + p0) * frame_bytes;  // encoded frame of pair p: own frame p + skip
+    const uint32_t* types_c = types[b].p + (uint64_t)p0 * blocks;
+    if (OnePassStep(m)) {  // the transform ran at the front of the step; its finish follows the segmentation (pipelined: on that stream, Lat)
+      if (c.schedule != Schedule::kPipelined) FinishOnePass(m, st, timing);
       return;
     }
     Run(Stage::kTransform, st, timing, [&] {
       // records carry RAW coefficients, as the reference's encoder serialises them (libs/encoder.cpp:638-650:
       // the decoder picks the step per tile, libs/decoder.cpp:130-135); planes carry the quantised ones
       if (c.wire && fused_records)
-        Abi(svc_hip_dct_records_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, types[b].p, c.mv_block, c.mv_block,
-                                       0, 0, ph, records[0].p, record_bytes, st), "svc_hip_dct_records_frames");
+        Abi(svc_hip_dct_records_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, types_c, c.mv_block, c.mv_block,
+                                       0, 0, ph, Records(m).p + (uint64_t)p0 * record_bytes, record_bytes, st), "svc_hip_dct_records_frames");
       else if (c.wire) {  // any other transform block: Dct, then SerializeEncodedFrame
-        Abi(svc_hip_dct_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, coeffs[0].p, st), "svc_hip_dct_frames");
-        Abi(svc_hip_serialize_frames(coeffs[0].p, plane_elems, sh.pairs, types[b].p, pw, ph, c.dct_block_w, c.dct_block_h, mfw, mfh,
-                                     c.mv_block, c.mv_block, records[0].p, record_bytes, st), "svc_hip_serialize_frames");
+        float* planes = coeffs[0].p + (uint64_t)p0 * 3 * plane_elems;
+        Abi(svc_hip_dct_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, c.dct_block_h, planes, st), "svc_hip_dct_frames");
+        Abi(svc_hip_serialize_frames(planes, plane_elems, pn, types_c, pw, ph, c.dct_block_w, c.dct_block_h, mfw, mfh,
+                                     c.mv_block, c.mv_block, Records(m).p + (uint64_t)p0 * record_bytes, record_bytes, st), "svc_hip_serialize_frames");
       } else
-        Abi(svc_hip_dct_quant_frames(enc, frame_bytes, sh.pairs, pw, ph, c.dct_block_w, c.dct_block_h, types[b].p, c.mv_block,
-                                     c.mv_block, c.fg_step, c.bg_step, Coeffs(s).p, st), "svc_hip_dct_quant_frames");
+        Abi(svc_hip_dct_quant_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, c.dct_block_h, types_c, c.mv_block,
+                                     c.mv_block, c.fg_step, c.bg_step, Coeffs(m).p + (uint64_t)p0 * 3 * plane_elems, st), "svc_hip_dct_quant_frames");
     });
   }
 
-  // RANSAC + segmentation of step l on its latency stream, behind everything the main stream holds so far; the main
-  // stream picks the result up (JoinLat) only where it is needed: in front of the transform of step l, `depth`
-  // iterations later.
+  // RANSAC + segmentation of micro-step l on its latency stream, behind everything the main stream holds so far; the main
+  // stream picks the result up (JoinLat) only where it is needed: in front of the transform of l, `depth` iterations later.
   void ForkLat(uint64_t l, bool timing) {
     hipStream_t st = sL[l % (uint64_t)depth];
     Hip(hipEventRecord(e_fork, sM), "hipEventRecord");
     Hip(hipStreamWaitEvent(st, e_fork, 0), "hipStreamWaitEvent");
     Lat(l, st, timing);
-    Hip(hipEventRecord(e_join[Set(l)], st), "hipEventRecord");
-    join_pending[Set(l)] = true;
-    fork_iter[Set(l)] = iter;
-    if (defer_rmse && c.world > 1 && sh.pairs) {
+    Hip(hipEventRecord(e_join[Slot(l)], st), "hipEventRecord");
+    join_pending[Slot(l)] = true;
+    fork_iter[Slot(l)] = iter;
+    if (defer_rmse && c.world > 1 && Pn(l)) {
       // multi-rank: the RMSE tail on this latency stream BEHIND the region ids (and behind the join event, so the transform
       // does not wait for it); the communication stream stays free for the halo
       const int b = Set(l);
-      Abi(svc_hip_ransac_rmse_frames(mv[b].p, blocks, sh.pairs, c.ransac, gm[b].p, mask[b].p, count[b].p, rmse[b].p, st),
-          "svc_hip_ransac_rmse_frames");
-      Hip(hipEventRecord(e_rmse[b], st), "hipEventRecord");
-      rmse_pending[b] = true;
+      const uint32_t p0 = P0(l), pn = Pn(l);
+      Abi(svc_hip_ransac_rmse_frames(mv[b].p + (uint64_t)p0 * blocks * 2, blocks, pn, c.ransac, gm[b].p + (uint64_t)p0 * 2,
+                                     mask[b].p + (uint64_t)p0 * blocks, count[b].p + p0, rmse[b].p + p0, st), "svc_hip_ransac_rmse_frames");
+      Hip(hipEventRecord(e_rmse[Slot(l)], st), "hipEventRecord");
+      rmse_pending[Slot(l)] = true;
     }
   }
   void JoinLat(uint64_t l) {
-    if (!join_pending[Set(l)]) return;
-    Hip(hipStreamWaitEvent(sM, e_join[Set(l)], 0), "hipStreamWaitEvent");
-    join_pending[Set(l)] = false;
+    if (!join_pending[Slot(l)]) return;
+    Hip(hipStreamWaitEvent(sM, e_join[Slot(l)], 0), "hipStreamWaitEvent");
+    join_pending[Slot(l)] = false;
   }
 
-  // One iteration of the software pipeline: luma + pyramid of step s, motion search of s - 1, fork of RANSAC +
-  // segmentation of s - 2, transform of s - 2 - depth.  Buffer hazards (a step's small buffers are set s % (depth + 2)):
+  // One iteration of the software pipeline over micro-steps.  Multi-rank (a halo to wait for): luma + pyramid of m, motion search of
+  // m - 1, fork of RANSAC + segmentation of m - 2, transform of m - 2 - depth.  One rank: the motion search of m follows its own pyramids
+  // in the same iteration (nothing to wait for), so RANSAC + segmentation of m - 1 fork at the start of the next one and the transform
+  // of m - 1 - depth joins them.  Buffer hazards (a micro-step's events live in slot m % (depth + 2), its data at its chunk's offset
+  // in set step % (depth + 2)):
   //   lat(l) reads mv[l], writes mask / types[l] on stream l % depth, and must be done before transform(l) reads types[l]:
   //     joined there, `depth` iterations after its fork;
-  //   hbma(h) writes mv[h]: the set's last reader lat(h - depth - 2) was joined an iteration earlier;
+  //   hbma(h) writes its chunk of mv[set]: the last reader of that range, lat of the same chunk nsets steps earlier, was joined long before;
   //   up to `depth` lats are in flight on their own streams, each with its own segmentation workspace.
   void Iterate(bool new_step, bool timing) {
-    const uint64_t lumas = n_luma, hbmas = n_hbma, lats = n_lat;
-    const bool do_hbma = n_hbma < lumas, do_lat = n_lat < hbmas;
-    const uint64_t h = n_hbma, l = n_lat, d = n_dct;
-    // draining (no new step) joins at once; otherwise the transform of step d waits until lat(d) has had its iterations
-    const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Set(d)] >= (uint64_t)depth);
+    if (new_step) Decide(n_luma);  // may drain the pipeline (the first speculation allocates the extra coefficient sets)
+    const uint64_t lumas_before = n_luma, hbmas = n_hbma, lats = n_lat;
+    const bool do_lat = n_lat < hbmas;
+    const uint64_t l = n_lat, d = n_dct;
+    // draining (no new step) joins at once; otherwise the transform of micro-step d waits until lat(d) has had its iterations
+    const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Slot(d)] >= (uint64_t)depth);
     if (do_lat) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
     if (new_step) {
-      const uint64_t s = n_luma;
-      const int b = Par(s);
+      const uint64_t m = n_luma;
+      const int b = Par(m);
       if (c.world > 1 && halo_recorded[b])  // the send out of pyr[b] two steps ago must have left
         Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
-      Luma(s, sM, timing);
-      if (c.world > 1) Halo(s, timing);
+      Luma(m, sM, timing);
+      if (c.world > 1) Halo(m, timing);
       ++n_luma;
     }
-    if (do_hbma && c.world > 1)  // the halo of step h has had a whole iteration to arrive
-      Hip(hipStreamWaitEvent(sM, e_halo[Par(h)], 0), "hipStreamWaitEvent");
+    // one rank: the search of the micro-step whose pyramids were just enqueued; multi-rank: the previous one's, whose halo has had a
+    // whole iteration to arrive
+    const bool do_hbma = (c.world > 1 && new_step) ? n_hbma < lumas_before : n_hbma < n_luma;
+    const uint64_t h = n_hbma;
+    if (do_hbma && c.world > 1) Hip(hipStreamWaitEvent(sM, e_halo[Par(h)], 0), "hipStreamWaitEvent");
     if (do_hbma) Hbma(h, sM, timing);
     if (do_dct) {
       JoinLat(d);
@@ -389,6 +481,7 @@ struct ClipEncoder::Impl {
 
   void SerialStep(bool timing) {
     const uint64_t s = n_luma;
+    Decide(s);
     const int b = Par(s);
     if (c.world > 1 && halo_recorded[b]) Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
     Luma(s, sM, timing);
@@ -431,7 +524,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   m.record_bytes = (c.wire && transform) ? svc_hip_serialized_frame_bytes(m.pw, m.ph, c.dct_block_w, c.dct_block_h) : 0;
   m.iters = svc_hip_ransac_iter_count(c.ransac);
   const uint32_t P = m.sh.pairs, N = m.sh.frames;
-  m.seg_ws_bytes = c.segmentation ? svc_hip_segment_workspace_bytes(m.mfw, m.mfh, std::max(P, 1u), c.segment.attempt_count) : 0;
+  // (computed below, once the chunk size is known: the workspace of one launch)
   // All three at the default priority.  Measured on MI355X (38-frame shard, pipelined): raising the second and
   // the communication stream stretched the main stream's HBM-bound kernels 1.8x (0.41 -> 0.64 ms per step), and
   // a low-priority main stream was slower still (0.79).  Confining the second stream to every 2nd / 4th / 8th CU
@@ -448,6 +541,18 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   m.depth = 1;
   if (pipelined) m.depth = c.lat_depth ? (int)c.lat_depth : 2;
   m.nsets = !pipelined ? 1 : m.depth + 2;
+  // Chunks per step.  Only where one rank holds the clip and the schedule pipelines (a multi-rank step is tied to its neighbour's by the
+  // halo, and its shards are small already).  Default: as many chunks as keep a chunk above kChunkMinPixels, at most kMaxAutoChunks --
+  // enough to overlap the latency-bound stages of one step with its own bandwidth-bound kernels, few enough that the extra launches
+  // (four main-stream kernels per chunk) stay below 1 % of the step (profiles/r06_ab_chunks.txt).
+  m.nch = 1;
+  if (pipelined && c.world == 1 && P > 1) {
+    if (c.chunk_pairs) m.nch = (P + c.chunk_pairs - 1) / c.chunk_pairs;
+    else m.nch = (uint32_t)std::min<uint64_t>(Impl::kMaxAutoChunks, std::max<uint64_t>(1, (uint64_t)P * m.pw * m.ph / Impl::kChunkMinPixels));
+    m.nch = std::min(m.nch, P);
+  }
+  m.cp = P ? (P + m.nch - 1) / m.nch : 0;
+  if (m.cp) m.nch = (P + m.cp - 1) / m.cp;  // no empty chunk at the end
   // only where the chain is long enough to matter: 0.13 ms at 4K against 0.03 ms at 1080p, where it measures neutral
   // (profiles/r03_ab_defer_rmse.txt)
   m.defer_rmse = pipelined && !c.inline_rmse && m.blocks > 8192;
@@ -471,6 +576,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
     m.gm[b].Alloc((size_t)P * 2); m.rmse[b].Alloc(P);
     m.mask[b].Alloc((size_t)P * m.blocks); m.count[b].Alloc(P); m.types[b].Alloc((size_t)P * m.blocks);
   }
+  m.seg_ws_bytes = c.segmentation ? svc_hip_segment_workspace_bytes(m.mfw, m.mfh, std::max(m.cp, 1u), c.segment.attempt_count) : 0;
   for (int k = 0; k < m.depth; ++k) m.seg_ws[k].Alloc(m.seg_ws_bytes);
   m.fused_records = c.wire && c.dct_block_w == c.dct_block_h && c.dct_block_w <= 64 && c.dct_block_w % 2 == 0;
   // one pass over the BGR clip: the tuned record emitter (8x8 / 16x16 on widths that are whole 16-pixel segments) also leaves the luma plane
@@ -481,14 +587,16 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   m.spec_quant = !c.wire && !c.two_bgr_passes && transform && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) &&
                  m.pw % 16 == 0 && c.mv_block % 16 == 0 && c.mv_block % c.dct_block_w == 0 && c.fg_step > 0 && c.bg_step > 0 && P > 0 &&
                  (c.always_speculate || (uint64_t)P * m.pw * m.ph >= Impl::kSpecMinPixels);
-  m.rec_sets = (m.one_bgr_pass || m.spec_quant) && pipelined ? m.nsets + 1 : 1;
+  // a micro-step's output is written at its front and completed up to depth + 2 iterations later; the same chunk of the NEXT step that uses
+  // the set comes nch iterations later per set: ceil((depth + 3) / nch) sets keep them apart (5 with whole-shard steps, 2 with three chunks)
+  m.rec_sets = (m.one_bgr_pass || m.spec_quant) && pipelined ? (m.nsets + 1 + (int)m.nch - 1) / (int)m.nch : 1;
   if (transform) {
     if (c.wire)
       for (int b = 0; b < m.rec_sets; ++b) m.records[b].Alloc((size_t)P * m.record_bytes);
     if (!c.wire || !m.fused_records)
-      for (int b = 0; b < (m.spec_quant ? m.rec_sets : 1); ++b) m.coeffs[b].Alloc((size_t)P * 3 * m.plane_elems);
+      m.coeffs[0].Alloc((size_t)P * 3 * m.plane_elems);  // the other rec_sets - 1 sets: Impl::GrowCoeffSets, on the first speculation
     if (m.spec_quant) {
-      for (int k = 0; k < m.depth; ++k) m.redo_ws[k].Alloc(svc_hip_dct_redo_workspace_bytes(P, m.pw, m.ph, c.mv_block, c.mv_block));
+      for (int k = 0; k < m.depth; ++k) m.redo_ws[k].Alloc(svc_hip_dct_redo_workspace_bytes(m.cp, m.pw, m.ph, c.mv_block, c.mv_block));
       m.fg_dev.Alloc(Impl::kFgSlots);
       Hip(hipHostMalloc(reinterpret_cast<void**>(&m.fg_host), Impl::kFgSlots * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
       for (hipEvent_t& e : m.e_fg) Hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -520,16 +628,30 @@ uint32_t ClipEncoder::padded_width() const { return p_->pw; }
 uint32_t ClipEncoder::padded_height() const { return p_->ph; }
 uint32_t ClipEncoder::blocks() const { return p_->blocks; }
 uint64_t ClipEncoder::pyramid_stride() const { return p_->pyr_stride; }
-uint32_t ClipEncoder::steps_submitted() const { return (uint32_t)p_->n_luma; }
+uint32_t ClipEncoder::steps_submitted() const { return (uint32_t)(p_->n_luma / p_->nch); }
+uint32_t ClipEncoder::chunks_per_step() const { return p_->nch; }
+uint32_t ClipEncoder::output_sets() const { return (uint32_t)(p_->one_bgr_pass ? p_->rec_sets : p_->coeff_sets); }
+
+void ClipEncoder::ResetPolicy() {
+  Sync();
+  p_->ResetPolicy();
+}
+
+void ClipEncoder::PolicyInfo(uint64_t* chunks_decided, uint64_t* chunks_speculated, double* foreground_share) {
+  Sync();
+  if (chunks_decided) *chunks_decided = p_->n_decided;
+  if (chunks_speculated) *chunks_speculated = p_->n_spec;
+  if (foreground_share) *foreground_share = p_->fg_share;
+}
 
 void ClipEncoder::LoadFrames(const uint8_t* src, uint32_t first_local, uint32_t n, bool src_on_device) {
   Impl& m = *p_;
   if (!src || (uint64_t)first_local + n > m.sh.frames) throw std::runtime_error("svc::ClipEncoder: LoadFrames out of range");
   Sync();
-  // other frames: what the speculation policy knew about the clip's foreground share is void (every measurement has landed: Sync above)
-  m.fg_share = -1.0;
-  m.n_fg = 0;
-  for (bool& p : m.fg_pending) p = false;
+  // other frames: what the speculation policy knew about the clip's foreground share is void (every measurement has landed: Sync above) --
+  // unless the caller says the clips it loads are consecutive pieces of one stream, whose last measurement is a fair prior for the next
+  // piece (speculation is correct at ANY share: a stale prior costs one slow step, never a wrong byte)
+  if (!m.c.keep_foreground_prior) m.ResetPolicy();
   Hip(hipMemcpy(m.bgr.p + (size_t)first_local * m.frame_bytes, src, (size_t)n * m.frame_bytes,
                 src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "hipMemcpy");
   // a device-to-device hipMemcpy returns before the copy has run, and the streams of Step() do not order behind the
@@ -542,7 +664,8 @@ void ClipEncoder::SetHaloTransport(HaloFn fn) { p_->halo = std::move(fn); }
 
 void ClipEncoder::Step(bool timed) {
   p_->last_timed = timed;
-  if (p_->c.schedule == Schedule::kPipelined) p_->Iterate(true, timed);
+  if (p_->c.schedule == Schedule::kPipelined)
+    for (uint32_t k = 0; k < p_->nch; ++k) p_->Iterate(true, timed);
   else p_->SerialStep(timed);
 }
 
@@ -604,7 +727,7 @@ void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
 }  // namespace svc
 
 // ---- C handle API (include/svc_clip.h) ---------------------------------------------------------
-static_assert(sizeof(svc_clip_config) == 136 && sizeof(svc_clip_info) == 72, "the ctypes binding (clip.py) mirrors this layout");
+static_assert(sizeof(svc_clip_config) == 136 && sizeof(svc_clip_info) == 80, "the ctypes binding (clip.py) mirrors this layout");
 struct svc_clip {
   std::unique_ptr<svc::ClipEncoder> enc;
   svc::ClipEncoderConfig cfg;
@@ -651,7 +774,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
                                std::to_string(sizeof(svc_clip_config)) + " bytes (set struct_size = sizeof(svc_clip_config))");
     constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
-                                   SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE;
+                                   SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -670,6 +793,8 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.inline_rmse = (k->tuning & SVC_CLIP_TUNE_INLINE_RMSE) != 0;
     c.two_bgr_passes = (k->tuning & SVC_CLIP_TUNE_TWO_BGR_PASSES) != 0;
     c.always_speculate = (k->tuning & SVC_CLIP_TUNE_ALWAYS_SPECULATE) != 0;
+    c.keep_foreground_prior = (k->tuning & SVC_CLIP_KEEP_FOREGROUND_PRIOR) != 0;
+    c.chunk_pairs = k->chunk_pairs;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
     h->enc.reset(new svc::ClipEncoder(c));
@@ -693,6 +818,8 @@ int svc_clip_get_info(svc_clip* clip, svc_clip_info* o) {
                           ? svc_hip_serialized_frame_bytes(o->padded_w, o->padded_h, clip->cfg.dct_block_w, clip->cfg.dct_block_h) : 0;
     o->first_frame = s.first_frame; o->frames = s.frames; o->pairs = s.pairs; o->first_encoded = s.first_encoded;
     o->needs_halo = s.needs_halo ? 1u : 0u;
+    o->chunks_per_step = e.chunks_per_step();
+    o->output_sets = e.output_sets();
   });
 }
 
@@ -723,6 +850,12 @@ int svc_clip_stage_time(svc_clip* clip, uint32_t stage, double* total_ms, uint32
 }
 
 int svc_clip_reset_timers(svc_clip* clip) { return Guard([&] { clip->enc->ResetTimers(); }); }
+
+int svc_clip_reset_policy(svc_clip* clip) { return Guard([&] { clip->enc->ResetPolicy(); }); }
+
+int svc_clip_policy_info(svc_clip* clip, uint64_t* chunks_decided, uint64_t* chunks_speculated, double* foreground_share) {
+  return Guard([&] { clip->enc->PolicyInfo(chunks_decided, chunks_speculated, foreground_share); });
+}
 
 int svc_clip_output(svc_clip* clip, uint32_t buffer, void** d_ptr, uint64_t* bytes) {
   return Guard([&] {

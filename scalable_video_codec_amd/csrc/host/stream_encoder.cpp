@@ -6,8 +6,11 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -60,11 +63,13 @@ struct Slot {
   PinBuf<float> pin_mv, pin_gm, pin_coeffs;
   PinBuf<uint32_t> pin_types;
   hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
+  hipEvent_t t_in[2] = {}, t_k[2] = {}, t_out[2] = {};  // EncodeStats: start / end of the batch's work on each stream
+  uint64_t h2d_bytes = 0, d2h_bytes = 0;
   bool busy = false;
   uint32_t frames = 0;  // source frames resident in bgr (the last one carries into the next batch)
   uint32_t encoded = 0, first = 0;
   ~Slot() {
-    for (hipEvent_t e : {h2d_done, compute_done, d2h_done})
+    for (hipEvent_t e : {h2d_done, compute_done, d2h_done, t_in[0], t_in[1], t_k[0], t_k[1], t_out[0], t_out[1]})
       if (e) (void)hipEventDestroy(e);
   }
 };
@@ -80,6 +85,7 @@ struct StreamEncoder::Impl {
   hipStream_t s_in = nullptr, s_compute = nullptr, s_out = nullptr;
   bool fused_records = false;  // wire: the transform kernel emits the records itself
   std::unique_ptr<CopyCrew> crew;
+  EncodeStats stats;
 
   ~Impl() {
     for (hipStream_t s : {s_in, s_compute, s_out})
@@ -136,6 +142,7 @@ StreamEncoder::StreamEncoder(const StreamEncoderConfig& config) : p_(new Impl) {
     Hip(hipEventCreateWithFlags(&s->h2d_done, hipEventDisableTiming), "hipEventCreate");
     Hip(hipEventCreateWithFlags(&s->compute_done, hipEventDisableTiming), "hipEventCreate");
     Hip(hipEventCreateWithFlags(&s->d2h_done, hipEventDisableTiming), "hipEventCreate");
+    for (hipEvent_t* e : {&s->t_in[0], &s->t_in[1], &s->t_k[0], &s->t_k[1], &s->t_out[0], &s->t_out[1]}) Hip(hipEventCreate(e), "hipEventCreate");
     m.slots.push_back(std::move(s));
   }
 }
@@ -143,6 +150,7 @@ StreamEncoder::StreamEncoder(const StreamEncoderConfig& config) : p_(new Impl) {
 StreamEncoder::~StreamEncoder() = default;
 uint32_t StreamEncoder::padded_width() const { return p_->pw; }
 uint32_t StreamEncoder::padded_height() const { return p_->ph; }
+const EncodeStats& StreamEncoder::last_stats() const { return p_->stats; }
 
 void StreamEncoder::Encode(const uint8_t* bgr, uint32_t n_frames, const Sink& sink) {
   if (!bgr || n_frames < 2) throw std::runtime_error("svc::StreamEncoder: a clip needs at least two frames");
@@ -162,8 +170,27 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
     Abi(svc_hip_wire_header(std::max<uint32_t>(header_frame_count, 1), c.width, c.height, m.bw, m.bh, c.levels, m.tw,
                             m.th, &header), "svc_hip_wire_header");
 
+  using Clock = std::chrono::steady_clock;
+  auto ms_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
+  EncodeStats st;
+  st.copy_threads = m.crew->threads();
+  {
+    cpu_set_t set;
+    st.host_cores = sched_getaffinity(0, sizeof(set), &set) == 0 ? (uint32_t)CPU_COUNT(&set) : 0;
+  }
+  const Clock::time_point t_start = Clock::now();
+
   auto deliver = [&](Slot& s) {
+    Clock::time_point t0 = Clock::now();
     Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize");
+    st.deliver_wait_ms += ms_since(t0);
+    float ms = 0;
+    Hip(hipEventElapsedTime(&ms, s.t_in[0], s.t_in[1]), "hipEventElapsedTime"); st.h2d_ms += ms;
+    Hip(hipEventElapsedTime(&ms, s.t_k[0], s.t_k[1]), "hipEventElapsedTime"); st.kernels_ms += ms;
+    Hip(hipEventElapsedTime(&ms, s.t_out[0], s.t_out[1]), "hipEventElapsedTime"); st.d2h_ms += ms;
+    st.h2d_bytes += s.h2d_bytes; st.d2h_bytes += s.d2h_bytes;
+    ++st.batches; st.encoded_frames += s.encoded;
+    t0 = Clock::now();
     EncodedBatch b;
     b.header = (c.wire && s.first == 1) ? &header : nullptr;
     b.first_frame = s.first; b.count = s.encoded;
@@ -173,6 +200,7 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
     b.records = c.wire ? s.pin_records.p : nullptr;
     b.record_bytes = m.record_bytes;
     sink(b);
+    st.sink_ms += ms_since(t0);
   };
 
   std::vector<Slot*> pending;
@@ -181,7 +209,13 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
   bool ended = false;
   while (!ended) {
     Slot& s = *m.slots[k % c.depth];
-    if (s.busy) { Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize"); s.busy = false; }
+    if (s.busy) {
+      const Clock::time_point t0 = Clock::now();
+      Hip(hipEventSynchronize(s.d2h_done), "hipEventSynchronize");
+      st.slot_wait_ms += ms_since(t0);
+      s.busy = false;
+    }
+    const Clock::time_point t_stage = Clock::now();
     const bool carry = prev != nullptr;
     const uint32_t want = carry ? B : B + 1, off = carry ? 1 : 0;
     // source -> pinned, padding each row out to the padded width
@@ -194,6 +228,8 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
     }
     const uint32_t encoded = carry ? n_new : (n_new ? n_new - 1 : 0);
     if (encoded == 0) break;  // the clip ended on a batch boundary (or had a single frame): nothing left to encode
+    Hip(hipEventRecord(s.t_in[0], m.s_in), "hipEventRecord");
+    s.h2d_bytes = (uint64_t)n_new * m.frame_bytes;
     Hip(hipMemcpyAsync(s.bgr.p + (size_t)off * m.frame_bytes, s.pin_in.p + (size_t)off * m.frame_bytes,
                        (size_t)n_new * m.frame_bytes, hipMemcpyHostToDevice, m.s_in), "hipMemcpyAsync H2D");
     if (carry) {
@@ -216,11 +252,14 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
       Hip(hipMemcpyAsync(s.samples.p, s.pin_samples.p, (size_t)encoded * m.iters * c.ransac.subset_sz * sizeof(uint32_t),
                          hipMemcpyHostToDevice, m.s_in), "hipMemcpyAsync samples");
     }
+    Hip(hipEventRecord(s.t_in[1], m.s_in), "hipEventRecord");
     Hip(hipEventRecord(s.h2d_done, m.s_in), "hipEventRecord");
     s.frames = off + n_new;
+    st.staging_ms += ms_since(t_stage);
 
     // the kernels: always B pairs (a short last batch re-encodes stale frames past its end and drops them)
     Hip(hipStreamWaitEvent(m.s_compute, s.h2d_done, 0), "hipStreamWaitEvent");
+    Hip(hipEventRecord(s.t_k[0], m.s_compute), "hipEventRecord");
     Abi(svc_hip_luma_pyramid_frames(s.bgr.p, m.frame_bytes, B + 1, m.pw, m.ph, c.levels, s.pyr.p, m.pyr_stride, m.s_compute),
         "svc_hip_luma_pyramid_frames");
     Abi(svc_hip_hbma_pairs(s.pyr.p, s.pyr.p + m.pyr_stride, m.pyr_stride, B, c.levels, m.pw, m.ph, c.search_range,
@@ -245,9 +284,12 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
       Abi(svc_hip_dct_quant_frames(enc_bgr, m.frame_bytes, B, m.pw, m.ph, m.tw, m.th, s.types.p, m.bw,
                                    m.bh, c.fg_step, c.bg_step, s.coeffs.p, m.s_compute), "svc_hip_dct_quant_frames");
     }
+    Hip(hipEventRecord(s.t_k[1], m.s_compute), "hipEventRecord");
     Hip(hipEventRecord(s.compute_done, m.s_compute), "hipEventRecord");
 
     Hip(hipStreamWaitEvent(m.s_out, s.compute_done, 0), "hipStreamWaitEvent");
+    Hip(hipEventRecord(s.t_out[0], m.s_out), "hipEventRecord");
+    s.d2h_bytes = (uint64_t)encoded * ((uint64_t)m.blocks * 12 + 8 + (c.wire ? m.record_bytes : 3 * m.plane_elems * sizeof(float)));
     Hip(hipMemcpyAsync(s.pin_mv.p, s.mv.p, (size_t)encoded * m.blocks * 2 * sizeof(float), hipMemcpyDeviceToHost, m.s_out), "D2H mv");
     Hip(hipMemcpyAsync(s.pin_types.p, s.types.p, (size_t)encoded * m.blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, m.s_out), "D2H types");
     Hip(hipMemcpyAsync(s.pin_gm.p, s.gm.p, (size_t)encoded * 2 * sizeof(float), hipMemcpyDeviceToHost, m.s_out), "D2H gm");
@@ -255,6 +297,7 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
       Hip(hipMemcpyAsync(s.pin_records.p, s.records.p, (size_t)encoded * m.record_bytes, hipMemcpyDeviceToHost, m.s_out), "D2H records");
     else
       Hip(hipMemcpyAsync(s.pin_coeffs.p, s.coeffs.p, (size_t)encoded * 3 * m.plane_elems * sizeof(float), hipMemcpyDeviceToHost, m.s_out), "D2H coeffs");
+    Hip(hipEventRecord(s.t_out[1], m.s_out), "hipEventRecord");
     Hip(hipEventRecord(s.d2h_done, m.s_out), "hipEventRecord");
 
     s.busy = true; s.encoded = encoded; s.first = first;
@@ -264,6 +307,8 @@ void StreamEncoder::Encode(const Source& next, uint32_t header_frame_count, cons
   }
   for (Slot* s : pending) deliver(*s);
   for (auto& s : m.slots) s->busy = false;  // everything delivered and synchronised
+  st.wall_ms = ms_since(t_start);
+  m.stats = st;
 }
 
 }  // namespace svc

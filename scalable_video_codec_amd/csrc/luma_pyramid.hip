@@ -328,6 +328,159 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
     }
   }
 }
+// ---- plane -> next level, a wave per column strip, no LDS (round 6) ---------------------------------------------------
+// The LDS-tiled plane pass above spends its time on arithmetic and LDS, not on bytes (24 vector instructions per output pixel,
+// LDS busy 39 % of a CU's time with 16 M of 41 M cycles bank conflicts: profiles/r05_pmc_C3_sq_tcp_summary.csv).  Here a WAVE owns
+// a strip of 512 source columns (lane i: columns 8i .. 8i + 7, one dwordx2 per source row) and walks OB output rows down it:
+//   * vertical first, two columns per instruction: a source dword is split once into its even and odd bytes as pairs of u16
+//     (E = bytes 0, 2; O = bytes 1, 3) and the 1 4 6 4 1 column sums run on the pairs (<= 4088 each, with the rounding constant
+//     folded in as + 8).  Output row oy needs rows 2 oy - 2 .. 2 oy + 2: with S = r[2 oy - 2] + 4 r[2 oy - 1] carried from the
+//     previous row, V = S + 6 r[2 oy] + (4 r[2 oy + 1] + r[2 oy + 2]) is four instructions per pair register and no row is kept;
+//   * horizontal on the column sums, still in pairs: the two outputs centred on a dword's bytes 0 and 2 are
+//     6 E + 4 (O' + O) + (E' + E'') where ' / '' are E, O shifted by one u16 across the neighbouring dword (v_alignbyte) --
+//     <= 65 408, so a pair of u16 never carries; the result bytes are bytes 1 and 3 of the sums (the >> 8), picked by one v_perm;
+//   * the neighbouring lane's registers arrive by DPP wave shifts; the strip's own neighbours (two column sums left, one right;
+//     reflected at the plane's border) come from one more dword per row, loaded by every lane from an address of its own
+//     (lane 0: the dword left of the strip, the strip's last lane: the dword right of it, every other lane: a dword it reads anyway).
+// No LDS, no barrier, 2 x 8 + 4 bytes in flight per lane and row.
+#ifndef SVC_PYR_STRIP
+#define SVC_PYR_STRIP 1
+#endif
+#ifndef SVC_PYR_STRIP_OB
+#define SVC_PYR_STRIP_OB 8
+#endif
+#ifndef SVC_PYR_STRIP_ORDER
+#define SVC_PYR_STRIP_ORDER 1
+#endif
+// timing experiments only (wrong results; tools/ab_pyr_standalone.sh): what the pass costs without its arithmetic / without the strip's
+// extra dword per row / with non-temporal loads and stores
+#ifndef SVC_PYR_STRIP_NOMATH
+#define SVC_PYR_STRIP_NOMATH 0
+#endif
+#ifndef SVC_PYR_STRIP_NOHALO
+#define SVC_PYR_STRIP_NOHALO 0
+#endif
+#ifndef SVC_PYR_STRIP_NT
+#define SVC_PYR_STRIP_NT 0
+#endif
+struct PyrStripArgs {
+  uint8_t* pyr;
+  uint64_t pyr_stride, src_off, dst_off;
+  uint32_t sw, sh;  // source plane; sw % 8 == 0, sh % 2 == 0, sh >= 4
+  uint32_t strips, bands, total_waves;
+};
+
+typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint16_t k, uint32_t c) {  // v_pk_mad_u16
+  return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) * k + __builtin_bit_cast(u16x2_t, c)));
+}
+
+template <int OB>
+__global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6));
+  if (wv >= a.total_waves) return;
+#if SVC_PYR_STRIP_ORDER == 0
+  // consecutive waves: consecutive bands of one strip (they share two or three source rows)
+  const uint32_t band = wv % a.bands, t = wv / a.bands, strip = t % a.strips, frame = t / a.strips;
+#else
+  // consecutive waves: the strips of one band side by side -- a workgroup's four waves read whole rows of a 1080p plane, one contiguous run
+  const uint32_t strip = wv % a.strips, t = wv / a.strips, band = t % a.bands, frame = t / a.bands;
+#endif
+  const int w = (int)a.sw, h = (int)a.sh, dw = w >> 1, dh = h >> 1;
+  const int x0 = (int)strip * 512, valid = min(512, w - x0), la = valid / 8 - 1, xe = x0 + valid;
+  const int oy0 = (int)band * OB, rows = min(OB, dh - oy0);
+  const uint8_t* src = a.pyr + (size_t)frame * a.pyr_stride + a.src_off;
+  uint8_t* dst = a.pyr + (size_t)frame * a.pyr_stride + a.dst_off;
+
+  const uint32_t col = (uint32_t)x0 + min(lane, (uint32_t)la) * 8u;
+  // the extra dword and which of its bytes become (lo, hi) of the pair H: lane 0 -> columns (x0 - 2, x0 - 1), reflected (2, 1) at the plane's
+  // left border; lane `la` -> column xe, reflected w - 2 at the right border; selector 0x0c = a zero byte
+  uint32_t hcol = col, hsel = 0x0c0c0c0cu;
+  if (lane == 0) { hcol = x0 ? (uint32_t)x0 - 4u : 0u; hsel = x0 ? 0x0c030c02u : 0x0c010c02u; }
+  if (lane == (uint32_t)la) { hcol = xe < w ? (uint32_t)xe : (uint32_t)w - 4u; hsel = xe < w ? 0x0c0c0c00u : 0x0c0c0c02u; }
+  const bool last = lane == (uint32_t)la;
+
+  // a source row -> its five pair registers
+  struct Row { uint32_t e0, o0, e1, o1, hh; };
+  auto fetch = [&](int y, uint2& v, uint32_t& hw) {
+    const uint8_t* rp = src + (size_t)reflect101(min(y, h), h) * (size_t)w;  // wave-uniform
+#if SVC_PYR_STRIP_NT
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t nt = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(rp + col));
+    v = make_uint2(nt.x, nt.y);
+#else
+    v = *reinterpret_cast<const uint2*>(rp + col);
+#endif
+#if SVC_PYR_STRIP_NOHALO
+    hw = v.x;
+#else
+    hw = *reinterpret_cast<const uint32_t*>(rp + hcol);
+#endif
+  };
+  auto split = [&](const uint2& v, uint32_t hw) {
+    Row r;
+    r.e0 = v.x & 0x00FF00FFu; r.o0 = __builtin_amdgcn_perm(0u, v.x, 0x0c030c01u);
+    r.e1 = v.y & 0x00FF00FFu; r.o1 = __builtin_amdgcn_perm(0u, v.y, 0x0c030c01u);
+    r.hh = __builtin_amdgcn_perm(0u, hw, hsel);
+    return r;
+  };
+
+  // every source row of the band is requested before the first is used (2 OB + 3 rows x 12 bytes per lane in flight: the pass is bound by
+  // memory latency, not by arithmetic -- a version that walked the band with two rows of prefetch measured level with the LDS-tiled pass
+  // it replaces, profiles/r06_ab_pyr_strip.txt); straight-line code, so the compiler's vmcnt waits are exact and rows are consumed as they land
+  constexpr int kRows = 2 * OB + 3;
+  uint2 rv[kRows];
+  uint32_t rh[kRows];
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) fetch(2 * oy0 - 2 + r, rv[r], rh[r]);  // rows past the band's last output (and past the plane: clamped) are not used
+  Row s, e;  // s = r[2 oy - 2] + 4 r[2 oy - 1] + 8, e = r[2 oy]
+  constexpr uint32_t k8 = 0x00080008u;
+  {
+    const Row r0 = split(rv[0], rh[0]), r1 = split(rv[1], rh[1]);
+    e = split(rv[2], rh[2]);
+    s.e0 = (r1.e0 << 2) + r0.e0 + k8; s.o0 = (r1.o0 << 2) + r0.o0 + k8;
+    s.e1 = (r1.e1 << 2) + r0.e1 + k8; s.o1 = (r1.o1 << 2) + r0.o1 + k8;
+    s.hh = (r1.hh << 2) + r0.hh + k8;
+  }
+  uint8_t* out = dst + (size_t)oy0 * dw + (x0 >> 1) + 4 * lane;
+  const bool mine = lane <= (uint32_t)la;
+#pragma unroll
+  for (int i = 0; i < OB; ++i) {
+    const Row o = split(rv[3 + 2 * i], rh[3 + 2 * i]), n = split(rv[4 + 2 * i], rh[4 + 2 * i]);  // r[2 oy + 1], r[2 oy + 2]
+    // column sums V = s + 6 e + (4 o + n); next s = e + 4 o + 8 (plain 32-bit adds where no pair can carry: v_add3_u32)
+    Row v;
+    { const uint32_t q = o.e0 << 2; v.e0 = pk_mad(e.e0, 6, s.e0) + q + n.e0; s.e0 = q + e.e0 + k8; }
+    { const uint32_t q = o.o0 << 2; v.o0 = pk_mad(e.o0, 6, s.o0) + q + n.o0; s.o0 = q + e.o0 + k8; }
+    { const uint32_t q = o.e1 << 2; v.e1 = pk_mad(e.e1, 6, s.e1) + q + n.e1; s.e1 = q + e.e1 + k8; }
+    { const uint32_t q = o.o1 << 2; v.o1 = pk_mad(e.o1, 6, s.o1) + q + n.o1; s.o1 = q + e.o1 + k8; }
+    { const uint32_t q = o.hh << 2; v.hh = pk_mad(e.hh, 6, s.hh) + q + n.hh; s.hh = q + e.hh + k8; }
+    e = n;
+    // neighbours: the previous lane's second dword (lane 0: the strip's left neighbours), the next lane's first dword (last lane: the right one)
+    const uint32_t pe = __builtin_amdgcn_update_dpp(v.hh << 16, v.e1, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    const uint32_t po = __builtin_amdgcn_update_dpp(v.hh, v.o1, 0x138, 0xf, 0xf, false);
+    uint32_t ne = __builtin_amdgcn_update_dpp(v.hh, v.e0, 0x130, 0xf, 0xf, false);  // wave_shl:1
+    ne = last ? v.hh : ne;
+    // outputs centred on columns 0, 2 (dword 0) and 4, 6 (dword 1) of the lane
+    const uint32_t l2a = __builtin_amdgcn_alignbyte(v.e0, pe, 2), l1a = __builtin_amdgcn_alignbyte(v.o0, po, 2);
+    const uint32_t mid = __builtin_amdgcn_alignbyte(v.e1, v.e0, 2), l1b = __builtin_amdgcn_alignbyte(v.o1, v.o0, 2);
+    const uint32_t r2b = __builtin_amdgcn_alignbyte(ne, v.e1, 2);
+    const uint32_t qa = pk_mad(v.e0, 6, ((l1a + v.o0) << 2) + l2a + mid);
+    const uint32_t qb = pk_mad(v.e1, 6, ((l1b + v.o1) << 2) + mid + r2b);
+#if SVC_PYR_STRIP_NOMATH
+    const uint32_t px = rv[3 + 2 * i].x ^ rv[4 + 2 * i].y ^ rh[3 + 2 * i] ^ rh[4 + 2 * i] ^ (i == 0 ? rv[0].x ^ rv[1].x ^ rv[2].x ^ rh[0] ^ rh[1] ^ rh[2] : 0u);
+#else
+    const uint32_t px = __builtin_amdgcn_perm(qb, qa, 0x07050301u);  // (>> 8) of the four sums
+#endif
+#if SVC_PYR_STRIP_NT
+    if (mine && i < rows) __builtin_nontemporal_store(px, reinterpret_cast<uint32_t*>(out));
+#else
+    if (mine && i < rows) *reinterpret_cast<uint32_t*>(out) = px;  // (the plane's last band may be short)
+#endif
+    out += dw;
+  }
+}
+
 // any frame width: one pixel per lane
 __global__ __launch_bounds__(256) void luma_any_kernel(const uint8_t* bgr, uint64_t frame_stride, uint8_t* pyr, uint64_t pyr_stride,
                                                         uint32_t px_per_frame, uint32_t total) {
@@ -423,6 +576,21 @@ int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frame
       const uint64_t tt = (uint64_t)fa.tiles_per_frame * n_frames;
       if (tt > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many tiles for one launch");
       fa.total_tiles = (uint32_t)tt;
+#if SVC_PYR_STRIP
+      if (pa.sh >= 4) {
+        PyrStripArgs sa{};
+        sa.pyr = d_pyr; sa.pyr_stride = pyr_stride; sa.src_off = pa.src_off; sa.dst_off = pa.dst_off;
+        sa.sw = pa.sw; sa.sh = pa.sh;
+        sa.strips = div_up(pa.sw, 512);
+        sa.bands = div_up(pa.dh, SVC_PYR_STRIP_OB);
+        const uint64_t tw = (uint64_t)sa.strips * sa.bands * n_frames;
+        if (tw > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many strips for one launch");
+        sa.total_waves = (uint32_t)tw;
+        hipLaunchKernelGGL((pyr_strip_kernel<SVC_PYR_STRIP_OB>), dim3(div_up(sa.total_waves, 4)), dim3(256), 0, stream, sa);
+        if ((rc = check_launch("pyr_strip_kernel"))) return rc;
+        continue;
+      }
+#endif
       {
         // a fixed grid whose workgroups walk the tiles: 0.062 -> 0.054 ms per launch at C3 (profiles/r04_ab_pyr_persist.txt; 1024 workgroups
         // are too few, 2048 and 4096 level).  A double-buffered LDS-DMA form of the same walk measured no better (r04_ab_pyr_stream.txt).

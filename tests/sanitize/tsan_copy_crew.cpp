@@ -98,6 +98,24 @@ int main() {
     CHECK(pid > 0 && waitpid(pid, &status, 0) == pid && WIFEXITED(status) && WEXITSTATUS(status) == 0);
     flat(crew, (size_t)(2u << 20) + 1, 402);  // the parent's crew is untouched
   }
+  {  // ... and a child that lets an inherited crew go out of scope (unwinding, a unique_ptr owner) must not join threads it does not have, nor
+     // take a lock a helper may have held at fork(): the destructor returns at once there.  alarm(): a hang fails the test instead of stalling it
+    auto* crew = new svc::CopyCrew(3);
+    flat(*crew, (size_t)(2u << 20), 410);
+    std::fflush(stdout);
+    pid_t pid = fork();
+    if (pid == 0) {
+      alarm(20);
+      g_fail = 0;
+      flat(*crew, (size_t)(2u << 20) + 5, 411);
+      delete crew;  // the forked child's destructor
+      _exit(g_fail ? 1 : 0);
+    }
+    int status = -1;
+    CHECK(pid > 0 && waitpid(pid, &status, 0) == pid && WIFEXITED(status) && WEXITSTATUS(status) == 0);
+    flat(*crew, (size_t)(2u << 20) + 1, 412);
+    delete crew;  // the owner's: stops and joins
+  }
 #endif
   if (g_fail) return 1;
   std::puts("copy crew ok");

@@ -41,7 +41,7 @@ def test_clip_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/svc_clip.h but not exported"
     assert set(names) == set(clip.SIGNATURES), set(names) ^ set(clip.SIGNATURES)
-    assert ctypes.sizeof(clip.ClipConfig) == 136 and ctypes.sizeof(clip.ClipInfo) == 72  # struct layout of the header
+    assert ctypes.sizeof(clip.ClipConfig) == 136 and ctypes.sizeof(clip.ClipInfo) == 80  # struct layout of the header
     out = subprocess.check_output(["nm", "-DC", "--defined-only", native.MOTION_LIB_PATH], text=True)
     for sym in ("svc::ClipEncoder::ClipEncoder(svc::ClipEncoderConfig const&)", "svc::ClipEncoder::Step(bool)",
                 "svc::PlanShard(unsigned int, unsigned int, unsigned int)", "svc::ClipEncoder::SetComm(void*)"):

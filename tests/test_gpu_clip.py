@@ -160,6 +160,90 @@ def test_buffer_sets_never_serve_stale_steps(native, lat_depth, steps_after):
     enc.close()
 
 
+@pytest.mark.parametrize("form", ["two_passes", "wire", "speculative"])
+@pytest.mark.parametrize("chunk_pairs", [1, 2, 3, 4, 7])
+def test_chunked_steps_equal_whole_steps(native, form, chunk_pairs):
+    """Round 6: a pipelined step at one rank is cut into chunks of frame pairs and the pipeline runs over the CHUNKS (RANSAC + segmentation
+    of a chunk beside the motion search of the next and the transform of the previous one: a clip encoded once no longer pays the
+    latency-bound stages end to end).  Every chunk size -- a pair per chunk, chunks that do not divide the clip, one chunk -- at every
+    pipeline depth, in all three output forms, in bursts of steps over clips that CHANGE between bursts (a chunk served from a stale set,
+    a join event reused too early, a coefficient set rewritten before its foreground tiles were redone would surface the other clip's
+    bytes): the outputs of the serial whole-shard step, bit for bit.  Launch counts: every stage once per chunk and step."""
+    dev = torch.device("cuda")
+    n = 9
+    cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
+    fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    wire = form == "wire"
+    buf = "records" if wire else "coeffs"
+    tuning = {"two_passes": clipmod.TUNE_TWO_BGR_PASSES, "wire": 0, "speculative": clipmod.TUNE_ALWAYS_SPECULATE}[form]
+    want = {}
+    for name, f in (("a", fa), ("b", fb)):
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, wire=wire, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
+        s.load_frames(f)
+        s.step()
+        s.sync()
+        want[name] = (s.outputs(), s.read(buf), s.read("pyramids"))
+        s.close()
+    assert want["a"][0]["block_types"].count_nonzero() > 0 and not torch.equal(want["a"][1], want["b"][1])
+    chunks = -(-(n - 1) // chunk_pairs)
+    for lat_depth in (0, 1, 3):
+        enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, wire=wire, lat_depth=lat_depth, tuning=tuning, chunk_pairs=chunk_pairs,
+                           ransac=dict(inlier_thresh=1.5))
+        assert enc.info.chunks_per_step == chunks
+        steps = 0
+        for burst, (name, f, k) in enumerate((("a", fa, 1), ("b", fb, 1), ("a", fa, 6), ("b", fb, 2), ("a", fa, 3), ("b", fb, 5))):
+            enc.load_frames(f)
+            for _ in range(k):
+                enc.step(timed=True)
+            steps += k
+            out = enc.outputs()  # syncs
+            for key in want[name][0]:
+                assert torch.equal(out[key], want[name][0][key]), (lat_depth, burst, key)
+            assert torch.equal(enc.read(buf), want[name][1]), (lat_depth, burst)
+            assert torch.equal(enc.read("pyramids")[enc.info.pyramid_stride:], want[name][2][enc.info.pyramid_stride:]), (lat_depth, burst)
+        t = enc.stage_times_ms()
+        assert all(launches == steps * chunks for _, launches in t.values()), t
+        assert ("type_patch" in t) == (form != "two_passes")
+        if form == "speculative":
+            assert enc.policy_info()["chunks_speculated"] == enc.policy_info()["chunks_decided"] == steps * chunks
+        enc.close()
+
+
+def test_the_foreground_prior_survives_a_load_only_on_request(native):
+    """LoadFrames voids what the speculation policy knew (other frames: the first step over them is two passes) unless the caller states
+    that the clips are consecutive pieces of one stream (SVC_CLIP_KEEP_FOREGROUND_PRIOR): then the step right after a load speculates
+    on the last piece's share.  svc_clip_reset_policy voids it by hand.  Bytes never depend on any of it."""
+    dev = torch.device("cuda")
+    big = configs.CodecConfig("t-1080p-3L", 43, 1920, 1080, 26, levels=3, dct_block=8)  # 25 encoded frames x 1920 x 1088 = 52 M: may speculate
+    frames = _frames(big, big.frames, dev)
+    ref = None
+    for keep in (False, True):
+        enc = clipmod.Clip(big, big.frames, tuning=clipmod.KEEP_FOREGROUND_PRIOR if keep else 0)
+        enc.load_frames(frames)
+        for _ in range(6):
+            enc.step()
+        enc.sync()
+        warm = enc.policy_info()
+        assert 0 <= warm["foreground_share"] <= 0.02 and warm["chunks_speculated"] > 0
+        enc.load_frames(frames)          # "the next piece of the stream"
+        enc.step()
+        enc.sync()
+        after = enc.policy_info()
+        spec_now = after["chunks_speculated"] - warm["chunks_speculated"]
+        assert (spec_now == enc.info.chunks_per_step) if keep else (spec_now == 0), (keep, warm, after)
+        enc.reset_policy()
+        assert enc.policy_info()["foreground_share"] == -1.0
+        enc.step()
+        enc.sync()
+        assert enc.policy_info()["chunks_speculated"] == after["chunks_speculated"]  # nothing known: two passes
+        got = (enc.outputs(), enc.read("coeffs"))
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(got[0][k], ref[0][k]) for k in ref[0]) and torch.equal(got[1], ref[1])
+        enc.close()
+
+
 def test_wire_and_no_segmentation(native):
     dev = torch.device("cuda")
     n = 6

@@ -41,9 +41,17 @@ def test_bench_driver_at_the_headline_size(native, oracle, encoded):
     drv = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED)
     assert (drv.info.frames, drv.info.pairs) == (cfg.frames, cfg.frames - 1)
     drv.load_frames(torch.stack(ref.frames_bgr).contiguous())
-    for _ in range(4):
+    for _ in range(3):
+        drv.step()
+    drv.sync()  # the foreground share of these steps has landed: the next ones read the clip once (speculative transform, round 5)
+    before = drv.policy_info()
+    for _ in range(2):
         drv.step()
     drv.sync()
+    after = drv.policy_info()
+    # the step whose outputs are compared below DID speculate: every chunk launch of the last two steps took the one-pass form
+    assert after["chunks_speculated"] - before["chunks_speculated"] == 2 * drv.info.chunks_per_step, (before, after)
+    assert 0 <= after["foreground_share"] <= 0.02
     out = drv.outputs(device=dev)
     assert torch.equal(out["mv"], ref.mv) and torch.equal(out["min_mad"], ref.mad)
     assert out["global_motion"].cpu().numpy().tobytes() == ref.gm.cpu().numpy().tobytes()
@@ -52,7 +60,33 @@ def test_bench_driver_at_the_headline_size(native, oracle, encoded):
     assert torch.equal(out["block_types"], ref.types)
     coeffs = drv.read("coeffs", device=dev)
     assert torch.equal(coeffs.view(ref.coeffs.shape), ref.coeffs)
-    del coeffs
+    # (c) the speculated step's coefficient planes against the oracle DIRECTLY (libs/encoder.cpp:323-339 + libs/decoder.cpp:130-144): tiles of
+    # foreground MV blocks (redone with fg_step after the segmentation) and of background blocks (quantised at the front of the step), sampled
+    # over the frames that have foreground; 1e-4 * max(1, |ref|) on the raw coefficient means equality away from the quantiser's rounding edges
+    types = out["block_types"].cpu().numpy().astype(np.uint32)
+    fg_frames = np.flatnonzero((types != 0).any(axis=1))
+    assert len(fg_frames) >= 4
+    rng = np.random.default_rng(6)
+    planes = coeffs.view(ref.coeffs.shape)
+    n_fg = n_bg = n_equal = n_total = 0
+    for p in rng.choice(fg_frames, 4, replace=False):
+        frame = ref.frames_bgr[p + 1].cpu().numpy()
+        want = oracle.quant_frame(oracle.dct_frame_f64(frame, 8, 8).astype(np.float32), 16, 16, types[p], cfg.fg_step, cfg.bg_step)
+        got = planes[p].cpu().numpy()
+        fg_blocks = np.flatnonzero(types[p] != 0)
+        bg_blocks = np.flatnonzero(types[p] == 0)
+        for blocks, is_fg in ((rng.choice(fg_blocks, min(12, len(fg_blocks)), replace=False), True), (rng.choice(bg_blocks, 12, replace=False), False)):
+            for b in blocks:
+                by, bx = divmod(int(b), ref.mfw)
+                tile_got = got[:, by * 16:by * 16 + 16, bx * 16:bx * 16 + 16]   # the four 8x8 tiles of the MV block, three channels
+                tile_want = want[:, by * 16:by * 16 + 16, bx * 16:bx * 16 + 16]
+                step = cfg.fg_step if is_fg else cfg.bg_step
+                assert np.abs(tile_got - tile_want).max() <= step, (p, b, is_fg)
+                n_equal += int((tile_got == tile_want).sum()); n_total += tile_got.size
+                n_fg += 4 * is_fg; n_bg += 4 * (not is_fg)
+    assert n_fg >= 32 and n_bg >= 32 and n_fg + n_bg >= 64, (n_fg, n_bg)
+    assert n_equal / n_total > 0.999, (n_equal, n_total)
+    del coeffs, planes
     pyr = drv.read("pyramids", device=dev)
     assert torch.equal(pyr[drv.info.pyramid_stride:], ref.pyr[ref.stride:])  # slot 0 = halo: unused at world 1
     from oracle.binding import DEFAULT_RANSAC
