@@ -203,7 +203,11 @@ int svc_hip_block_types_frames(const uint8_t* d_inlier_mask, uint32_t blocks,
  * ids numbered as the reference numbers them (0 = background).  The in-repo steps are the
  * reference's; the OpenCV steps follow this repo's deterministic definitions (DESIGN.md
  * section 4.6; parity with OpenCV 3.4's kmeans RNG cannot be pinned offline).  Frame f uses
- * seed + f.  d_workspace: svc_hip_segment_workspace_bytes() bytes of scratch. */
+ * seed + f.  d_workspace: svc_hip_segment_workspace_bytes() bytes of scratch.
+ * cluster_count up to 64 and attempt_count up to 16 run as fused kernels on `stream` (only enqueued).  Beyond that, up to 255 clusters
+ * and 64 attempts (what svc_hip_kmeans_host takes), the call composes the per-call entry points frame by frame through host memory --
+ * the same definitions and bits, but SYNCHRONOUS: it waits for `stream` and returns with the ids in place (round 6; the reference's
+ * Validate admits any positive count, libs/encoder.cpp:39-61).  Larger counts: SVC_ERR_UNSUPPORTED. */
 uint64_t svc_hip_segment_workspace_bytes(uint32_t mv_field_w, uint32_t mv_field_h,
                                          uint32_t n_frames, uint32_t attempt_count);
 
@@ -348,8 +352,11 @@ int svc_hip_wire_patch_types_frames(const uint32_t* d_block_types, uint32_t n_fr
  *   svc_hip_dct_quant_redo_frames   once the ids exist: the tiles of every MV block whose id is not 0 are transformed again and
  *                                   quantised with fg_step.  d_ws: svc_hip_dct_redo_workspace_bytes(n_frames, frame_w, frame_h,
  *                                   mv_block_w, mv_block_h) bytes, 16-byte aligned.
- * The two calls together leave exactly the bytes of svc_hip_dct_quant_frames.  Cost: 15 bytes per FOREGROUND pixel moved again against
- * 3 bytes per pixel of every frame saved -- ahead while less than ~17 % of the MV blocks are foreground, behind above that.
+ * The two calls together leave exactly the bytes of svc_hip_dct_quant_frames.  When it pays: by bytes alone (15 per FOREGROUND pixel moved
+ * again against 3 per pixel of every frame saved) up to ~17 % foreground MV blocks, but MEASURED on MI355X only below ~2-3 %: the redo moves
+ * scattered 16-pixel pieces at about a third of the streaming rate (profiles/r05_ab_speculative_quant.txt: 0.5 % foreground -> the step
+ * 5 % faster, 13 % -> 19 % slower).  Decide with svc_hip_count_foreground on a recent batch's region ids (svc::ClipEncoder speculates at
+ * <= 2 %).
  * block: 8 or 16; frame_w a multiple of 16; MV blocks whole 16-pixel segments wide and whole transform blocks tall; else UNSUPPORTED. */
 int svc_hip_dct_quant_luma_frames(const uint8_t* d_bgr, uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t frame_w,
                                   uint32_t frame_h, uint32_t block, uint32_t bg_step, float* d_planes, uint8_t* d_pyr,

@@ -12,6 +12,8 @@
 #include <malloc.h>
 
 #include "host/copy_crew.hpp"
+
+#include <vector>
 #include "svc_common.hpp"
 
 namespace svc {
@@ -341,6 +343,60 @@ int svc_hip_segment_frames(const uint8_t* d_inlier_mask, const float* d_mv_xy, u
                                    seed, d_workspace, workspace_bytes, d_block_types, 0, stream);
 }
 
+// Beyond the fused kernels' table sizes (cluster_count > 64 or attempt_count > 16; the reference's Validate admits any positive count,
+// libs/encoder.cpp:39-61): libs/encoder.cpp:507-623 composed the reference's way from the per-call entry points -- mask, close, open,
+// index list, BuildMvFeatures (with its m.y overwrite), kmeans, one connectedComponents per cluster, offset numbering -- frame by frame
+// through host memory.  Same definitions, same bits as the fused form (tests/test_gpu_segment.py); SYNCHRONOUS: it waits for `stream`
+// and returns with the region ids in place.  Up to what the per-call k-means takes (255 clusters, 64 attempts).
+static int segment_frames_by_calls(const uint8_t* d_mask, const float* d_mv, uint32_t mfw, uint32_t mfh, uint32_t n_frames, uint32_t bw,
+                                   uint32_t bh, const svc_segment_params& p, uint64_t seed, uint32_t* d_types, hipStream_t stream) {
+  const size_t n = (size_t)mfw * mfh;
+  std::vector<uint8_t> mask(n_frames * n), fg(n), tmp(n), one(n);
+  std::vector<float> mv(n_frames * n * 2), feats;
+  std::vector<uint32_t> types(n_frames * n, 0u), idx;
+  std::vector<int32_t> labels, cc(n);
+  SVC_HIP_TRY(hipMemcpyAsync(mask.data(), d_mask, mask.size(), hipMemcpyDeviceToHost, stream));
+  SVC_HIP_TRY(hipMemcpyAsync(mv.data(), d_mv, mv.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+  SVC_HIP_TRY(hipStreamSynchronize(stream));
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    for (size_t i = 0; i < n; ++i) fg[i] = mask[f * n + i] ? 0 : 255;  // libs/encoder.cpp:507-513
+    int rc = svc_hip_morph_rect_host(fg.data(), mfw, mfh, p.morph_rect_w, p.morph_rect_h, 3, tmp.data());  // :524-525 close
+    if (rc) return rc;
+    if ((rc = svc_hip_morph_rect_host(tmp.data(), mfw, mfh, p.morph_rect_w, p.morph_rect_h, 2, fg.data()))) return rc;  // :526-527 open
+    idx.clear();
+    for (size_t i = 0; i < n; ++i)
+      if (fg[i] == 255) idx.push_back((uint32_t)i);  // :538-546
+    if (idx.empty()) continue;  // region ids stay 0 (:549-551)
+    const uint32_t k = std::min<uint32_t>(p.cluster_count, (uint32_t)idx.size());  // :555
+    feats.assign(idx.size() * 4, 0.0f);  // (0, mv.x, x_px, y_px): :300-321 with libs/math.hpp:285-291
+    for (size_t j = 0; j < idx.size(); ++j) {
+      feats[4 * j + 1] = mv[(f * n + idx[j]) * 2];
+      feats[4 * j + 2] = (float)((idx[j] % mfw) * bw);
+      feats[4 * j + 3] = (float)((idx[j] / mfw) * bh);
+    }
+    labels.resize(idx.size());
+    double compactness = 0;
+    if ((rc = svc_hip_kmeans_host(feats.data(), (uint32_t)idx.size(), 4, k, p.attempt_count, p.max_iter_count, p.epsilon, seed + f,
+                                  labels.data(), &compactness)))  // :575-576
+      return rc;
+    uint32_t* ty = types.data() + f * n;
+    uint32_t offset = 0;
+    for (uint32_t cid = 0; cid < k; ++cid) {  // :597-623
+      std::fill(one.begin(), one.end(), (uint8_t)0);
+      for (size_t j = 0; j < idx.size(); ++j)
+        if ((uint32_t)labels[j] == cid) one[idx[j]] = 255;
+      uint32_t count = 0;
+      if ((rc = svc_hip_connected_components_host(one.data(), mfw, mfh, p.connectivity, cc.data(), &count))) return rc;
+      for (size_t j = 0; j < idx.size(); ++j)
+        if (cc[idx[j]] != 0) ty[idx[j]] = (uint32_t)cc[idx[j]] + offset;
+      offset += count;
+    }
+  }
+  SVC_HIP_TRY(hipMemcpyAsync(d_types, types.data(), types.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  SVC_HIP_TRY(hipStreamSynchronize(stream));
+  return SVC_OK;
+}
+
 int svc_hip_segment_frames_ex(const uint8_t* d_inlier_mask, const float* d_mv_xy, uint32_t mv_field_w,
                               uint32_t mv_field_h, uint32_t n_frames, uint32_t mv_block_w, uint32_t mv_block_h,
                               svc_segment_params params, uint64_t seed, uint8_t* d_workspace,
@@ -356,6 +412,9 @@ int svc_hip_segment_frames_ex(const uint8_t* d_inlier_mask, const float* d_mv_xy
   SVC_REQUIRE(params.connectivity == 4 || params.connectivity == 8,
               "segment: invalid connected components connectivity: must be either 4 or 8");
   SVC_REQUIRE(params.morph_rect_w > 0 && params.morph_rect_h > 0, "segment: morphology rectangle must be positive");
+  if ((params.cluster_count > 64 || params.attempt_count > 16) && params.cluster_count <= 255 && params.attempt_count <= 64)
+    return segment_frames_by_calls(d_inlier_mask, d_mv_xy, mv_field_w, mv_field_h, n_frames, mv_block_w, mv_block_h, params, seed,
+                                   d_block_types, static_cast<hipStream_t>(stream));
   SVC_REQUIRE(workspace_bytes >= svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames, params.attempt_count),
               "segment: workspace of %llu B is smaller than the %llu B needed", (unsigned long long)workspace_bytes,
               (unsigned long long)svc_hip_segment_workspace_bytes(mv_field_w, mv_field_h, n_frames, params.attempt_count));

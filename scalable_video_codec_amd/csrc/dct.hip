@@ -24,8 +24,11 @@
 // LDS ordering -- and one channel's 1-2 KiB LDS slab is reused for the next.
 // LDS pitches (144 B rows; 1152 / 2432 B slabs) make both the row writes
 // (ds_write_b128) and the column reads (ds_read_b128 / ds_read_b64) conflict-free.
-// Stores: N = 8, float2 per lane = 512 contiguous bytes per wave instruction;
-// N = 16, one float per lane = 256 contiguous bytes.
+// Stores: N = 8, float2 per lane = 512 contiguous bytes per wave instruction; N = 16, one float per lane = 256 contiguous bytes -- which is
+// NOT what holds N = 16 at 0.65 of the HBM peak against N = 8's 0.76: a 16 x 16 form with eight segment columns per wave, two adjacent
+// columns per lane and float2 stores (512 bytes per instruction; dct16_wide_kernel, commit e2da6a1) measures level with this one at C5
+// (1.502-1.513 against 1.507-1.516 ms serial, profiles/r06_ab_dct16_wide.txt) and was removed.  N = 16 is bound by its f64 arithmetic:
+// 600 f64 instructions per lane and segment row (420 FMA + 90 MUL + 90 ADD) against 348 at N = 8, see DESIGN.md 4.2.
 #include <algorithm>
 
 #include "luma16.hpp"
@@ -159,9 +162,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-#ifndef SVC_DCT16_WIDE
-#define SVC_DCT16_WIDE 1
-#endif
 constexpr int kRowPitch = 144;                  // 16 f64 + 16 B pad
 constexpr int kSlab8 = 8 * kRowPitch;           // 1152 B  (= 128 mod 256)
 constexpr int kSlab16 = 16 * kRowPitch + 128;   // 2432 B  (= 128 mod 256)
@@ -194,8 +194,10 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // pyramid -> motion search -> RANSAC -> segmentation of the SAME frame -- that is why the two-pass step reads the BGR clip twice.  Speculation
 // removes the second read: SPEC = 1 runs at the FRONT of the step (with LUMA), quantises EVERY tile as background (id 0: bg_step) and leaves the
 // luma plane; once the ids exist, SPEC = 2 redoes exactly the tiles of foreground MV blocks (fg_list, built by fg_list_kernel) with fg_step:
-// a fixed grid whose workgroups walk the list.  Same arithmetic, same bytes as SPEC = 0 with the ids up front.  The redo costs 15 bytes per
-// foreground pixel; the saving is 3 bytes per pixel of every frame: ahead while less than ~17 % of the MV blocks are foreground (C3: 0.5 %).
+// a fixed grid whose workgroups walk the list.  Same arithmetic, same bytes as SPEC = 0 with the ids up front.  By bytes alone (15 per
+// foreground pixel redone against 3 per pixel saved) speculation would pay up to ~17 % foreground; MEASURED on MI355X it pays below ~2-3 % --
+// the redo moves scattered 16-pixel pieces at a third of the streaming rate (profiles/r05_ab_speculative_quant.txt: at 13 % foreground the
+// speculative step is 19 % slower).  svc_hip_count_foreground is how a caller decides (svc::ClipEncoder does, per chunk: C3 has 0.5 %).
 template <int N, bool QUANT, bool WIRE, bool LUMA = false, int SPEC = 0>
 __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
   static_assert(!LUMA || (WIRE && !QUANT) || (QUANT && !WIRE && SPEC == 1), "the luma by-product rides on the raw-coefficient record emitter or on the speculative quantiser");
@@ -397,90 +399,6 @@ __global__ __launch_bounds__(256) void dct_kernel(DctArgs a) {
     }
   }
   }  // the trips of SPEC = 2 (one trip otherwise); a slab is rewritten by the wave that owns it, behind its own wave_lds_sync
-}
-
-// ---- 16 x 16 planes, two adjacent columns per lane (round 6) ---------------------------------------------------------------
-// dct_kernel<16> stores one float per lane: a wave's four segment columns are 64 adjacent coefficients = 256 contiguous bytes per store
-// instruction, against 512 for N = 8 (float2 per lane).  Here a wave owns EIGHT adjacent segment columns (128 pixels x 16 rows): the row pass
-// runs twice (segment columns 0-3, then 4-7; lane = (segment column, row) as before) into eight slabs, and in the column pass lane L takes
-// the adjacent columns 2 L, 2 L + 1 of the 128 -- two 16-point column transforms per lane, float2 stores, 512 contiguous bytes per
-// instruction.  Same dct1d chains on the same operands in the same order as dct_kernel<16>: the same bits.  128-lane workgroups (two waves x
-// eight slabs = 38 KB of LDS).  Planes only (QUANT or raw), optionally the luma plane + every tile as background (SPEC 1); the record
-// emitter and the foreground redo keep dct_kernel<16>.  Needs W / 16 to be a multiple of 8 (launch_dct checks).
-template <bool QUANT, bool LUMA, int SPEC>
-__global__ __launch_bounds__(128) void dct16_wide_kernel(DctArgs a) {
-  static_assert(!LUMA || (QUANT && SPEC == 1), "the luma by-product rides on the speculative quantiser here");
-  constexpr int N = 16, kSlab = kSlab16, kCols = 8;  // segment columns per wave
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kCols * kSlab];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t sc0 = (xcd_contiguous_block(blockIdx.x, gridDim.x) * 2u + wave) * kCols;  // the wave's first segment column
-  if (sc0 >= a.total_segcols) return;
-  const uint32_t band_g = sc0 / a.segs_per_band, seg0 = sc0 - band_g * a.segs_per_band;  // segs_per_band % 8 == 0: one band, one frame
-  const uint32_t frame = band_g / a.bands_per_frame, band = band_g - frame * a.bands_per_frame;
-  const uint32_t y_pix = band * N, x_pix0 = seg0 * 16;
-  const uint32_t j = lane & 15u, q = lane >> 4;  // row pass: row j of segment column q (first trip), 4 + q (second)
-
-  uint32_t wds[2][12];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const uint4* p = reinterpret_cast<const uint4*>(a.bgr + (size_t)frame * a.frame_stride + ((size_t)(y_pix + j) * a.w + x_pix0 + (4 * t + q) * 16) * 3);
-    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-    wds[t][0] = v0.x; wds[t][1] = v0.y; wds[t][2] = v0.z; wds[t][3] = v0.w;
-    wds[t][4] = v1.x; wds[t][5] = v1.y; wds[t][6] = v1.z; wds[t][7] = v1.w;
-    wds[t][8] = v2.x; wds[t][9] = v2.y; wds[t][10] = v2.z; wds[t][11] = v2.w;
-  }
-  if (LUMA) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      uint32_t y16[4];
-      luma16(wds[t], y16);
-      *reinterpret_cast<uint4*>(a.luma + (size_t)frame * a.luma_stride + (size_t)(y_pix + j) * a.w + x_pix0 + (4 * t + q) * 16) =
-          make_uint4(y16[0], y16[1], y16[2], y16[3]);
-    }
-  }
-  uint8_t* wslab = lds + wave * kCols * kSlab;
-  const uint32_t x_col = x_pix0 + 2 * lane;  // column pass: this lane's two columns
-  float step = 1.f, inv_step = 1.f;
-  if (QUANT) {
-    uint32_t t = 0;
-    if (SPEC == 0) t = a.types[(size_t)frame * a.mv_blocks + (y_pix / a.mv_bh) * a.mfw + x_col / a.mv_bw];
-    step = t == 0 ? a.bg_step : a.fg_step;
-    inv_step = t == 0 ? a.bg_inv : a.fg_inv;
-  }
-  float* out_frame = a.planes + (size_t)frame * 3 * a.w * a.h;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      int x[16];
-      double r[16];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) x[p] = (int)((wds[t][(3 * p + c) >> 2] >> (8 * ((3 * p + c) & 3))) & 0xFFu);
-      dct1d<16, int>(x, r);
-      double2* row = reinterpret_cast<double2*>(wslab + (4 * t + q) * kSlab + j * kRowPitch);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) row[i] = make_double2(r[2 * i], r[2 * i + 1]);
-    }
-    wave_lds_sync();
-    const uint8_t* cs = wslab + (lane >> 3) * kSlab + (lane & 7u) * 16;
-    double ca[16], cb[16], ya[16], yb[16];
-#pragma unroll
-    for (int y = 0; y < 16; ++y) {
-      const double2 t = *reinterpret_cast<const double2*>(cs + y * kRowPitch);
-      ca[y] = t.x;
-      cb[y] = t.y;
-    }
-    dct1d<16, double>(ca, ya);
-    dct1d<16, double>(cb, yb);
-    float* dst = out_frame + (size_t)c * a.w * a.h + (size_t)y_pix * a.w + x_col;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      f32x2 f = {(float)ya[v], (float)yb[v]};
-      if (QUANT) f = quant2_fast(f, step, inv_step);
-      *reinterpret_cast<float2*>(dst + (size_t)v * a.w) = make_float2(f.x, f.y);
-    }
-    wave_lds_sync();  // the slabs are rewritten by the next channel
-  }
 }
 
 // The foreground MV blocks of a batch of frames as a list (order irrelevant: every entry is redone independently).
@@ -705,11 +623,6 @@ int launch_dct(const uint8_t* d_bgr, uint64_t frame_stride, uint32_t n_frames, u
     else { if (quant) SVC_DCT_LAUNCH(8, true, false); else SVC_DCT_LAUNCH(8, false, false); }
   } else {
     if (wire) { if (quant) SVC_DCT_LAUNCH(16, true, true); else SVC_DCT_LAUNCH(16, false, true); }
-    else if (SVC_DCT16_WIDE && a.segs_per_band % 8 == 0) {
-      const dim3 wgrid(div_up(a.total_segcols, 16)), wblock(128);
-      if (quant) hipLaunchKernelGGL((dct16_wide_kernel<true, false, 0>), wgrid, wblock, 0, stream, a);
-      else hipLaunchKernelGGL((dct16_wide_kernel<false, false, 0>), wgrid, wblock, 0, stream, a);
-    }
     else { if (quant) SVC_DCT_LAUNCH(16, true, false); else SVC_DCT_LAUNCH(16, false, false); }
   }
 #undef SVC_DCT_LAUNCH
@@ -764,8 +677,6 @@ int launch_dct_quant_speculative(const uint8_t* d_bgr, uint64_t frame_stride, ui
   a.fg_inv = a.bg_inv = 1.0f / a.bg_step;
   const dim3 grid(div_up(a.total_segcols, 256 / block)), blk(256);
   if (block == 8) hipLaunchKernelGGL((dct_kernel<8, true, false, true, 1>), grid, blk, 0, stream, a);
-  else if (SVC_DCT16_WIDE && a.segs_per_band % 8 == 0)
-    hipLaunchKernelGGL((dct16_wide_kernel<true, true, 1>), dim3(div_up(a.total_segcols, 16)), dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((dct_kernel<16, true, false, true, 1>), grid, blk, 0, stream, a);
   return check_launch("dct_kernel<speculative>");
 }

@@ -180,18 +180,21 @@ struct ClipEncoder::Impl {
     fg_blocks[slot] = (uint64_t)Pn(m) * blocks;
     ++n_fg;
   }
+  void PollForeground() {  // the newest measurement that has landed, if any, becomes the share the policy acts on; never waits
+    for (uint64_t k = n_fg; k > 0 && k + kFgSlots > n_fg; --k) {  // newest first
+      const int slot = (int)((k - 1) % kFgSlots);
+      if (!fg_pending[slot]) continue;
+      if (!Ready(e_fg[slot])) continue;
+      fg_share = (double)fg_host[slot] / (double)fg_blocks[slot];
+      break;
+    }
+  }
   bool DecideSpeculation() {
     if (!spec_quant || c.two_bgr_passes) return false;
     ++n_decided;
     bool yes = c.always_speculate;
     if (!yes) {
-      for (uint64_t k = n_fg; k > 0 && k + kFgSlots > n_fg; --k) {  // newest first
-        const int slot = (int)((k - 1) % kFgSlots);
-        if (!fg_pending[slot]) continue;
-        if (!Ready(e_fg[slot])) continue;
-        fg_share = (double)fg_host[slot] / (double)fg_blocks[slot];
-        break;
-      }
+      PollForeground();
       yes = fg_share >= 0.0 && fg_share <= kSpecMaxShare;
     }
     n_spec += yes;
@@ -639,6 +642,7 @@ void ClipEncoder::ResetPolicy() {
 
 void ClipEncoder::PolicyInfo(uint64_t* chunks_decided, uint64_t* chunks_speculated, double* foreground_share) {
   Sync();
+  p_->PollForeground();
   if (chunks_decided) *chunks_decided = p_->n_decided;
   if (chunks_speculated) *chunks_speculated = p_->n_spec;
   if (foreground_share) *foreground_share = p_->fg_share;

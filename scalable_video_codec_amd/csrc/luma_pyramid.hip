@@ -363,6 +363,9 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
 #ifndef SVC_PYR_STRIP_NT
 #define SVC_PYR_STRIP_NT 0
 #endif
+#ifndef SVC_PYR_STRIP_HALO_MASKED
+#define SVC_PYR_STRIP_HALO_MASKED 1
+#endif
 struct PyrStripArgs {
   uint8_t* pyr;
   uint64_t pyr_stride, src_off, dst_off;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
 #else
     v = *reinterpret_cast<const uint2*>(rp + col);
 #endif
-#if SVC_PYR_STRIP_NOHALO
+#if SVC_PYR_STRIP_NOHALO || SVC_PYR_STRIP_HALO_MASKED
     hw = v.x;
 #else
     hw = *reinterpret_cast<const uint32_t*>(rp + hcol);
@@ -432,8 +435,26 @@ __global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
   constexpr int kRows = 2 * OB + 3;
   uint2 rv[kRows];
   uint32_t rh[kRows];
+#if SVC_PYR_STRIP_HALO_MASKED
+  // the strip's extra dword per row is needed by two lanes only: loaded under their exec mask, in one block in front of the rows (a load
+  // instruction's cost in the texture addresser grows with its active lanes: with all 64 lanes loading it the pass took 0.215 instead of
+  // 0.180 ms without it, profiles/r06_ab_pyr_standalone.txt)
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) rh[r] = 0;
+  if (lane == 0 || last) {
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+      rh[r] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(min(2 * oy0 - 2 + r, h), h) * (size_t)w + hcol);
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    uint32_t unused;
+    fetch(2 * oy0 - 2 + r, rv[r], unused);
+  }
+#else
 #pragma unroll
   for (int r = 0; r < kRows; ++r) fetch(2 * oy0 - 2 + r, rv[r], rh[r]);  // rows past the band's last output (and past the plane: clamped) are not used
+#endif
   Row s, e;  // s = r[2 oy - 2] + 4 r[2 oy - 1] + 8, e = r[2 oy]
   constexpr uint32_t k8 = 0x00080008u;
   {

@@ -51,6 +51,24 @@ def test_bench_line_contract():
     for key in ("reference_signatures_fps", "stream_encoder_fps", "reference_application_fps", "reference_application_batched_encoder_fps"):
         assert key in e and (e[key] is None or e[key] > 0), (key, e)  # None = not measured here (the *_note beside it says why)
         assert e[key] is not None or key.replace("_fps", "_note") in e, (key, e)
+    # the batched driver's rate explains itself (round 6): >= 1 s of passes, per-batch phases from the encoder's own clocks, the cores it had
+    if e["stream_encoder_fps"] is not None:
+        ph = e["stream_encoder_phases"]
+        assert ph["seconds"] >= 1.0 or ph["passes"] == 64
+        assert set(ph["host_ms_per_batch"]) == {"staging", "slot_wait", "deliver_wait", "sink", "wall"} and set(ph["device_ms_per_batch"]) == {"h2d", "kernels", "d2h"}
+        assert ph["host_cores"] >= 1 and ph["copy_threads"] >= 1 and ph["batches"] >= ph["passes"] >= 1 and ph["h2d_GBps"] > 0 and ph["d2h_GBps"] > 0
+    # what `value` is, and what a clip encoded once costs beside it (round 6): schema and identities only
+    assert d["config"]["value_is"].startswith("steady state") and d["config"]["chunks_per_step"] >= 1 and d["config"]["output_sets"] >= 1
+    pol = d["config"]["speculation_policy"]
+    assert pol["chunk_launches"] == d["steps"] * d["config"]["chunks_per_step"] and 0 <= pol["speculated"] <= pol["had_the_choice"] <= pol["chunk_launches"]
+    fe = d["first_encode"]
+    assert fe["unit"] == "frames/s" and fe["reps"] >= 1 and fe["encoded_frames"] == d["config"]["encoded_frames_per_step"]
+    for key in ("once_through", "with_prior"):
+        row = fe[key]
+        assert row["ms_min"] <= row["ms_median"] <= row["ms_max"] and abs(row["value"] - fe["encoded_frames"] / (row["ms_median"] * 1e-3)) <= 1e-6 * row["value"]
+        assert 0 <= row["chunk_launches_speculated"] <= row["chunk_launches"] == fe["reps"] * fe["chunks_per_step"]
+    assert fe["once_through"]["chunk_launches_speculated"] == 0 or d["config"]["chunks_per_step"] > 1  # a load voids the policy
+    assert fe["policy_voided_steps"]["steps"] == d["steps"] and fe["policy_voided_steps"]["value"] > 0
     assert set(d["hbm_streaming_measured"]) >= {"read_only", "write_only", "copy_1_read_1_write", "3_read_1_write", "unit"}
     assert not any(k.startswith("frac_of_streaming") for k in r)
     assert "traffic_source" in r and d["config"]["driver"].startswith("svc::ClipEncoder")

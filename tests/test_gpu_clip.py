@@ -220,9 +220,10 @@ def test_the_foreground_prior_survives_a_load_only_on_request(native):
     for keep in (False, True):
         enc = clipmod.Clip(big, big.frames, tuning=clipmod.KEEP_FOREGROUND_PRIOR if keep else 0)
         enc.load_frames(frames)
-        for _ in range(6):
-            enc.step()
-        enc.sync()
+        for _ in range(2):  # the host enqueues faster than the GPU measures: the first burst learns the share, the second acts on it
+            for _ in range(3):
+                enc.step()
+            enc.sync()
         warm = enc.policy_info()
         assert 0 <= warm["foreground_share"] <= 0.02 and warm["chunks_speculated"] > 0
         enc.load_frames(frames)          # "the next piece of the stream"

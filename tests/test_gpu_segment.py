@@ -50,6 +50,24 @@ def test_segment_parameters(native, oracle, kw):
     assert np.array_equal(got.astype(np.uint32), want)
 
 
+@pytest.mark.parametrize("kw", [dict(cluster_count=100), dict(attempt_count=20), dict(cluster_count=255, attempt_count=17, max_iter_count=4)])
+def test_segment_beyond_the_fused_kernels_tables(native, oracle, kw):
+    """The reference's Validate admits any positive cluster / attempt count (libs/encoder.cpp:39-61).  The fused kernels hold tables for 64
+    clusters and 16 attempts; beyond that -- up to the 255 / 64 of the per-call k-means -- svc_hip_segment_frames composes the per-call
+    entry points frame by frame (synchronously) instead of refusing: the oracle's region ids, several frames, frame f on seed + f."""
+    rng = np.random.default_rng(11)
+    mfw, mfh, frames = 60, 34, 3
+    masks, mvs = zip(*[_scene(rng, mfw, mfh, 3 + f, 0.04) for f in range(frames)])
+    masks, mvs = np.stack(masks), np.stack(mvs)
+    got = native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh, seed=77, **kw).cpu().numpy()
+    okw = {"attempts" if k == "attempt_count" else "max_iter" if k == "max_iter_count" else k: v for k, v in kw.items()}
+    for f in range(frames):
+        want = oracle.segment(masks[f], mvs[f], mfw, mfh, seed=77 + f, **okw)
+        assert np.array_equal(got[f].astype(np.uint32), want), (kw, f)
+    with pytest.raises(native.SvcError):
+        native.segment_frames(torch.from_numpy(masks).cuda(), torch.from_numpy(mvs).cuda(), mfw, mfh, seed=77, cluster_count=256)
+
+
 def test_segment_edge_cases(native, oracle):
     mfw, mfh = 30, 20
     n = mfw * mfh

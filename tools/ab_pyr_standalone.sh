@@ -4,8 +4,8 @@
 # nomath / nohalo are TIMING experiments (wrong results): the pass without its arithmetic, without the strip's extra dword per row.
 set -eu
 cd "$GRAFT_REPO_ROOT"
-cp scalable_video_codec_amd/libsvc_hip.so /tmp/asbuilt.so
-for v in pyr_tiled pyr_bandmajor pyr_ob4 pyr_ob12 pyr_ob16 pyr_nt pyr_nohalo pyr_nomath pyr_nomath_nohalo; do
+cp scalable_video_codec_amd/libsvc_hip.so /tmp/asbuilt.so; trap "cp /tmp/asbuilt.so scalable_video_codec_amd/libsvc_hip.so" EXIT
+for v in ${PYR_VARIANTS:-pyr_tiled pyr_bandmajor pyr_ob4 pyr_ob12 pyr_ob16 pyr_nt pyr_nohalo pyr_nomath pyr_nomath_nohalo}; do
   cp scalable_video_codec_amd/_ab_${v}_libsvc_hip.so scalable_video_codec_amd/libsvc_hip.so; echo "== $v"; python3 tools/ubench_pyr_standalone.py 2>/dev/null | grep -v "alone again"
 done
 cp /tmp/asbuilt.so scalable_video_codec_amd/libsvc_hip.so; echo "== as built"; python3 tools/ubench_pyr_standalone.py 2>/dev/null

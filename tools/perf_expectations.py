@@ -30,6 +30,13 @@ def expectations(d: dict):
     if d.get("sustained"):
         yield "sustained loop ran >= 3 s", d["sustained"]["seconds"] >= 3.0
         yield "sustained step within 5 % of the timed step", abs(d["sustained"]["ms_per_step"] / d["ms_per_step"] - 1) <= 0.05
+    fe = d.get("first_encode")
+    if fe:
+        # round 6: what a clip encoded ONCE costs next to the steady-state `value` (the order of the once-through step is two passes: nothing is
+        # known about the clip), and the state of a stream's next piece
+        yield "a clip encoded once within 10 % of the steady-state step", fe["once_through"]["ms_median"] <= 1.10 * d["ms_per_step"]
+        yield "once-through step did not speculate (a load voids the policy)", fe["once_through"]["chunk_launches_speculated"] == 0 or fe["chunks_per_step"] > 2
+        yield "a stream's next piece (prior kept) within 12 % of the steady-state step", fe["with_prior"]["ms_median"] <= 1.12 * d["ms_per_step"]
     c = d.get("cpu_baseline")
     if c:
         yield ">= 30x the one-core CPU row (north_star, HBM-resident)", d["value"] >= 30 * c["value"]
