@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 // LDS, store the interior to the level-0 plane, and then each lane produces 4 level-1 pixels
 // from the LDS copy.  Versus luma_kernel + pyr_down_kernel this removes the re-read of the
 // whole luma plane and one launch; the halo rows cost 12.5 % more BGR reads, served from L2.
+#ifndef SVC_LUMA_HALO_DWORD
+#define SVC_LUMA_HALO_DWORD 0
+#endif
 #ifndef SVC_LUMA_TW
 #define SVC_LUMA_TW 128
 #endif
@@ -295,8 +298,17 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
     const int yr = reflect101(y0 - 2 + r, h);
     const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
     if (FROM_BGR) {
+#if SVC_LUMA_HALO_DWORD
+      // A/B variant (profiles/r06_ab_luma_halo.txt): one unaligned dword that ENDS with the pixel instead of three byte loads -- 2 - 4 % SLOWER
+      // (0.564 - 0.579 against 0.550 - 0.558 ms at C3): an unaligned dword is two requests where it straddles.  A halo pixel's column is never
+      // 0 -- the reflected columns are 1, 2, w - 3, w - 2 -- so the byte in front of it is in the same row
+      typedef uint32_t u32_a1 __attribute__((aligned(1)));
+      const uint32_t v = *reinterpret_cast<const u32_a1*>(src + ((size_t)yr * w + reflect101(x, w)) * 3 - 1);
+      tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of((v >> 8) & 0xFFu, (v >> 16) & 0xFFu, v >> 24);
+#else
       const uint8_t* p = src + ((size_t)yr * w + reflect101(x, w)) * 3;
       tile[r * kPitch + kOff + (x - x0)] = (uint8_t)luma_of(p[0], p[1], p[2]);
+#endif
     } else {
       tile[r * kPitch + kOff + (x - x0)] = src[(size_t)yr * w + reflect101(x, w)];
     }
@@ -363,8 +375,8 @@ __global__ __launch_bounds__(256) void luma_pyr1_kernel(LumaPyr1Args a) {
 #ifndef SVC_PYR_STRIP_NT
 #define SVC_PYR_STRIP_NT 0
 #endif
-#ifndef SVC_PYR_STRIP_HALO_MASKED
-#define SVC_PYR_STRIP_HALO_MASKED 1
+#ifndef SVC_PYR_STRIP_HALO
+#define SVC_PYR_STRIP_HALO 1
 #endif
 struct PyrStripArgs {
   uint8_t* pyr;
@@ -378,8 +390,15 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint16_t k, uint32_t c) {
   return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) * k + __builtin_bit_cast(u16x2_t, c)));
 }
 
+// SVC_PYR_STRIP_HALO: how the strip's own neighbours (two column sums left of it, one right) get into lane 0 / the strip's last lane --
+//   1 (as built)  one more vector dword per row under a two-lane exec mask, in one block in front of the rows;
+//   0             the same dword loaded by all 64 lanes from per-lane addresses: + 6 % (a load costs the texture addresser by its active lanes);
+//   2             two SCALAR loads per row (the addresses are wave-uniform; `src` is a __restrict__ kernel argument, so hipcc emits
+//                 s_load_dword) and their column sums on the scalar unit -- 25 % fewer vector instructions, 19 fewer vector loads, and + 6 %:
+//                 38 scalar loads per wave that must ALL have returned (lgkmcnt(0)) before the first row is touched.
+// alone over a C3-sized clip, one box: 0.2050 / 0.2180 / 0.2168 ms (profiles/r06_ab_pyr_strip.txt, section 9).
 template <int OB>
-__global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
+__global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a, const uint8_t* __restrict__ pyr_in, uint8_t* __restrict__ pyr_out) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6));
   if (wv >= a.total_waves) return;
@@ -393,95 +412,125 @@ __global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
   const int w = (int)a.sw, h = (int)a.sh, dw = w >> 1, dh = h >> 1;
   const int x0 = (int)strip * 512, valid = min(512, w - x0), la = valid / 8 - 1, xe = x0 + valid;
   const int oy0 = (int)band * OB, rows = min(OB, dh - oy0);
-  const uint8_t* src = a.pyr + (size_t)frame * a.pyr_stride + a.src_off;
-  uint8_t* dst = a.pyr + (size_t)frame * a.pyr_stride + a.dst_off;
+  const uint8_t* src = pyr_in + (size_t)frame * a.pyr_stride + a.src_off;  // the source plane is only read, the destination plane only
+  uint8_t* dst = pyr_out + (size_t)frame * a.pyr_stride + a.dst_off;       // written, and they do not overlap: __restrict__ holds
 
   const uint32_t col = (uint32_t)x0 + min(lane, (uint32_t)la) * 8u;
-  // the extra dword and which of its bytes become (lo, hi) of the pair H: lane 0 -> columns (x0 - 2, x0 - 1), reflected (2, 1) at the plane's
-  // left border; lane `la` -> column xe, reflected w - 2 at the right border; selector 0x0c = a zero byte
-  uint32_t hcol = col, hsel = 0x0c0c0c0cu;
-  if (lane == 0) { hcol = x0 ? (uint32_t)x0 - 4u : 0u; hsel = x0 ? 0x0c030c02u : 0x0c010c02u; }
-  if (lane == (uint32_t)la) { hcol = xe < w ? (uint32_t)xe : (uint32_t)w - 4u; hsel = xe < w ? 0x0c0c0c00u : 0x0c0c0c02u; }
   const bool last = lane == (uint32_t)la;
+  // the strip's neighbours as a pair H = (lo, hi) of u16: left of it the columns (x0 - 2, x0 - 1) -- bytes 2, 3 of the dword in front of the
+  // strip, reflected (columns 2, 1: bytes 2, 1 of the strip's first dword) at the plane's left border; right of it column xe in lo -- byte 0 of
+  // the dword behind the strip, reflected (column w - 2: byte 2 of the plane's last dword) at the right border
+  const uint32_t hcol_l = x0 ? (uint32_t)x0 - 4u : 0u, hcol_r = xe < w ? (uint32_t)xe : (uint32_t)w - 4u;
+  const uint32_t hsel_l = x0 ? 0x0c030c02u : 0x0c010c02u, hsel_r = xe < w ? 0x0c0c0c00u : 0x0c0c0c02u;  // v_perm selectors; 0x0c = a zero byte
+#if SVC_PYR_STRIP_HALO != 2
+  uint32_t hcol = col, hsel = 0x0c0c0c0cu;
+  if (lane == 0) { hcol = hcol_l; hsel = hsel_l; }
+  if (last) { hcol = hcol_r; hsel = hsel_r; }
+#endif
 
-  // a source row -> its five pair registers
-  struct Row { uint32_t e0, o0, e1, o1, hh; };
-  auto fetch = [&](int y, uint2& v, uint32_t& hw) {
-    const uint8_t* rp = src + (size_t)reflect101(min(y, h), h) * (size_t)w;  // wave-uniform
+  // a source row -> its pair registers (E = bytes 0, 2; O = bytes 1, 3 of each dword)
+  struct Row { uint32_t e0, o0, e1, o1; };
+  auto row_offset = [&](int r) { return (uint32_t)reflect101(min(2 * oy0 - 2 + r, h), h) * (uint32_t)w; };  // wave-uniform; a plane is < 4 GB
+  auto fetch = [&](int r, uint2& v) {
 #if SVC_PYR_STRIP_NT
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    const u32x2_t nt = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(rp + col));
+    const u32x2_t nt = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src + row_offset(r) + col));
     v = make_uint2(nt.x, nt.y);
 #else
-    v = *reinterpret_cast<const uint2*>(rp + col);
-#endif
-#if SVC_PYR_STRIP_NOHALO || SVC_PYR_STRIP_HALO_MASKED
-    hw = v.x;
-#else
-    hw = *reinterpret_cast<const uint32_t*>(rp + hcol);
+    v = *reinterpret_cast<const uint2*>(src + row_offset(r) + col);
 #endif
   };
-  auto split = [&](const uint2& v, uint32_t hw) {
+  auto split = [&](const uint2& v) {
     Row r;
     r.e0 = v.x & 0x00FF00FFu; r.o0 = __builtin_amdgcn_perm(0u, v.x, 0x0c030c01u);
     r.e1 = v.y & 0x00FF00FFu; r.o1 = __builtin_amdgcn_perm(0u, v.y, 0x0c030c01u);
-    r.hh = __builtin_amdgcn_perm(0u, hw, hsel);
     return r;
   };
 
-  // every source row of the band is requested before the first is used (2 OB + 3 rows x 12 bytes per lane in flight: the pass is bound by
-  // memory latency, not by arithmetic -- a version that walked the band with two rows of prefetch measured level with the LDS-tiled pass
-  // it replaces, profiles/r06_ab_pyr_strip.txt); straight-line code, so the compiler's vmcnt waits are exact and rows are consumed as they land
+  // every source row of the band is requested before the first is used (2 OB + 3 rows in flight: a version that walked the band with two
+  // rows of prefetch measured level with the LDS-tiled pass it replaces); straight-line code, so the compiler's waits are exact and rows are
+  // consumed as they land
   constexpr int kRows = 2 * OB + 3;
   uint2 rv[kRows];
-  uint32_t rh[kRows];
-#if SVC_PYR_STRIP_HALO_MASKED
-  // the strip's extra dword per row is needed by two lanes only: loaded under their exec mask, in one block in front of the rows (a load
-  // instruction's cost in the texture addresser grows with its active lanes: with all 64 lanes loading it the pass took 0.215 instead of
-  // 0.180 ms without it, profiles/r06_ab_pyr_standalone.txt)
-#pragma unroll
-  for (int r = 0; r < kRows; ++r) rh[r] = 0;
-  if (lane == 0 || last) {
-#pragma unroll
-    for (int r = 0; r < kRows; ++r)
-      rh[r] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(min(2 * oy0 - 2 + r, h), h) * (size_t)w + hcol);
-  }
+  // the neighbours' pair per row: hl / hr (uniform: scalar registers) with SVC_PYR_STRIP_HALO == 2, else hh (per lane: lane 0 and the last one)
+  uint32_t hl[kRows], hr[kRows], hh[kRows];
+#if SVC_PYR_STRIP_HALO == 2
+  auto pick = [](uint32_t word, uint32_t sel) {  // what v_perm_b32(0, word, sel) gives for the two selectors in use, on the scalar unit
+    const uint32_t lo = (word >> (8 * (sel & 3u))) & 0xFFu;
+    const uint32_t hi = ((sel >> 16) & 0xFFu) == 0x0cu ? 0u : (word >> (8 * ((sel >> 16) & 3u))) & 0xFFu;
+    return lo | (hi << 16);
+  };
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
-    uint32_t unused;
-    fetch(2 * oy0 - 2 + r, rv[r], unused);
+    const uint32_t ro = row_offset(r);
+    hl[r] = pick(*reinterpret_cast<const uint32_t*>(src + ro + hcol_l), hsel_l);
+    hr[r] = pick(*reinterpret_cast<const uint32_t*>(src + ro + hcol_r), hsel_r);
+    hh[r] = 0;
   }
+#elif SVC_PYR_STRIP_HALO == 1
+  // the extra dword under the exec mask of the two lanes that need it, in one block in front of the rows (a load instruction costs the texture
+  // addresser by its active lanes: with all 64 lanes loading it the pass took 0.215 instead of 0.180 ms without it)
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) hh[r] = hl[r] = hr[r] = 0;
+  if (lane == 0 || last) {
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) hh[r] = *reinterpret_cast<const uint32_t*>(src + row_offset(r) + hcol);
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) hh[r] = __builtin_amdgcn_perm(0u, hh[r], hsel);
 #else
 #pragma unroll
-  for (int r = 0; r < kRows; ++r) fetch(2 * oy0 - 2 + r, rv[r], rh[r]);  // rows past the band's last output (and past the plane: clamped) are not used
+  for (int r = 0; r < kRows; ++r) {
+    hl[r] = hr[r] = 0;
+#if SVC_PYR_STRIP_NOHALO
+    hh[r] = 0;
+#else
+    hh[r] = __builtin_amdgcn_perm(0u, *reinterpret_cast<const uint32_t*>(src + row_offset(r) + hcol), hsel);
 #endif
-  Row s, e;  // s = r[2 oy - 2] + 4 r[2 oy - 1] + 8, e = r[2 oy]
+  }
+#endif
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) fetch(r, rv[r]);  // rows past the band's last output (and past the plane: clamped) are loaded and not used
+
+  // column sums, two columns per register: V(oy) = s + 6 e + (4 o + n) with s = r[2 oy - 2] + 4 r[2 oy - 1] + 8 carried, e = r[2 oy],
+  // o = r[2 oy + 1], n = r[2 oy + 2] (plain 32-bit adds where no pair can carry: v_add3_u32 / s_add)
   constexpr uint32_t k8 = 0x00080008u;
+  Row s, e;
+  uint32_t s_l, e_l, s_r, e_r, s_h, e_h;  // the same for the neighbours' pairs
   {
-    const Row r0 = split(rv[0], rh[0]), r1 = split(rv[1], rh[1]);
-    e = split(rv[2], rh[2]);
+    const Row r0 = split(rv[0]), r1 = split(rv[1]);
+    e = split(rv[2]);
     s.e0 = (r1.e0 << 2) + r0.e0 + k8; s.o0 = (r1.o0 << 2) + r0.o0 + k8;
     s.e1 = (r1.e1 << 2) + r0.e1 + k8; s.o1 = (r1.o1 << 2) + r0.o1 + k8;
-    s.hh = (r1.hh << 2) + r0.hh + k8;
+    s_l = (hl[1] << 2) + hl[0] + k8; e_l = hl[2];
+    s_r = (hr[1] << 2) + hr[0] + k8; e_r = hr[2];
+    s_h = (hh[1] << 2) + hh[0] + k8; e_h = hh[2];
   }
   uint8_t* out = dst + (size_t)oy0 * dw + (x0 >> 1) + 4 * lane;
   const bool mine = lane <= (uint32_t)la;
 #pragma unroll
   for (int i = 0; i < OB; ++i) {
-    const Row o = split(rv[3 + 2 * i], rh[3 + 2 * i]), n = split(rv[4 + 2 * i], rh[4 + 2 * i]);  // r[2 oy + 1], r[2 oy + 2]
-    // column sums V = s + 6 e + (4 o + n); next s = e + 4 o + 8 (plain 32-bit adds where no pair can carry: v_add3_u32)
+    const Row o = split(rv[3 + 2 * i]), n = split(rv[4 + 2 * i]);
     Row v;
     { const uint32_t q = o.e0 << 2; v.e0 = pk_mad(e.e0, 6, s.e0) + q + n.e0; s.e0 = q + e.e0 + k8; }
     { const uint32_t q = o.o0 << 2; v.o0 = pk_mad(e.o0, 6, s.o0) + q + n.o0; s.o0 = q + e.o0 + k8; }
     { const uint32_t q = o.e1 << 2; v.e1 = pk_mad(e.e1, 6, s.e1) + q + n.e1; s.e1 = q + e.e1 + k8; }
     { const uint32_t q = o.o1 << 2; v.o1 = pk_mad(e.o1, 6, s.o1) + q + n.o1; s.o1 = q + e.o1 + k8; }
-    { const uint32_t q = o.hh << 2; v.hh = pk_mad(e.hh, 6, s.hh) + q + n.hh; s.hh = q + e.hh + k8; }
     e = n;
+    // the neighbours' column sums: (V[x0 - 2], V[x0 - 1]) for lane 0, (V[xe], -) for the last lane
+    uint32_t v_l, v_r;
+#if SVC_PYR_STRIP_HALO == 2
+    { const uint32_t q = hl[3 + 2 * i] << 2; v_l = s_l + 6u * e_l + q + hl[4 + 2 * i]; s_l = q + e_l + k8; e_l = hl[4 + 2 * i]; }
+    { const uint32_t q = hr[3 + 2 * i] << 2; v_r = s_r + 6u * e_r + q + hr[4 + 2 * i]; s_r = q + e_r + k8; e_r = hr[4 + 2 * i]; }
+#else
+    { const uint32_t q = hh[3 + 2 * i] << 2; v_l = pk_mad(e_h, 6, s_h) + q + hh[4 + 2 * i]; s_h = q + e_h + k8; e_h = hh[4 + 2 * i]; }
+    v_r = v_l;
+#endif
     // neighbours: the previous lane's second dword (lane 0: the strip's left neighbours), the next lane's first dword (last lane: the right one)
-    const uint32_t pe = __builtin_amdgcn_update_dpp(v.hh << 16, v.e1, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    const uint32_t po = __builtin_amdgcn_update_dpp(v.hh, v.o1, 0x138, 0xf, 0xf, false);
-    uint32_t ne = __builtin_amdgcn_update_dpp(v.hh, v.e0, 0x130, 0xf, 0xf, false);  // wave_shl:1
-    ne = last ? v.hh : ne;
+    const uint32_t pe = __builtin_amdgcn_update_dpp(v_l << 16, v.e1, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 keeps `old`
+    const uint32_t po = __builtin_amdgcn_update_dpp(v_l, v.o1, 0x138, 0xf, 0xf, false);
+    uint32_t ne = __builtin_amdgcn_update_dpp(v_r, v.e0, 0x130, 0xf, 0xf, false);  // wave_shl:1
+    ne = last ? v_r : ne;
     // outputs centred on columns 0, 2 (dword 0) and 4, 6 (dword 1) of the lane
     const uint32_t l2a = __builtin_amdgcn_alignbyte(v.e0, pe, 2), l1a = __builtin_amdgcn_alignbyte(v.o0, po, 2);
     const uint32_t mid = __builtin_amdgcn_alignbyte(v.e1, v.e0, 2), l1b = __builtin_amdgcn_alignbyte(v.o1, v.o0, 2);
@@ -489,7 +538,8 @@ __global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
     const uint32_t qa = pk_mad(v.e0, 6, ((l1a + v.o0) << 2) + l2a + mid);
     const uint32_t qb = pk_mad(v.e1, 6, ((l1b + v.o1) << 2) + mid + r2b);
 #if SVC_PYR_STRIP_NOMATH
-    const uint32_t px = rv[3 + 2 * i].x ^ rv[4 + 2 * i].y ^ rh[3 + 2 * i] ^ rh[4 + 2 * i] ^ (i == 0 ? rv[0].x ^ rv[1].x ^ rv[2].x ^ rh[0] ^ rh[1] ^ rh[2] : 0u);
+    const uint32_t px = rv[3 + 2 * i].x ^ rv[4 + 2 * i].y ^ v_l ^ v_r ^ (i == 0 ? rv[0].x ^ rv[1].x ^ rv[2].x : 0u);
+    (void)qa; (void)qb;
 #else
     const uint32_t px = __builtin_amdgcn_perm(qb, qa, 0x07050301u);  // (>> 8) of the four sums
 #endif
@@ -500,6 +550,7 @@ __global__ __launch_bounds__(256) void pyr_strip_kernel(PyrStripArgs a) {
 #endif
     out += dw;
   }
+  (void)s_l; (void)e_l; (void)s_r; (void)e_r; (void)s_h; (void)e_h;
 }
 
 // any frame width: one pixel per lane
@@ -607,7 +658,8 @@ int launch_pyr_down_levels(uint8_t* d_pyr, uint64_t pyr_stride, uint32_t n_frame
         const uint64_t tw = (uint64_t)sa.strips * sa.bands * n_frames;
         if (tw > 0x7FFFFFFFull) return fail(SVC_ERR_UNSUPPORTED, "pyramid: too many strips for one launch");
         sa.total_waves = (uint32_t)tw;
-        hipLaunchKernelGGL((pyr_strip_kernel<SVC_PYR_STRIP_OB>), dim3(div_up(sa.total_waves, 4)), dim3(256), 0, stream, sa);
+        hipLaunchKernelGGL((pyr_strip_kernel<SVC_PYR_STRIP_OB>), dim3(div_up(sa.total_waves, 4)), dim3(256), 0, stream, sa,
+                           static_cast<const uint8_t*>(d_pyr), d_pyr);
         if ((rc = check_launch("pyr_strip_kernel"))) return rc;
         continue;
       }
