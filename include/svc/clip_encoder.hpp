@@ -14,15 +14,22 @@
 // communication stream of its own.  RANSAC draws and k-means seeds are a function of (seed, clip
 // frame index) only, so a sharded clip encodes to exactly the bytes of the unsharded one.
 //
-// Schedule.  kSerial runs a step's stages back to back on one stream.  kPipelined is a software
-// pipeline over consecutive steps, as a streaming encoder runs consecutive chunks: per call of
-// Step() the main stream carries luma+pyramid of the newest step, the motion search of the one
-// before and the transform of the step four back -- the HBM-bound kernels, back to back -- while
-// RANSAC + segmentation (latency-bound: one workgroup per frame) of the step two back start beside
-// them on a stream of their own (forked at the start of the iteration, in front of the luma launch) and have two
-// iterations to finish, consecutive steps alternating between
-// two such streams, and the halo of the newest step crosses xGMI meanwhile.  The small per-frame outputs exist in four
-// sets, pyramids in two; Flush() drains the pipeline.
+// Schedule.  kSerial runs a step's stages back to back on one stream.  kPipelined is a software pipeline over consecutive steps, as a
+// streaming encoder runs consecutive pieces of a stream: per call of Step() the main stream carries the HBM-bound kernels back to back --
+// at one rank luma+pyramid and the motion search of the newest step (nothing to wait for between them) and the transform of the step three
+// back; on a multi-rank run luma+pyramid of the newest step, the motion search of the one before (its halo has had an iteration to cross
+// xGMI) and the transform of the step four back -- while RANSAC + segmentation (latency-bound: one workgroup per frame) of an earlier step
+// start beside them on a stream of their own (forked at the start of the iteration, in front of the luma launch) and have two iterations to
+// finish, consecutive steps alternating between two such streams.  The small per-frame outputs exist in four sets, pyramids in two; Flush()
+// drains the pipeline.
+//
+// Chunks (round 6).  With ClipEncoderConfig::chunk_pairs a pipelined step at one rank is cut into chunks of that many frame pairs and the
+// pipeline runs over the CHUNKS: every stage launch covers one chunk, RANSAC + segmentation of chunk c run beside the motion search of chunk
+// c + 1 and the transform of chunk c - 1 -- the stages of ONE step overlap each other, so LoadFrames / one Step() / Sync() (a clip encoded
+// once, as the reference encodes it: libs/encoder.cpp:453-664) is no longer a serial chain of whole-shard kernels.  Same bytes for every
+// chunk size (tests/test_gpu_clip.py::test_chunked_steps_equal_whole_steps).  Default: one chunk -- the latency-bound stages take as long
+// for half a shard as for a whole one, so two chunks hold CUs beside the bandwidth kernels twice as long: at 1080p x 300 frames a
+// once-through clip gains up to 5 %, the steady state of back-to-back steps loses 0-4 % (profiles/r06_ab_chunks.txt).
 //
 // Wire output (records of the RAW coefficients, what the reference's encoder emits: libs/encoder.cpp:638-650) with the tuned 8x8 /
 // 16x16 transform reads the BGR clip ONCE per step: the record-emitting transform of step s runs at the FRONT of the step and stores
@@ -92,7 +99,7 @@ struct ClipEncoderConfig {
   // Not tuning but a statement about the input: LoadFrames() brings consecutive pieces of ONE stream, so the foreground share measured on the
   // last piece stays the policy's prior for the next (default: a load voids it; the first step over new frames is then two passes)
   bool keep_foreground_prior = false;
-  uint32_t chunk_pairs = 0;             // pipelined, one rank: frame pairs per chunk of a step; 0 = the driver's choice (see "Chunks" above)
+  uint32_t chunk_pairs = 0;             // pipelined, one rank: frame pairs per chunk of a step; 0 = one chunk (whole-shard launches)
 };
 
 enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kTypePatch, kCount };

@@ -56,9 +56,10 @@ typedef struct svc_clip_config {
   uint32_t clip_frames; /* frames of the whole clip */
   uint32_t rank, world; /* this handle holds shard `rank` of `world` */
   uint32_t schedule;    /* SVC_CLIP_SERIAL / SVC_CLIP_PIPELINED */
-  uint32_t chunk_pairs; /* pipelined, one rank: frame pairs per chunk of a step (a step's stages overlap each other chunk by chunk, so a
-                           clip encoded ONCE does not pay RANSAC + segmentation end to end; clip_encoder.hpp); 0 = the driver's choice.
-                           (Was `reserved0`, always 0, through round 5.) */
+  uint32_t chunk_pairs; /* pipelined, one rank: frame pairs per chunk of a step (a step's stages then overlap each other chunk by chunk, so a
+                           clip encoded ONCE does not pay RANSAC + segmentation end to end; clip_encoder.hpp); 0 = whole-shard launches
+                           (one chunk: best steady state; two chunks at 1080p x 300 frames trade 0-4 % of it for up to 5 % on a
+                           once-through clip).  (Was `reserved0`, always 0, through round 5.) */
   /* Tuning; all zero = the defaults.  These are the A/B switches of the measurements under profiles/ -- they change
    * launch shapes and kernel choice, never results. */
   uint32_t hbma_flags;  /* SVC_HBMA_* passed to svc_hip_hbma_pairs (0 = SVC_HBMA_AUTO) */

@@ -156,11 +156,13 @@ struct ClipEncoder::Impl {
   // small shards do not pay: the front-of-step transform costs a fixed ~10 us more than it saves below ~25 frames of 1080p
   // (profiles/r05_ab_speculative_quant.txt: 1080p shards of 150 / 75 / 38 / 19 frames -6 / -4 / -2 / +-1 %; C2's 29 frames of 720p +5 %)
   static constexpr uint64_t kSpecMinPixels = 50000000ull;  // encoded frames x padded pixels of the shard
-  // a chunk: at least this many pixels x frames, and at most this many chunks per step.  Measured (profiles/r06_ab_chunks.txt): C3 in two
-  // chunks encodes a clip once in 2.49 instead of 2.63 ms at +0.5 % on the steady state; three and five chunks lose more in launches than
-  // they hide; C5's 63 frames of 4K lose 4 % of the steady state to two chunks (its kernels' tails) and stay whole
-  static constexpr uint64_t kChunkMinPixels = 300000000ull;
-  static constexpr uint32_t kMaxAutoChunks = 2;
+  // The driver's own choice (chunk_pairs = 0) is ONE chunk: whole-shard launches, the schedule of rounds 2-5.  Measured (profiles/
+  // r06_ab_chunks.txt, r06_z_final_*): two chunks at C3 encode a clip once in 2.48-2.53 ms instead of 2.55-2.64, but cost the steady state
+  // 0-4 % box to box (RANSAC + segmentation are latency-bound, so two chunks hold CUs beside the bandwidth kernels twice as long, and the
+  // pyramid pass pays the write-back behind the transform twice); three and five chunks lose more; C5 loses 4 % to two.  A caller that
+  // encodes clips once and cares about the latency of one step sets chunk_pairs.
+  static constexpr uint64_t kChunkMinPixels = 300000000ull;  // (the rule an automatic choice would use: chunks of at least this many
+  static constexpr uint32_t kMaxAutoChunks = 1;              //  pixels x frames, at most this many per step)
   DevBuf<uint32_t> fg_dev;
   uint32_t* fg_host = nullptr;
   hipEvent_t e_fg[kFgSlots] = {};
@@ -545,9 +547,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   if (pipelined) m.depth = c.lat_depth ? (int)c.lat_depth : 2;
   m.nsets = !pipelined ? 1 : m.depth + 2;
   // Chunks per step.  Only where one rank holds the clip and the schedule pipelines (a multi-rank step is tied to its neighbour's by the
-  // halo, and its shards are small already).  Default: as many chunks as keep a chunk above kChunkMinPixels, at most kMaxAutoChunks --
-  // enough to overlap the latency-bound stages of one step with its own bandwidth-bound kernels, few enough that the extra launches
-  // (four main-stream kernels per chunk) stay below 1 % of the step (profiles/r06_ab_chunks.txt).
+  // halo, and its shards are small already); default one (see kMaxAutoChunks), chunk_pairs asks for more.
   m.nch = 1;
   if (pipelined && c.world == 1 && P > 1) {
     if (c.chunk_pairs) m.nch = (P + c.chunk_pairs - 1) / c.chunk_pairs;

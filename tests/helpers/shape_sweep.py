@@ -41,11 +41,11 @@ def random_config(rng, i, max_side):
                                mv_block=mv_block, search_range=search, dct_block=dct_block)
 
 
-def check(cfg, oracle, dev, tuning=0):
+def check(cfg, oracle, dev, tuning=0, chunk_pairs=0):
     pw, ph = cfg.padded
     src = synth.SynthClip(cfg.width, cfg.height, cfg.frames, cfg.seed, device=dev)
     frames = torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(cfg.frames)]).contiguous()
-    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED, tuning=tuning)
+    enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED, tuning=tuning, chunk_pairs=chunk_pairs)
     try:
         enc.load_frames(frames)
         for _ in range(3 if not tuning else 6):  # speculating: long enough for every coefficient set to have been a front AND a finish
@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--always-speculate", action="store_true",
                     help="planes + quant by the speculative one-pass form on every step of every configuration it covers (8 / 16 transform blocks, "
                          "padded width of whole 16-pixel segments, MV blocks of whole segments); the others take the two-pass order as ever")
+    ap.add_argument("--chunks", action="store_true",
+                    help="round 6: every configuration with a random number of frame pairs per chunk (1 .. pairs), so that the pipeline runs over "
+                         "the chunks of a step (6-frame clips)")
     ap.add_argument("--shape", action="append", default=[], help="WxH:levels:mv_block:search_range:dct_block -- run these instead of random ones")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -118,15 +121,20 @@ def main():
         args.count = len(fixed)
     for i in range(args.count):
         cfg = fixed[i] if fixed else random_config(rng, i, args.max_side)
+        chunk_pairs = 0
+        if args.chunks:
+            cfg = configs.CodecConfig(cfg.name, cfg.cfg_id, cfg.width, cfg.height, 6, levels=cfg.levels, mv_block=cfg.mv_block, search_range=cfg.search_range,
+                                      dct_block=cfg.dct_block)
+            chunk_pairs = int(rng.integers(1, 6))
         t0 = time.perf_counter()
         try:
-            verdict = check(cfg, oracle, dev, clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0)
+            verdict = check(cfg, oracle, dev, clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0, chunk_pairs)
         except Exception as e:  # noqa: BLE001
             verdict = f"EXCEPTION {type(e).__name__}: {str(e)[:200]}"
             if os.environ.get("SWEEP_TRACE"):
                 traceback.print_exc()
         bad += verdict is not None
-        print(f"{'ok  ' if verdict is None else 'FAIL'} {cfg.name} padded {cfg.padded} {time.perf_counter() - t0:.1f}s {verdict or ''}", flush=True)
+        print(f"{'ok  ' if verdict is None else 'FAIL'} {cfg.name} padded {cfg.padded}{f' chunk_pairs {chunk_pairs}' if chunk_pairs else ''} {time.perf_counter() - t0:.1f}s {verdict or ''}", flush=True)
     print(f"{args.count - bad} of {args.count} configurations equal the oracle", flush=True)
     return 1 if bad else 0
 

@@ -17,8 +17,8 @@ bench)
   for c in C2-720p-3L-dct8 C3b-1080p-4L-dct8-quant C5-4k-4L-dct16; do python3 bench.py --config $c --no-cpu-baseline --no-end-to-end > $F/${tag}_bench_$c.json 2>>$F/bench.err; echo "$c rc=$?"; done
   python3 bench.py --wire --no-cpu-baseline --no-end-to-end > $F/${tag}_bench_C3_wire.json 2>>$F/bench.err; echo "wire rc=$?"
   python3 bench.py --config C3b-1080p-4L-dct8-quant --no-end-to-end > $F/${tag}_bench_C3b_with_cpu.json 2>>$F/bench.err; echo "C3b+cpu rc=$?"
-  # round 6: the whole-shard schedule of rounds 2-5 (one chunk per step) beside the default (two chunks at C3)
-  python3 bench.py --chunk-pairs 299 --no-cpu-baseline --no-end-to-end > $F/${tag}_bench_C3_one_chunk.json 2>>$F/bench.err; echo "one chunk rc=$?" ;;
+  # round 6: two chunks per step (--chunk-pairs 150) beside the default (one chunk: whole-shard launches)
+  python3 bench.py --chunk-pairs 150 --no-cpu-baseline --no-end-to-end > $F/${tag}_bench_C3_two_chunks.json 2>>$F/bench.err; echo "two chunks rc=$?" ;;
 prof)
   bash tools/prof_bench.sh $F/${tag}_z_final_pipelined_profiled --steps 20 --warmup 8 --sustain-seconds 0 > /dev/null; echo prof1 done
   bash tools/prof_bench.sh $F/${tag}_z_final_serial --steps 20 --warmup 8 --schedule serial --sustain-seconds 0 > /dev/null; echo prof2 done
