@@ -141,6 +141,12 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert len(m["ms_per_step_by_rank"]) == 2 and m["ms_per_step_min"] == min(m["ms_per_step_by_rank"]) and m["ms_per_step_max"] == max(m["ms_per_step_by_rank"])
     assert m["frames_by_rank"] == [5, 4] and m["encoded_by_rank"] == [4, 4]
     assert len(m["halo_exchange_ms_by_rank"]) == 2 and all(v is not None and v > 0 for v in m["halo_exchange_ms_by_rank"])
+    # which order each rank ran (round 6): the speculation policy is per rank and involves no collective, so the line carries, per rank, the
+    # launches of the timed region that had the choice and those that speculated (a 5-frame shard never has the choice: two passes)
+    pr = m["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and [x["frames"] for x in pr] == [5, 4] and [x["encoded"] for x in pr] == [4, 4]
+    assert all(x["ms_per_step"] > 0 and x["launches_speculated"] <= x["launches_with_the_choice"] for x in pr)
+    assert all(x["bgr_passes_per_step"] in ("two", "one", "mixed") for x in pr) and [x["bgr_passes_per_step"] for x in pr] == ["two", "two"]
     # the prediction DESIGN.md section 6 makes for this shard size sits next to the measurement (none for a 5-frame shard:
     # the committed table has the BASELINE shard sizes; the field says so instead of inventing a number)
     p = m["prediction"]
