@@ -407,7 +407,8 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     hbma_flags = hbma_flags_of(args)
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
              (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0) | \
-             (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0) | (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0)
+             (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0) | (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0) | \
+             (clipmod.TUNE_WHOLE_SHARD_STEPS if args.whole_shard_steps else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
                        lat_depth=args.lat_depth, tuning=tuning, chunk_pairs=args.chunk_pairs)
@@ -487,6 +488,8 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     encoded = torch.tensor([float(info.pairs)], dtype=torch.float64, device=red_dev)
     st = enc.stage_times_ms()
+    sp = enc.stage_pairs()
+    steps_timed = {k: (sp[k] / info.pairs if info.pairs and sp.get(k) else float(v[1])) for k, v in st.items()}  # halo: once per step
     per_rank = None
     if world > 1:
         # every rank's own clock and halo time: a straggler or a slow link shows up by rank in the line
@@ -504,9 +507,10 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
         # every stage is one launch sequence per step: its per-step time is the average over the launches that were
         # timed (in the pipelined schedule a timed call covers stages of four different steps, and the first call
         # after a drain times fewer of them, so the counts differ from stage to stage)
-        # a stage is launched once per chunk and step (chunks = 1: whole-shard launches); its per-step time is the launches' average x chunks
-        "stage_ms_per_step": {k: v[0] / v[1] * (1 if k == "halo_exchange" else chunks) for k, v in st.items()},
-        "launches_per_step": {k: (1.0 if k == "halo_exchange" else float(chunks)) for k in st},
+        # a stage is launched once per chunk of a step (one chunk by default; a step that finds the pipeline empty may run in two): the driver
+        # counts the frame pairs its timed launches covered, so the per-step time is exact whatever the chunking: total x pairs per step / pairs
+        "stage_ms_per_step": {k: v[0] / steps_timed[k] for k, v in st.items()},
+        "launches_per_step": {k: v[1] / steps_timed[k] for k, v in st.items()},
         "launches_timed": {k: v[1] for k, v in st.items()},
         "chunks": chunks, "policy": policy, "output_sets": enc.output_sets(),
         "timed_steps": timed_steps,
@@ -613,6 +617,9 @@ def main() -> None:
     ap.add_argument("--no-segmentation", action="store_true",
                     help="region ids from the in-repo part only (foreground = one region) instead of the full segmentation glue")
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
+    ap.add_argument("--whole-shard-steps", action="store_true",
+                    help="never the idle-pipeline rule (a step that finds the pipeline empty -- first_encode's once-through step -- runs in two chunks on "
+                         "big shards in the two-pass order); A/B")
     ap.add_argument("--two-bgr-passes", action="store_true",
                     help="luma + pyramid and the transform as two passes over the BGR clip (A/B of the default, which reads it once: the transform at the "
                          "front of the step also leaves the luma plane; what needs region ids -- the records' type words with --wire, the foreground "
@@ -621,8 +628,8 @@ def main() -> None:
                     help="planes + quant: the speculative one-pass form on every step (default: only while the newest foreground share that has arrived "
                          "is at most 2 %%; A/B)")
     ap.add_argument("--chunk-pairs", type=int, default=0,
-                    help="pipelined, one rank: frame pairs per chunk of a step (0 = the driver's choice; a number >= the clip's pairs = whole-shard "
-                         "launches, the schedule of rounds 2-5)")
+                    help="pipelined, one rank: frame pairs per chunk of EVERY step (0 = whole-shard launches, with the idle-pipeline rule for a step "
+                         "that finds the pipeline empty)")
     ap.add_argument("--first-encode-reps", type=int, default=8, help="N = 1: repetitions of {load the clip, ONE step, sync} behind first_encode (0 = skip)")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-stage HIP events on every n-th timed step (every step when --steps < 8)")
     # A/B switches (svc_clip_config tuning fields): kernel choice and launch shapes only, results never change.  The

@@ -29,7 +29,9 @@
 // once, as the reference encodes it: libs/encoder.cpp:453-664) is no longer a serial chain of whole-shard kernels.  Same bytes for every
 // chunk size (tests/test_gpu_clip.py::test_chunked_steps_equal_whole_steps).  Default: one chunk -- the latency-bound stages take as long
 // for half a shard as for a whole one, so two chunks hold CUs beside the bandwidth kernels twice as long: at 1080p x 300 frames a
-// once-through clip gains up to 5 %, the steady state of back-to-back steps loses 0-4 % (profiles/r06_ab_chunks.txt).
+// once-through clip gains up to 5 %, the steady state of back-to-back steps loses 0-4 % (profiles/r06_ab_chunks.txt).  Hence the
+// idle-pipeline rule: only a step that finds the pipeline EMPTY (the first after LoadFrames / Sync) is cut in two, on big shards in the
+// two-pass order; steps that follow each other keep whole-shard launches.
 //
 // Wire output (records of the RAW coefficients, what the reference's encoder emits: libs/encoder.cpp:638-650) with the tuned 8x8 /
 // 16x16 transform reads the BGR clip ONCE per step: the record-emitting transform of step s runs at the FRONT of the step and stores
@@ -99,7 +101,10 @@ struct ClipEncoderConfig {
   // Not tuning but a statement about the input: LoadFrames() brings consecutive pieces of ONE stream, so the foreground share measured on the
   // last piece stays the policy's prior for the next (default: a load voids it; the first step over new frames is then two passes)
   bool keep_foreground_prior = false;
-  uint32_t chunk_pairs = 0;             // pipelined, one rank: frame pairs per chunk of a step; 0 = one chunk (whole-shard launches)
+  uint32_t chunk_pairs = 0;             // pipelined, one rank: frame pairs per chunk of EVERY step; 0 = whole-shard launches, except that a
+                                        // step which finds the pipeline empty (a clip encoded once) runs in two chunks on big shards in the
+                                        // two-pass order (the idle-pipeline rule, Step())
+  bool whole_shard_steps = false;       // never the idle-pipeline rule (A/B)
 };
 
 enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kTypePatch, kCount };
@@ -142,6 +147,7 @@ class ClipEncoder {
 
   // Sum over timed steps of a stage's event time / number of launches timed; Sync()s first.
   void StageTime(Stage s, double* total_ms, uint32_t* launches);
+  uint64_t StagePairs(Stage s);  // frame pairs those launches covered (a step's launches are its chunks): time per step = total x pairs / this
   void ResetTimers();
   uint32_t steps_submitted() const;
   uint32_t chunks_per_step() const;  // launches of every stage per Step()

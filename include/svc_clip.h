@@ -39,6 +39,8 @@ typedef struct svc_clip svc_clip;
  * stream, so the foreground share measured on the last piece stays the speculation policy's prior for the next (default: a load voids it and
  * the first step over new frames runs the plain two-pass order).  Safe at any share: a stale prior costs one slow step, never a byte. */
 #define SVC_CLIP_KEEP_FOREGROUND_PRIOR 64u
+#define SVC_CLIP_TUNE_WHOLE_SHARD_STEPS 128u /* never the idle-pipeline rule (a step that finds the pipeline empty runs in two chunks on big
+                                                shards in the two-pass order: clip_encoder.hpp); A/B */
 
 typedef struct svc_clip_config {
   uint32_t struct_size;   /* sizeof(svc_clip_config) of the caller's build: svc_clip_create refuses any other value, so a
@@ -115,6 +117,8 @@ int svc_clip_sync(svc_clip* clip);            /* flush + wait for the GPU */
 
 /* HIP-event time of a stage summed over the timed steps, and the launches it covers. */
 int svc_clip_stage_time(svc_clip* clip, uint32_t stage, double* total_ms, uint32_t* launches);
+/* Frame pairs the timed launches of a stage covered (a step's launches are its chunks): time per step = total_ms x pairs / this. */
+int svc_clip_stage_pairs(svc_clip* clip, uint32_t stage, uint64_t* pairs);
 int svc_clip_reset_timers(svc_clip* clip);
 
 /* The speculation policy (planes + quant, clip_encoder.hpp): forget what it has measured (syncs first) ... */

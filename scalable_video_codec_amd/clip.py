@@ -20,6 +20,7 @@ _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
 
 SERIAL, PIPELINED = 0, 1
 TUNE_STANDALONE_SHAPES, TUNE_SEGMENT_FORK, TUNE_NARROW_ATTEMPTS, TUNE_INLINE_RMSE, TUNE_TWO_BGR_PASSES, TUNE_ALWAYS_SPECULATE = 1, 2, 4, 8, 16, 32  # svc_clip_config.tuning bits
+TUNE_WHOLE_SHARD_STEPS = 128  # never the idle-pipeline rule (A/B)
 KEEP_FOREGROUND_PRIOR = 64  # same field: the clips loaded are consecutive pieces of one stream (the policy keeps its prior across load_frames)
 STAGES = ("luma_pyramid", "halo_exchange", "hbma", "ransac", "segment", "dct_quant", "type_patch")
 BUFFERS = {"mv": (0, torch.float32), "min_mad": (1, torch.float32), "global_motion": (2, torch.float32),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "svc_clip_flush": (C.c_int, [_vp]),
     "svc_clip_sync": (C.c_int, [_vp]),
     "svc_clip_stage_time": (C.c_int, [_vp, _u32, C.POINTER(C.c_double), C.POINTER(_u32)]),
+    "svc_clip_stage_pairs": (C.c_int, [_vp, _u32, C.POINTER(_u64)]),
     "svc_clip_reset_timers": (C.c_int, [_vp]),
     "svc_clip_reset_policy": (C.c_int, [_vp]),
     "svc_clip_policy_info": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(C.c_double)]),
@@ -246,6 +248,15 @@ class Clip:
             _check(load().svc_clip_stage_time(self._h, i, C.byref(t), C.byref(n)))
             if n.value:
                 out[name] = (t.value, n.value)
+        return out
+
+    def stage_pairs(self) -> Dict[str, int]:
+        """stage -> frame pairs its timed launches covered (a step's launches are its chunks): ms per step = total ms x pairs per step / this."""
+        out = {}
+        for i, name in enumerate(STAGES):
+            n = _u64()
+            _check(load().svc_clip_stage_pairs(self._h, i, C.byref(n)))
+            out[name] = n.value
         return out
 
     # -- outputs ----------------------------------------------------------------------------------

@@ -88,10 +88,16 @@ struct ClipEncoder::Impl {
   // run beside the motion search of chunk c + 1 and the transform of chunk c - 1 -- so a clip that is encoded ONCE (LoadFrames, Step, Sync)
   // no longer pays the latency-bound stages end to end.  Buffers: chunk c of step s lives at offset p0(c) inside set s % nsets; events and
   // "pending" flags are per micro-step slot m % nsets (at most depth + 2 micro-steps are in flight).
-  uint32_t nch = 1, cp = 0;
-  uint32_t StepOf(uint64_t m) const { return (uint32_t)(m / nch); }
-  uint32_t P0(uint64_t m) const { return (uint32_t)(m % nch) * cp; }                    // first pair of the micro-step's chunk
-  uint32_t Pn(uint64_t m) const { return std::min<uint32_t>(cp, sh.pairs - std::min(sh.pairs, P0(m))); }  // its pairs
+  uint32_t nch = 1, cp = 0;  // the configured plan (chunk_pairs); a step may be cut differently (Step(): the idle-pipeline rule), so a
+  // micro-step carries its own description from the moment it enters the pipeline until its last stage has been enqueued
+  struct Micro { uint32_t step = 0, p0 = 0, pn = 0; bool first = true; };
+  static constexpr int kRing = 8;  // > depth + 2 micro-steps in flight
+  Micro ring[kRing], next_micro;
+  uint32_t n_steps = 0;
+  const Micro& At(uint64_t m) const { return ring[(int)(m % (uint64_t)kRing)]; }
+  uint32_t StepOf(uint64_t m) const { return At(m).step; }
+  uint32_t P0(uint64_t m) const { return At(m).p0; }  // first pair of the micro-step's chunk
+  uint32_t Pn(uint64_t m) const { return At(m).pn; }  // its pairs
   int Slot(uint64_t m) const { return (int)(m % (uint64_t)nsets); }
   hipStream_t sM = nullptr, sL[kMaxDepth] = {nullptr, nullptr, nullptr}, sC = nullptr;
   DevBuf<uint8_t> bgr, pyr[2], mask[kSets], seg_ws[kMaxDepth], records[kSets + 1];
@@ -156,13 +162,16 @@ struct ClipEncoder::Impl {
   // small shards do not pay: the front-of-step transform costs a fixed ~10 us more than it saves below ~25 frames of 1080p
   // (profiles/r05_ab_speculative_quant.txt: 1080p shards of 150 / 75 / 38 / 19 frames -6 / -4 / -2 / +-1 %; C2's 29 frames of 720p +5 %)
   static constexpr uint64_t kSpecMinPixels = 50000000ull;  // encoded frames x padded pixels of the shard
-  // The driver's own choice (chunk_pairs = 0) is ONE chunk: whole-shard launches, the schedule of rounds 2-5.  Measured (profiles/
-  // r06_ab_chunks.txt, r06_z_final_*): two chunks at C3 encode a clip once in 2.48-2.53 ms instead of 2.55-2.64, but cost the steady state
-  // 0-4 % box to box (RANSAC + segmentation are latency-bound, so two chunks hold CUs beside the bandwidth kernels twice as long, and the
-  // pyramid pass pays the write-back behind the transform twice); three and five chunks lose more; C5 loses 4 % to two.  A caller that
-  // encodes clips once and cares about the latency of one step sets chunk_pairs.
-  static constexpr uint64_t kChunkMinPixels = 300000000ull;  // (the rule an automatic choice would use: chunks of at least this many
-  static constexpr uint32_t kMaxAutoChunks = 1;              //  pixels x frames, at most this many per step)
+  // The driver's own choice (chunk_pairs = 0) for steps that FOLLOW EACH OTHER is one chunk: whole-shard launches, the schedule of rounds
+  // 2-5.  Measured (profiles/r06_ab_chunks.txt, r06_z_final_*): two chunks at C3 encode a clip once in 2.48-2.53 ms instead of 2.55-2.64, but
+  // cost the steady state 0-4 % box to box (RANSAC + segmentation are latency-bound, so two chunks hold CUs beside the bandwidth kernels
+  // twice as long, and the pyramid pass pays the write-back behind the transform twice); three and five chunks lose more; C5 loses 4 % to two.
+  // Hence the idle-pipeline rule (ClipEncoder::Step): only a step that finds the pipeline empty is cut in two.
+  static constexpr uint64_t kChunkMinPixels = 300000000ull;  // (what an automatic choice for every step would ask of a chunk)
+  // the idle-pipeline rule applies from this many pixels x frames per shard: C3 / C3b (625 M: - 3.6 / - 4.8 %) and C5 (522 M: - 4.5 %, profiles/
+  // r06_ab_chunks.txt: 2.83-2.85 -> 2.70-2.73 ms) were measured; smaller shards were not
+  static constexpr uint64_t kIdleRuleMinPixels = 400000000ull;
+  static constexpr uint32_t kMaxAutoChunks = 1;              // chunks of a step that follows another one
   DevBuf<uint32_t> fg_dev;
   uint32_t* fg_host = nullptr;
   hipEvent_t e_fg[kFgSlots] = {};
@@ -202,6 +211,14 @@ struct ClipEncoder::Impl {
     n_spec += yes;
     return yes;
   }
+  // Would a step enqueued now read the BGR clip once?  (no counters touched: Step()'s chunk plan asks before the micro-steps decide)
+  bool WouldReadOnce() {
+    if (one_bgr_pass) return true;
+    if (!spec_quant || c.two_bgr_passes) return false;
+    if (c.always_speculate) return true;
+    PollForeground();
+    return fg_share >= 0.0 && fg_share <= kSpecMaxShare;
+  }
   void ResetPolicy() {  // what the policy knew is void (the caller has Sync()ed: every measurement has landed)
     fg_share = -1.0;
     n_fg = 0;
@@ -236,8 +253,11 @@ struct ClipEncoder::Impl {
   }
 
   // Runs fn with HIP events around it on `stream` when timing is on.
+  uint64_t timed_pairs[kStages] = {};  // frame pairs the timed launches of a stage covered (a step's launches are its chunks)
+  uint64_t cur_pairs = 0;              // pairs of the micro-step whose stages are being enqueued
   template <typename F> void Run(Stage st, hipStream_t stream, bool timing, F&& fn) {
     if (!timing) { fn(); return; }
+    timed_pairs[(uint32_t)st] += cur_pairs;
     hipEvent_t a = TimingEvent(), b = TimingEvent();
     Hip(hipEventRecord(a, stream), "hipEventRecord");
     fn();
@@ -260,9 +280,10 @@ struct ClipEncoder::Impl {
     if (decided && !GrowCoeffSets()) decided = false;
   }
   void Luma(uint64_t m, hipStream_t st, bool timing) {
+    cur_pairs = Pn(m);
     const int b = Par(m);
     const uint32_t p0 = P0(m), pn = Pn(m), skip = Skip();
-    const bool first_chunk = m % nch == 0;
+    const bool first_chunk = At(m).first;
     if (spec_quant) SpecStep(m) = pn ? decided : false;  // decided at the top of the iteration (Iterate / SerialStep)
     if (pn && (one_bgr_pass || (spec_quant && SpecStep(m)))) {
       const uint8_t* enc = bgr.p + (uint64_t)(skip + p0) * frame_bytes;
@@ -294,6 +315,7 @@ struct ClipEncoder::Impl {
 
   // my last pyramid -> rank + 1's slot 0; slot 0 <- rank - 1's last pyramid  (world > 1: one chunk per step)
   void Halo(uint64_t m, bool timing) {
+    cur_pairs = 0;
     const int b = Par(m);
     Hip(hipEventRecord(e_pyr[b], sM), "hipEventRecord");
     Hip(hipStreamWaitEvent(sC, e_pyr[b], 0), "hipStreamWaitEvent");
@@ -308,6 +330,7 @@ struct ClipEncoder::Impl {
   }
 
   void Hbma(uint64_t m, hipStream_t st, bool timing) {
+    cur_pairs = Pn(m);
     const uint32_t p0 = P0(m), pn = Pn(m);
     if (!pn) return;
     const int b = Par(m), q = Set(m), k = Slot(m);
@@ -325,6 +348,7 @@ struct ClipEncoder::Impl {
 
   // RANSAC + region ids: one workgroup per frame, latency-bound
   void Lat(uint64_t m, hipStream_t st, bool timing) {
+    cur_pairs = Pn(m);
     const uint32_t p0 = P0(m), pn = Pn(m);
     if (!pn) return;
     const int b = Set(m), k = Slot(m);
@@ -374,6 +398,7 @@ struct ClipEncoder::Impl {
   // of its foreground MV blocks once more with fg_step (planes).  Latency-bound (a list, a few thousand scattered tiles): in the pipelined
   // schedule it runs on the latency stream right behind the segmentation, beside the main stream's kernels, and the main stream only joins.
   void FinishOnePass(uint64_t m, hipStream_t st, bool timing) {
+    cur_pairs = Pn(m);
     const uint32_t p0 = P0(m), pn = Pn(m);
     if (!pn || !c.dct_block_w) return;
     const int b = Set(m);
@@ -391,6 +416,7 @@ struct ClipEncoder::Impl {
   }
 
   void Transform(uint64_t m, hipStream_t st, bool timing) {
+    cur_pairs = Pn(m);
     const uint32_t p0 = P0(m), pn = Pn(m);
     if (!pn || !c.dct_block_w) return;
     const int b = Set(m);
@@ -454,7 +480,10 @@ struct ClipEncoder::Impl {
   //   hbma(h) writes its chunk of mv[set]: the last reader of that range, lat of the same chunk nsets steps earlier, was joined long before;
   //   up to `depth` lats are in flight on their own streams, each with its own segmentation workspace.
   void Iterate(bool new_step, bool timing) {
-    if (new_step) Decide(n_luma);  // may drain the pipeline (the first speculation allocates the extra coefficient sets)
+    if (new_step) {
+      ring[(int)(n_luma % (uint64_t)kRing)] = next_micro;
+      Decide(n_luma);  // may drain the pipeline (the first speculation allocates the extra coefficient sets)
+    }
     const uint64_t lumas_before = n_luma, hbmas = n_hbma, lats = n_lat;
     const bool do_lat = n_lat < hbmas;
     const uint64_t l = n_lat, d = n_dct;
@@ -486,6 +515,7 @@ struct ClipEncoder::Impl {
 
   void SerialStep(bool timing) {
     const uint64_t s = n_luma;
+    ring[(int)(s % (uint64_t)kRing)] = Micro{n_steps++, 0u, sh.pairs, true};
     Decide(s);
     const int b = Par(s);
     if (c.world > 1 && halo_recorded[b]) Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
@@ -631,7 +661,7 @@ uint32_t ClipEncoder::padded_width() const { return p_->pw; }
 uint32_t ClipEncoder::padded_height() const { return p_->ph; }
 uint32_t ClipEncoder::blocks() const { return p_->blocks; }
 uint64_t ClipEncoder::pyramid_stride() const { return p_->pyr_stride; }
-uint32_t ClipEncoder::steps_submitted() const { return (uint32_t)(p_->n_luma / p_->nch); }
+uint32_t ClipEncoder::steps_submitted() const { return p_->n_steps; }
 uint32_t ClipEncoder::chunks_per_step() const { return p_->nch; }
 uint32_t ClipEncoder::output_sets() const { return (uint32_t)(p_->one_bgr_pass ? p_->rec_sets : p_->coeff_sets); }
 
@@ -667,10 +697,26 @@ void ClipEncoder::SetComm(void* nccl_comm) { p_->comm = nccl_comm; }
 void ClipEncoder::SetHaloTransport(HaloFn fn) { p_->halo = std::move(fn); }
 
 void ClipEncoder::Step(bool timed) {
-  p_->last_timed = timed;
-  if (p_->c.schedule == Schedule::kPipelined)
-    for (uint32_t k = 0; k < p_->nch; ++k) p_->Iterate(true, timed);
-  else p_->SerialStep(timed);
+  Impl& m = *p_;
+  m.last_timed = timed;
+  if (m.c.schedule != Schedule::kPipelined) { m.SerialStep(timed); return; }
+  // The step's chunk plan.  Configured: chunk_pairs (default: one chunk).  The idle-pipeline rule (round 6): a step that finds the pipeline
+  // EMPTY -- the first one after LoadFrames / Sync: a clip encoded once is exactly that -- has no earlier step's kernels to overlap its
+  // RANSAC + segmentation with, so on a big shard in the two-pass order it is cut in two and overlaps them with its own second half
+  // (profiles/r06_ab_chunks.txt: C3 2.56-2.70 -> 2.49-2.58 ms); back-to-back steps keep whole-shard launches (the steady state loses 0-4 %
+  // to chunks).  Not in the one-pass orders: there the transform runs at the front and the step's tail cannot be hidden either way.
+  const uint32_t P = m.sh.pairs;
+  uint32_t n = m.nch, cp = m.cp;
+  if (!m.c.chunk_pairs && m.c.world == 1 && !m.c.whole_shard_steps && m.n_dct == m.n_luma && P >= 2 &&
+      (uint64_t)P * m.pw * m.ph >= Impl::kIdleRuleMinPixels && !m.WouldReadOnce()) {
+    n = 2; cp = (P + 1) / 2;
+  }
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t p0 = std::min(P, k * cp);
+    m.next_micro = Impl::Micro{m.n_steps, p0, std::min(cp, P - p0), k == 0};
+    m.Iterate(true, timed);
+  }
+  ++m.n_steps;
 }
 
 void ClipEncoder::Flush() {
@@ -682,6 +728,11 @@ void ClipEncoder::Sync() {
   Flush();
   for (hipStream_t s : {p_->sC, p_->sL[0], p_->sL[1], p_->sL[2], p_->sM})
     if (s) Hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+
+uint64_t ClipEncoder::StagePairs(Stage s) {
+  Sync();
+  return p_->timed_pairs[(uint32_t)s];
 }
 
 void ClipEncoder::StageTime(Stage s, double* total_ms, uint32_t* launches) {
@@ -702,6 +753,7 @@ void ClipEncoder::ResetTimers() {
     for (auto& pr : v) { p_->event_pool.push_back(pr.first); p_->event_pool.push_back(pr.second); }
     v.clear();
   }
+  for (uint64_t& n : p_->timed_pairs) n = 0;
 }
 
 void* ClipEncoder::Output(Buffer b, uint64_t* bytes) {
@@ -778,7 +830,8 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
                                std::to_string(sizeof(svc_clip_config)) + " bytes (set struct_size = sizeof(svc_clip_config))");
     constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
-                                   SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR;
+                                   SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR |
+                                   SVC_CLIP_TUNE_WHOLE_SHARD_STEPS;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -798,6 +851,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.two_bgr_passes = (k->tuning & SVC_CLIP_TUNE_TWO_BGR_PASSES) != 0;
     c.always_speculate = (k->tuning & SVC_CLIP_TUNE_ALWAYS_SPECULATE) != 0;
     c.keep_foreground_prior = (k->tuning & SVC_CLIP_KEEP_FOREGROUND_PRIOR) != 0;
+    c.whole_shard_steps = (k->tuning & SVC_CLIP_TUNE_WHOLE_SHARD_STEPS) != 0;
     c.chunk_pairs = k->chunk_pairs;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;
@@ -850,6 +904,13 @@ int svc_clip_stage_time(svc_clip* clip, uint32_t stage, double* total_ms, uint32
   return Guard([&] {
     if (stage >= SVC_STAGE_COUNT) throw std::runtime_error("svc_clip_stage_time: unknown stage");
     clip->enc->StageTime((svc::Stage)stage, total_ms, launches);
+  });
+}
+
+int svc_clip_stage_pairs(svc_clip* clip, uint32_t stage, uint64_t* pairs) {
+  return Guard([&] {
+    if (stage >= SVC_STAGE_COUNT || !pairs) throw std::runtime_error("svc_clip_stage_pairs: bad argument");
+    *pairs = clip->enc->StagePairs((svc::Stage)stage);
   });
 }
 

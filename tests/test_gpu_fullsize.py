@@ -105,6 +105,37 @@ def test_bench_driver_at_the_headline_size(native, oracle, encoded):
     drv.close()
 
 
+def test_a_step_into_an_empty_pipeline_runs_in_two_chunks(native, encoded):
+    """The idle-pipeline rule (round 6): a step that finds the pipeline EMPTY -- the first after load_frames / sync: a clip encoded once,
+    libs/encoder.cpp:453-664 -- has no earlier step to overlap its RANSAC + segmentation with, so on a big shard in the two-pass order it
+    runs in two chunks and overlaps them with its own second half; steps that follow each other keep whole-shard launches; the one-pass
+    orders and SVC_CLIP_TUNE_WHOLE_SHARD_STEPS never chunk.  Same bytes either way; the driver's pair counts make per-step times exact."""
+    cfg, ref = encoded
+    dev = torch.device("cuda")
+    frames = torch.stack(ref.frames_bgr).contiguous()
+    for tuning, first, wire in ((0, 2, False), (clipmod.TUNE_WHOLE_SHARD_STEPS, 1, False), (0, 1, True)):
+        drv = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED, tuning=tuning, wire=wire)
+        assert drv.info.chunks_per_step == 1
+        drv.load_frames(frames)
+        drv.step(timed=True)  # into an empty pipeline; nothing is known about the clip: two passes (planes) / one pass (wire)
+        drv.sync()
+        t, sp = drv.stage_times_ms(), drv.stage_pairs()
+        for k in ("luma_pyramid", "hbma", "ransac", "segment", "dct_quant"):
+            assert t[k][1] == first and sp[k] == drv.info.pairs, (tuning, wire, k, t[k], sp[k])
+        drv.step(timed=True)  # again into an empty pipeline (sync above) -- but now the clip's foreground share is known (0.5 %): planes + quant
+        drv.step(timed=True)  # reads the clip once, and the one-pass orders keep whole-shard launches; the third step follows the second anyway
+        drv.sync()
+        t, sp = drv.stage_times_ms(), drv.stage_pairs()
+        assert t["hbma"][1] == first + 2 and sp["hbma"] == 3 * drv.info.pairs
+        if not wire:
+            assert drv.policy_info()["chunks_speculated"] == 2
+        out = drv.outputs(device=dev)
+        assert torch.equal(out["mv"], ref.mv) and torch.equal(out["block_types"], ref.types) and torch.equal(out["inlier_mask"], ref.mask)
+        if not wire:
+            assert torch.equal(drv.read("coeffs", device=dev).view(ref.coeffs.shape), ref.coeffs)
+        drv.close()
+
+
 def test_bench_driver_on_one_shard_of_eight(native, encoded):
     """BASELINE config 4's rank 3 of 8 (38 frames of the 300, pipelined, the halo handed over through the transport hook
     as RCCL would deliver it): its outputs are the unsharded clip's rows, bit for bit."""
