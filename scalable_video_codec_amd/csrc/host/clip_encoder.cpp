@@ -82,12 +82,12 @@ struct ClipEncoder::Impl {
   // stream l % depth), and the small per-step buffers exist in depth + 2 sets (step s uses set s % nsets).
   static constexpr int kMaxDepth = 3, kSets = kMaxDepth + 2;
   int depth = 1, nsets = 1;
-  // Chunks (round 6).  A step's pass over the shard is cut into `nch` consecutive runs of `cp` frame pairs, and what the pipeline moves is a
-  // MICRO-STEP m = (step m / nch, chunk m % nch): every stage launch covers one chunk.  With nch = 1 this is the schedule of rounds 2-5 (a
-  // pipeline over consecutive whole-shard steps).  With nch > 1 the stages of ONE step overlap each other -- RANSAC + segmentation of chunk c
-  // run beside the motion search of chunk c + 1 and the transform of chunk c - 1 -- so a clip that is encoded ONCE (LoadFrames, Step, Sync)
-  // no longer pays the latency-bound stages end to end.  Buffers: chunk c of step s lives at offset p0(c) inside set s % nsets; events and
-  // "pending" flags are per micro-step slot m % nsets (at most depth + 2 micro-steps are in flight).
+  // Chunks (round 6).  A step's pass over the shard may be cut into consecutive runs of frame pairs, and what the pipeline moves is a
+  // MICRO-STEP = (step, chunk): every stage launch covers one chunk.  One chunk per step is the schedule of rounds 2-5 (a pipeline over
+  // consecutive whole-shard steps).  With more, the stages of ONE step overlap each other -- RANSAC + segmentation of chunk c run beside the
+  // motion search of chunk c + 1 and the transform of chunk c - 1 -- so a clip that is encoded ONCE (LoadFrames, Step, Sync) no longer pays
+  // the latency-bound stages end to end.  Buffers: a chunk lives at its offset p0 inside set (step % nsets); events and "pending" flags are
+  // per micro-step slot m % nsets (at most depth + 2 micro-steps are in flight).
   uint32_t nch = 1, cp = 0;  // the configured plan (chunk_pairs); a step may be cut differently (Step(): the idle-pipeline rule), so a
   // micro-step carries its own description from the moment it enters the pipeline until its last stage has been enqueued
   struct Micro { uint32_t step = 0, p0 = 0, pn = 0; bool first = true; };
@@ -703,8 +703,10 @@ void ClipEncoder::Step(bool timed) {
   // The step's chunk plan.  Configured: chunk_pairs (default: one chunk).  The idle-pipeline rule (round 6): a step that finds the pipeline
   // EMPTY -- the first one after LoadFrames / Sync: a clip encoded once is exactly that -- has no earlier step's kernels to overlap its
   // RANSAC + segmentation with, so on a big shard in the two-pass order it is cut in two and overlaps them with its own second half
-  // (profiles/r06_ab_chunks.txt: C3 2.56-2.70 -> 2.49-2.58 ms); back-to-back steps keep whole-shard launches (the steady state loses 0-4 %
-  // to chunks).  Not in the one-pass orders: there the transform runs at the front and the step's tail cannot be hidden either way.
+  // (profiles/r06_ab_idle_rule.txt, same box: C3 2.58-2.63 -> 2.49-2.52 ms, C3b 2.96-3.12 -> 2.89-2.92, C5 2.80-2.85 -> 2.60-2.70); back-to-back
+  // steps keep whole-shard launches (the steady state loses 0-4 % to chunks).  Not in the one-pass orders: there the transform runs at the
+  // front and the step's tail cannot be hidden either way.  ("Empty" = every stage of every earlier step has been enqueued -- after a Flush()
+  // without a Sync() the GPU may still be busy with them; the rule then costs a few launches and hides nothing: harmless.)
   const uint32_t P = m.sh.pairs;
   uint32_t n = m.nch, cp = m.cp;
   if (!m.c.chunk_pairs && m.c.world == 1 && !m.c.whole_shard_steps && m.n_dct == m.n_luma && P >= 2 &&
