@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrDownArgs a) {
 #ifndef SVC_LUMA_HALO_DWORD
 #define SVC_LUMA_HALO_DWORD 0
 #endif
+#ifndef SVC_LUMA_HALO_EDGE
+#define SVC_LUMA_HALO_EDGE 0
+#endif
 #ifndef SVC_LUMA_TW
 #define SVC_LUMA_TW 128
 #endif
@@ -291,9 +294,43 @@ __device__ __forceinline__ void luma_pyr1_tile(const LumaPyr1Args& a, uint32_t t
     }
     *reinterpret_cast<uint4*>(&tile[r * kPitch + kOff + sgm * 16]) = o4;  // 16-byte aligned (Guideline 17)
     if (FROM_BGR && r >= 2 && r < kTH + 2 && y < h) *reinterpret_cast<uint4*>(y_plane + (size_t)y * w + x) = o4;
+#if SVC_LUMA_HALO_EDGE
+    // A/B variant (profiles/r06_ab_luma_halo.txt, NOT shipped): the tile's halo pixels (two columns left, two right) by the lanes that hold the
+    // row's first / last segment -- ONE more 16-byte load each (the 16 bytes in front of / behind the segment hold them), none at the frame's
+    // border (reflect-101: the pixels are the lane's own) -- instead of the second task loop below (4 lanes per row, three byte loads each: a
+    // third of the kernel's lane-loads for 1.6 % of its bytes).  Bit-identical and 3 - 5 % SLOWER (0.571-0.576 against 0.550-0.557 ms at C3):
+    // what bounds the plane pass (load instructions by their active lanes) does not bound this kernel; the divergent loads in its main loop
+    // hold its level-0 stores back
+    if (FROM_BGR && sgm == 0) {
+      uint32_t ya, yb;  // Y of columns x0 - 2, x0 - 1
+      if (x0 > 0) {
+        const uint4 e = *reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3 - 16);
+        ya = luma_of((e.z >> 16) & 0xFFu, e.z >> 24, e.w & 0xFFu);
+        yb = luma_of((e.w >> 8) & 0xFFu, (e.w >> 16) & 0xFFu, e.w >> 24);
+      } else {
+        ya = (o4.x >> 16) & 0xFFu;  // column 2
+        yb = (o4.x >> 8) & 0xFFu;   // column 1
+      }
+      tile[r * kPitch + kOff - 2] = (uint8_t)ya;
+      tile[r * kPitch + kOff - 1] = (uint8_t)yb;
+    }
+    if (FROM_BGR && sgm == segs - 1) {
+      uint32_t ya, yb;  // Y of columns xe, xe + 1
+      if (xe < w) {
+        const uint4 e = *reinterpret_cast<const uint4*>(src + ((size_t)yr * w + x) * 3 + 48);
+        ya = luma_of(e.x & 0xFFu, (e.x >> 8) & 0xFFu, (e.x >> 16) & 0xFFu);
+        yb = luma_of(e.x >> 24, e.y & 0xFFu, (e.y >> 8) & 0xFFu);
+      } else {
+        ya = (o4.w >> 16) & 0xFFu;  // column w - 2
+        yb = (o4.w >> 8) & 0xFFu;   // column w - 3
+      }
+      tile[r * kPitch + kOff + segs * 16] = (uint8_t)ya;
+      tile[r * kPitch + kOff + segs * 16 + 1] = (uint8_t)yb;
+    }
+#endif
   }
   // (b) halo pixels: two columns on each side of the valid part, every row
-  for (int task = (int)tid; task < rows * 4; task += 256) {
+  for (int task = (int)tid; task < ((FROM_BGR && SVC_LUMA_HALO_EDGE) ? 0 : rows * 4); task += 256) {
     const int r = task >> 2, k = task & 3;
     const int yr = reflect101(y0 - 2 + r, h);
     const int x = k < 2 ? x0 - 2 + k : xe + (k - 2);
