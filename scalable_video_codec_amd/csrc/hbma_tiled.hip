@@ -52,6 +52,8 @@ struct TileGeom {
   static __device__ __forceinline__ int origin_x(int ax0) { return (ax0 - (M + RT)) & ~15; }
 };
 
+struct FakeLevel0Geom { static constexpr int W = 1088, ND = 6; };  // SVC_HBMA_L0_CEILING == 3 (timing experiment)
+
 // The tile of one level, global -> LDS, asynchronously.  Chunk i of the tile (row-major) is fetched by lane i % 64 of the
 // wave instruction that covers chunks [i & ~63, +64): LDS-DMA writes a wave's 64 x 16 bytes contiguously from the
 // wave-uniform LDS address in M0.  (row, c) = this lane's chunk of round 0 (constant over tiles); a round advances every
@@ -203,14 +205,31 @@ __global__ __launch_bounds__((TBX * TBY + 63) / 64 * 64) void hbma_tiled16_kerne
   mvx *= 2; mvy *= 2;
   search_level_lds<8, RT, 2, G1>(lds0, x1, y1, a1r, w >> 1, h >> 1, bx, by, mvx, mvy, best);
   mvx *= 2; mvy *= 2;
-#if SVC_HBMA_L0_CEILING
+#if SVC_HBMA_L0_CEILING == 1 || SVC_HBMA_L0_CEILING == 2
   // TIMING EXPERIMENT ONLY (wrong results; tools/ab_hbma_l0_ceiling.sh): what level 0 would cost if the field were coherent -- every lane's
   // window on its block's own rows (1), and at its block's own columns as well (2).  The kernel's ceiling for any scheme that only reorders or
   // stages level 0's reads: profiles/r06_ab_hbma_tiled_level0.txt.
   mvy = 0;
   if (SVC_HBMA_L0_CEILING >= 2) mvx = 0;
 #endif
+#if SVC_HBMA_L0_CEILING == 3
+  // TIMING EXPERIMENT ONLY (wrong results): level 0's tracked rows read from LDS at per-lane addresses with the REAL vectors' alignments and
+  // bank pattern, and nobody putting them there -- a staging scheme whose transfer is free.  What any LDS staging of level 0 can at best
+  // reach with this kernel's occupancy: the consumer side alone (anchor rows still from global memory).
+  {
+    __syncthreads();  // the tiles of levels 2 and 1 are dead: their LDS is read as if it held level 0
+    const int fx0 = (int)(tk * TBX) * 16 - 16, fy0 = (by * 16 + mvy - 1) & ~3;  // every lane's window lands inside 22 rows x 1088 bytes
+    uint32_t a0r[16][4];
+    {
+      const uint8_t* p0 = anc + (uint32_t)(by * 16 * w + bx * 16);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) load_anchor_row<4>(p0 + (uint32_t)(r * w), a0r[r]);
+    }
+    search_level_lds<16, RT, 0, FakeLevel0Geom>(lds0, fx0, fy0, a0r, w, h, bx, by, mvx, mvy, best);
+  }
+#else
   search_level<16, RT, false, 0>(trk, anc, w, h, bx, by, mvx, mvy, best);
+#endif
 
   if (live) {
     const uint32_t item = pair * a.blocks + byu * a.mfw + bxu;
