@@ -105,6 +105,7 @@ struct ClipEncoderConfig {
                                         // step which finds the pipeline empty (a clip encoded once) runs in two chunks on big shards in the
                                         // two-pass order (the idle-pipeline rule, Step())
   bool whole_shard_steps = false;       // never the idle-pipeline rule (A/B)
+  bool search_after_transform = false;  // one rank: the motion search, not a pyramid pass, right behind the transform kernel (A/B)
 };
 
 enum class Stage : uint32_t { kLumaPyramid = 0, kHalo, kHbma, kRansac, kSegment, kTransform, kTypePatch, kCount };

@@ -279,7 +279,7 @@ struct ClipEncoder::Impl {
     decided = spec_quant && Pn(m) && DecideSpeculation();
     if (decided && !GrowCoeffSets()) decided = false;
   }
-  void Luma(uint64_t m, hipStream_t st, bool timing) {
+  template <typename Between> void Luma(uint64_t m, hipStream_t st, bool timing, Between&& between) {
     cur_pairs = Pn(m);
     const int b = Par(m);
     const uint32_t p0 = P0(m), pn = Pn(m), skip = Skip();
@@ -296,6 +296,8 @@ struct ClipEncoder::Impl {
           Abi(svc_hip_dct_records_luma_frames(enc, frame_bytes, pn, pw, ph, c.dct_block_w, ph,
                                               Records(m).p + (uint64_t)p0 * record_bytes, record_bytes, slots, pyr_stride, st), "svc_hip_dct_records_luma_frames");
       });
+      between();  // (search_after_transform: the motion search of the previous micro-step goes here, right behind the transform)
+      cur_pairs = pn;
       Run(Stage::kLumaPyramid, st, timing, [&] {
         if (skip && first_chunk)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
           Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, 1, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
@@ -490,14 +492,30 @@ struct ClipEncoder::Impl {
     // draining (no new step) joins at once; otherwise the transform of micro-step d waits until lat(d) has had its iterations
     const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Slot(d)] >= (uint64_t)depth);
     if (do_lat) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
+    // search_after_transform (one rank; A/B): whatever kernel follows the transform shares the memory system with the write-back of what it
+    // left dirty (0.03 ms at C3, profiles/r06_ab_pyr_strip.txt).  With this switch that kernel is the motion search instead of a pyramid
+    // pass: a one-pass micro-step runs transform(m) | search(m - 1) | pyramid levels(m) (the search one micro-step behind, as on a
+    // multi-rank run), a two-pass one luma(m) | transform(m - 3) | search(m).
+    const bool reorder = c.search_after_transform && c.world == 1;
+    bool hbma_done = false;
+    auto pending_searches = [&](uint64_t upto) {
+      while (n_hbma < upto) { Hbma(n_hbma, sM, timing); ++n_hbma; }
+    };
     if (new_step) {
       const uint64_t m = n_luma;
       const int b = Par(m);
       if (c.world > 1 && halo_recorded[b])  // the send out of pyr[b] two steps ago must have left
         Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
-      Luma(m, sM, timing);
+      Luma(m, sM, timing, [&] { if (reorder) { pending_searches(lumas_before); hbma_done = true; } });
       if (c.world > 1) Halo(m, timing);
       ++n_luma;
+    }
+    if (reorder) {
+      if (do_dct) { JoinLat(d); Transform(d, sM, timing); }
+      if (!hbma_done) pending_searches(n_luma);  // two-pass micro-step (or draining): behind the transform of this iteration
+      n_lat += do_lat; n_dct += do_dct;
+      ++iter;
+      return;
     }
     // one rank: the search of the micro-step whose pyramids were just enqueued; multi-rank: the previous one's, whose halo has had a
     // whole iteration to arrive
@@ -519,7 +537,7 @@ struct ClipEncoder::Impl {
     Decide(s);
     const int b = Par(s);
     if (c.world > 1 && halo_recorded[b]) Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
-    Luma(s, sM, timing);
+    Luma(s, sM, timing, [] {});
     if (c.world > 1) {
       Halo(s, timing);
       Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
@@ -833,7 +851,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
                                    SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR |
-                                   SVC_CLIP_TUNE_WHOLE_SHARD_STEPS;
+                                   SVC_CLIP_TUNE_WHOLE_SHARD_STEPS | SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -854,6 +872,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.always_speculate = (k->tuning & SVC_CLIP_TUNE_ALWAYS_SPECULATE) != 0;
     c.keep_foreground_prior = (k->tuning & SVC_CLIP_KEEP_FOREGROUND_PRIOR) != 0;
     c.whole_shard_steps = (k->tuning & SVC_CLIP_TUNE_WHOLE_SHARD_STEPS) != 0;
+    c.search_after_transform = (k->tuning & SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM) != 0;
     c.chunk_pairs = k->chunk_pairs;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;

@@ -160,7 +160,8 @@ def test_buffer_sets_never_serve_stale_steps(native, lat_depth, steps_after):
     enc.close()
 
 
-@pytest.mark.parametrize("form", ["two_passes", "wire", "speculative"])
+@pytest.mark.parametrize("form", ["two_passes", "wire", "speculative", "two_passes+search_after_transform", "speculative+search_after_transform",
+                                  "wire+search_after_transform"])
 @pytest.mark.parametrize("chunk_pairs", [1, 2, 3, 4, 7])
 def test_chunked_steps_equal_whole_steps(native, form, chunk_pairs):
     """Round 6: a pipelined step at one rank is cut into chunks of frame pairs and the pipeline runs over the CHUNKS (RANSAC + segmentation
@@ -173,9 +174,11 @@ def test_chunked_steps_equal_whole_steps(native, form, chunk_pairs):
     n = 9
     cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
     fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    form, _, order = form.partition("+")  # "+search_after_transform": the A/B order of the main stream's kernels (same bytes)
     wire = form == "wire"
     buf = "records" if wire else "coeffs"
-    tuning = {"two_passes": clipmod.TUNE_TWO_BGR_PASSES, "wire": 0, "speculative": clipmod.TUNE_ALWAYS_SPECULATE}[form]
+    tuning = {"two_passes": clipmod.TUNE_TWO_BGR_PASSES, "wire": 0, "speculative": clipmod.TUNE_ALWAYS_SPECULATE}[form] | \
+        (clipmod.TUNE_SEARCH_AFTER_TRANSFORM if order else 0)
     want = {}
     for name, f in (("a", fa), ("b", fb)):
         s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, wire=wire, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
