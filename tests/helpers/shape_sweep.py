@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--chunks", action="store_true",
                     help="round 6: every configuration with a random number of frame pairs per chunk (1 .. pairs), so that the pipeline runs over "
                          "the chunks of a step (6-frame clips)")
+    ap.add_argument("--search-after-transform", action="store_true",
+                    help="round 6: the main stream with the motion search behind the transform kernel (ClipConfig::search_after_transform)")
     ap.add_argument("--shape", action="append", default=[], help="WxH:levels:mv_block:search_range:dct_block -- run these instead of random ones")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -128,7 +130,9 @@ def main():
             chunk_pairs = int(rng.integers(1, 6))
         t0 = time.perf_counter()
         try:
-            verdict = check(cfg, oracle, dev, clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0, chunk_pairs)
+            tuning = (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0) | (
+                clipmod.TUNE_SEARCH_AFTER_TRANSFORM if args.search_after_transform else 0)
+            verdict = check(cfg, oracle, dev, tuning, chunk_pairs)
         except Exception as e:  # noqa: BLE001
             verdict = f"EXCEPTION {type(e).__name__}: {str(e)[:200]}"
             if os.environ.get("SWEEP_TRACE"):
