@@ -227,6 +227,10 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
             # the encoder's own clocks (svc::EncodeStats): per batch of 16, host phases of the calling thread and HIP-event time per stream --
             # which of H2D / kernels / D2H / staging bounds this box's figure, and how many cores the copy crew had
             out["stream_encoder_phases"] = json.loads(ph[-1][len("phases "):]) if ph else None
+            # round 6: the same frames as ONE stream of the same length (a single Encode call over a cycling source): the pipeline fills and
+            # drains once instead of once per 65-frame clip, so wall per batch -> the D2H time of a batch
+            ls = [ln for ln in r.stdout.splitlines() if ln.startswith("long_stream ")]
+            out["stream_encoder_long_stream"] = json.loads(ls[-1][len("long_stream "):]) if ls else None
             out["stream_encoder_sample"] = (f"{n - 1} encoded frames per pass ({min(len(src), n)} distinct sample frames"
                                             f"{', repeated' if len(src) < n else ''}), batch 16, passes over the clip repeated for >= 1 s after one warm-up pass")
             os.remove(raw)

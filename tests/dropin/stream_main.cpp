@@ -92,6 +92,26 @@ int main(int argc, char** argv) {
                 passes, sum.batches, s, sum.host_cores, sum.copy_threads, sum.staging_ms / sum.batches, sum.slot_wait_ms / sum.batches,
                 sum.deliver_wait_ms / sum.batches, sum.sink_ms / sum.batches, sum.wall_ms / sum.batches, sum.h2d_ms / sum.batches,
                 sum.kernels_ms / sum.batches, sum.d2h_ms / sum.batches, sum.h2d_bytes / (sum.h2d_ms * 1e6), sum.d2h_bytes / (sum.d2h_ms * 1e6));
+    // ... and as ONE stream of the same length (the clip's frames cycled through the Source callback in a single Encode call): the passes
+    // above fill and drain the pipeline once per 65-frame clip, a stream does so once -- what is left per batch is the schedule's steady state
+    {
+      const uint32_t n_long = frames + 1;
+      const size_t frame_bytes = (size_t)w * h * 3;
+      uint32_t i = 0;
+      next = 1; total = 0; held = nullptr;
+      const auto t1 = std::chrono::steady_clock::now();
+      enc.Encode([&]() -> const uint8_t* { return i < n_long ? clip.data() + (size_t)(i++ % n) * frame_bytes : nullptr; }, n_long, sink);
+      const double sl = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+      const svc::EncodeStats& e = enc.last_stats();
+      if (total != n_long - 1) { std::fprintf(stderr, "%u encoded frames, expected %u\n", total, n_long - 1); return 1; }
+      std::printf("long_stream {\"encoded_frames\": %u, \"frames_per_s\": %.0f, \"batches\": %u, \"seconds\": %.4f, "
+                  "\"host_ms_per_batch\": {\"staging\": %.3f, \"slot_wait\": %.3f, \"deliver_wait\": %.3f, \"sink\": %.3f, \"wall\": %.3f}, "
+                  "\"device_ms_per_batch\": {\"h2d\": %.3f, \"kernels\": %.3f, \"d2h\": %.3f}, \"h2d_GBps\": %.2f, \"d2h_GBps\": %.2f}\n",
+                  total, total / sl, e.batches, sl, e.staging_ms / e.batches, e.slot_wait_ms / e.batches, e.deliver_wait_ms / e.batches,
+                  e.sink_ms / e.batches, e.wall_ms / e.batches, e.h2d_ms / e.batches, e.kernels_ms / e.batches, e.d2h_ms / e.batches,
+                  e.h2d_bytes / (e.h2d_ms * 1e6), e.d2h_bytes / (e.d2h_ms * 1e6));
+      total = n - 1;
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "%s\n", e.what());
     return 1;

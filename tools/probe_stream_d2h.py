@@ -50,6 +50,11 @@ def main():
                 fps = float(r.stdout.split("encoded frames,")[1].split("frames/s")[0])
                 ph = [ln for ln in r.stdout.splitlines() if ln.startswith("phases ")]
                 p = json.loads(ph[-1][len("phases "):])
+                ls = [ln for ln in r.stdout.splitlines() if ln.startswith("long_stream ")]
+                if ls:
+                    q = json.loads(ls[-1][len("long_stream "):])
+                    print(f"  stream_main [{env or 'as built'}] as ONE stream: {q['frames_per_s']:.0f} frames/s  wall per batch {q['host_ms_per_batch']['wall']} ms  "
+                          f"d2h {q['device_ms_per_batch']['d2h']} ms = {q['d2h_GBps']} GB/s", flush=True)
                 print(f"  stream_main [{env or 'as built'}]: {fps:.0f} frames/s  d2h {p['d2h_GBps']} GB/s  h2d {p['h2d_GBps']} GB/s  device ms {p['device_ms_per_batch']}  "
                       f"host ms {p['host_ms_per_batch']}", flush=True)
 
