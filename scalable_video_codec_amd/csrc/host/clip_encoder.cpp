@@ -899,6 +899,7 @@ int svc_clip_get_info(svc_clip* clip, svc_clip_info* o) {
     o->needs_halo = s.needs_halo ? 1u : 0u;
     o->chunks_per_step = e.chunks_per_step();
     o->output_sets = e.output_sets();
+    o->reserved = 0;
   });
 }
 
