@@ -210,9 +210,14 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
     tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     with tempfile.TemporaryDirectory(dir=tmp_root) as d:
         src = np.stack([f[:cfg.height, :cfg.width] for f in host])  # the unpadded source frames
-        # (b) the batched C++ driver
+        # (b) the batched C++ driver.  Round 6: THIS process has just used the GPU (the per-call leg above), and for most of a second after
+        # a process's last GPU work its idle copy queues still share the SDMA engines with the child's: the child's D2H then runs at exactly
+        # 29.1 GB/s and jumps to 54.9 in mid-run (`d2h_GBps_by_pass`; profiles/r06_probe_e2e_twice.txt) -- which is what moved round 5's
+        # figure between 1 087 and 1 956 frames/s.  A harness artefact, not the encoder's or the box's: the parent goes quiet first.
         exe = os.path.join(bin_dir, "stream_main")
         try:
+            torch.cuda.synchronize()
+            time.sleep(float(os.environ.get("SVC_BENCH_QUIET_SECONDS", "2.0")))
             raw = os.path.join(d, "clip.raw")
             n = 65  # fixed length whatever the run's --frames (the sample frames, repeated, as for the application rows below)
             with open(raw, "wb") as f:
@@ -229,6 +234,9 @@ def end_to_end_rates(cfg: configs.CodecConfig, frames_padded) -> dict:
             out["stream_encoder_phases"] = json.loads(ph[-1][len("phases "):]) if ph else None
             # round 6: the same frames as ONE stream of the same length (a single Encode call over a cycling source): the pipeline fills and
             # drains once instead of once per 65-frame clip, so wall per batch -> the D2H time of a batch
+            bp = [ln for ln in r.stdout.splitlines() if ln.startswith("d2h_GBps_by_pass ")]
+            if bp and out["stream_encoder_phases"] is not None:
+                out["stream_encoder_phases"]["d2h_GBps_by_pass"] = [float(x) for x in bp[-1].split()[1:]]
             ls = [ln for ln in r.stdout.splitlines() if ln.startswith("long_stream ")]
             out["stream_encoder_long_stream"] = json.loads(ls[-1][len("long_stream "):]) if ls else None
             out["stream_encoder_sample"] = (f"{n - 1} encoded frames per pass ({min(len(src), n)} distinct sample frames"

@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
     dump = false;
     uint32_t passes = 0, frames = 0;
     svc::EncodeStats sum;
+    double d2h_by_pass[64] = {};  // GB/s of each pass's D2H copies: does the link's rate move over the process's first second?
     const auto t0 = std::chrono::steady_clock::now();
     double s = 0;
     do {
@@ -81,10 +82,14 @@ int main(int argc, char** argv) {
       sum.deliver_wait_ms += e.deliver_wait_ms; sum.sink_ms += e.sink_ms; sum.h2d_ms += e.h2d_ms; sum.kernels_ms += e.kernels_ms;
       sum.d2h_ms += e.d2h_ms; sum.h2d_bytes += e.h2d_bytes; sum.d2h_bytes += e.d2h_bytes;
       sum.copy_threads = e.copy_threads; sum.host_cores = e.host_cores;
+      if (passes < 64) d2h_by_pass[passes] = e.d2h_bytes / (e.d2h_ms * 1e6);
       ++passes; frames += total;
       s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } while (s < 1.0 && passes < 64);
     total = n - 1;
+    std::printf("d2h_GBps_by_pass");
+    for (uint32_t q = 0; q < passes; ++q) std::printf(" %.1f", d2h_by_pass[q]);
+    std::printf("\n");
     std::printf("%u encoded frames, %.0f frames/s PCIe-inclusive (second pass)\n", frames, frames / s);
     std::printf("phases {\"passes\": %u, \"batches\": %u, \"seconds\": %.4f, \"host_cores\": %u, \"copy_threads\": %u, "
                 "\"host_ms_per_batch\": {\"staging\": %.3f, \"slot_wait\": %.3f, \"deliver_wait\": %.3f, \"sink\": %.3f, \"wall\": %.3f}, "

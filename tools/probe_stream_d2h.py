@@ -35,7 +35,7 @@ def main():
         for rep in range(args.reps):
             r = subprocess.run([ubench, "400"], capture_output=True, text=True, timeout=120)
             for ln in r.stdout.splitlines():
-                if "hipMemcpyAsync, one call" in ln or "slice per workgroup, 64" in ln or "beside" in ln:
+                if "hipMemcpyAsync, one call" in ln or "idle" in ln or "slice per workgroup, 64" in ln or "beside" in ln:
                     print("  ubench:", " ".join(ln.split()), flush=True)
             for env in [""] + args.env:
                 e = dict(os.environ)
@@ -50,6 +50,9 @@ def main():
                 fps = float(r.stdout.split("encoded frames,")[1].split("frames/s")[0])
                 ph = [ln for ln in r.stdout.splitlines() if ln.startswith("phases ")]
                 p = json.loads(ph[-1][len("phases "):])
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("d2h_GBps_by_pass"):
+                        print("   ", ln, flush=True)
                 ls = [ln for ln in r.stdout.splitlines() if ln.startswith("long_stream ")]
                 if ls:
                     q = json.loads(ls[-1][len("long_stream "):])

@@ -93,6 +93,28 @@ int main(int argc, char** argv) {
     std::snprintf(t, sizeof t, "H2D copy kernel, grid-stride, %d workgroups", g);
     line(t, time_ms(s, reps, [&] { hipLaunchKernelGGL(copy_kernel<false>, dim3(g), dim3(256), 0, s, (u32x4*)dev, (const u32x4*)pin_dev, n); }));
   }
+  // a single D2H copy after the link and the copy engines have been idle for a while (a short clip's batches come in bursts)
+  for (int gap_ms : {0, 1, 5, 20, 100}) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double sum = 0;
+    for (int i = 0; i < 4; ++i) {
+      CK(hipStreamSynchronize(s));
+      const auto t0 = std::chrono::steady_clock::now();
+      while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < gap_ms) {}
+      CK(hipEventRecord(e0, s));
+      CK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      sum += ms;
+    }
+    char t[128];
+    std::snprintf(t, sizeof t, "D2H hipMemcpyAsync, one call, %d ms of idle in front of each", gap_ms);
+    line(t, sum / 4);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  }
   // both directions at once on two streams (what a pipelined encoder does): SDMA both ways, then the kernel for D2H beside an SDMA H2D
   {
     hipStream_t s2;
