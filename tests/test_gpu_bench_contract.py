@@ -57,6 +57,7 @@ def test_bench_line_contract():
         assert ph["seconds"] >= 1.0 or ph["passes"] == 64
         assert set(ph["host_ms_per_batch"]) == {"staging", "slot_wait", "deliver_wait", "sink", "wall"} and set(ph["device_ms_per_batch"]) == {"h2d", "kernels", "d2h"}
         assert ph["host_cores"] >= 1 and ph["copy_threads"] >= 1 and ph["batches"] >= ph["passes"] >= 1 and ph["h2d_GBps"] > 0 and ph["d2h_GBps"] > 0
+        assert len(ph["d2h_GBps_by_pass"]) == ph["passes"] and min(ph["d2h_GBps_by_pass"]) > 0  # (a step in it = another process's idle copy queues)
         # ... and the same frames as ONE stream (a single Encode call): as many encoded frames as the passes had, the same phase keys
         ls = e["stream_encoder_long_stream"]
         assert ls["encoded_frames"] >= 64 * ph["passes"] and ls["frames_per_s"] > 0 and ls["batches"] >= ph["passes"]
