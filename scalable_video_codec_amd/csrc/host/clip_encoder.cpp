@@ -90,7 +90,9 @@ struct ClipEncoder::Impl {
   // per micro-step slot m % nsets (at most depth + 2 micro-steps are in flight).
   uint32_t nch = 1, cp = 0;  // the configured plan (chunk_pairs); a step may be cut differently (Step(): the idle-pipeline rule), so a
   // micro-step carries its own description from the moment it enters the pipeline until its last stage has been enqueued
-  struct Micro { uint32_t step = 0, p0 = 0, pn = 0; bool first = true; };
+  // order: who decides whether the micro-step reads its frames once -- 0 the policy, 1 two passes, 2 once (speculating BLIND: Step()'s
+  // mixed form of a step into an empty pipeline)
+  struct Micro { uint32_t step = 0, p0 = 0, pn = 0; bool first = true; uint8_t order = 0; };
   static constexpr int kRing = 8;  // > depth + 2 micro-steps in flight
   Micro ring[kRing], next_micro;
   uint32_t n_steps = 0;
@@ -276,6 +278,15 @@ struct ClipEncoder::Impl {
   uint32_t Skip() const { return sh.needs_halo ? 0u : 1u; }
   bool decided = false;  // this micro-step speculates
   void Decide(uint64_t m) {
+    if (At(m).order && spec_quant && Pn(m)) {
+      // Step() chose (the mixed form of a step into an empty pipeline).  No extra coefficient sets are needed for it: both chunks belong to
+      // ONE step, so they write different ranges of the same set, every earlier step's launches are already in the streams in front of
+      // them, and a later step that speculates by the policy grows the sets behind a drained pipeline (GrowCoeffSets) as ever.
+      decided = At(m).order == 2;
+      ++n_decided;
+      n_spec += decided;
+      return;
+    }
     decided = spec_quant && Pn(m) && DecideSpeculation();
     if (decided && !GrowCoeffSets()) decided = false;
   }
@@ -637,7 +648,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   // one set of coefficients and measures nothing)
   m.spec_quant = !c.wire && !c.two_bgr_passes && transform && c.dct_block_w == c.dct_block_h && (c.dct_block_w == 8 || c.dct_block_w == 16) &&
                  m.pw % 16 == 0 && c.mv_block % 16 == 0 && c.mv_block % c.dct_block_w == 0 && c.fg_step > 0 && c.bg_step > 0 && P > 0 &&
-                 (c.always_speculate || (uint64_t)P * m.pw * m.ph >= Impl::kSpecMinPixels);
+                 (c.always_speculate || c.idle_rule_any_size || (uint64_t)P * m.pw * m.ph >= Impl::kSpecMinPixels);
   // a micro-step's output is written at its front and completed up to depth + 2 iterations later; the same chunk of the NEXT step that uses
   // the set comes nch iterations later per set: ceil((depth + 3) / nch) sets keep them apart (5 with whole-shard steps, 2 with three chunks)
   m.rec_sets = (m.one_bgr_pass || m.spec_quant) && pipelined ? (m.nsets + 1 + (int)m.nch - 1) / (int)m.nch : 1;
@@ -725,15 +736,25 @@ void ClipEncoder::Step(bool timed) {
   // steps keep whole-shard launches (the steady state loses 0-4 % to chunks).  Not in the one-pass orders: there the transform runs at the
   // front and the step's tail cannot be hidden either way.  ("Empty" = every stage of every earlier step has been enqueued -- after a Flush()
   // without a Sync() the GPU may still be busy with them; the rule then costs a few launches and hides nothing: harmless.)
+  //
+  // The MIXED form (round 6; SVC_CLIP_TUNE_MIXED_STEPS, off by default): such a step that knows NOTHING about the clip runs its first half in
+  // the two-pass order and its second half reading its frames ONCE, blind -- luma(c0) | search(c0) | transform+luma(c1) | pyramid(c1) |
+  // search(c1) | transform(c0), the redo c1 owes beside the transform of c0.  Measured (profiles/r06_ab_mixed_step.txt, one box, three
+  // repetitions): at C3's 0.5 % foreground the clip encoded once gains 1.2-2.2 % (2.53 -> 2.47-2.50 ms); at 13 % (C3b, C5) the redo does NOT
+  // hide behind the first half's transform and the step loses 5-8 % (C3b 2.87 -> 3.03, C5 2.63 -> 2.84).  Deciding blind is a bet, not a
+  // free lunch: the default stays two passes for a clip nothing is known about.
   const uint32_t P = m.sh.pairs;
   uint32_t n = m.nch, cp = m.cp;
-  if (!m.c.chunk_pairs && m.c.world == 1 && !m.c.whole_shard_steps && m.n_dct == m.n_luma && P >= 2 &&
-      (uint64_t)P * m.pw * m.ph >= Impl::kIdleRuleMinPixels && !m.WouldReadOnce()) {
+  uint8_t order[2] = {0, 0};
+  const bool idle = !m.c.chunk_pairs && m.c.world == 1 && !m.c.whole_shard_steps && m.n_dct == m.n_luma && P >= 2 &&
+                    (m.c.idle_rule_any_size || (uint64_t)P * m.pw * m.ph >= Impl::kIdleRuleMinPixels);
+  if (idle && !m.WouldReadOnce()) {  // (polls the newest foreground measurement)
     n = 2; cp = (P + 1) / 2;
+    if (m.spec_quant && !m.c.two_bgr_passes && m.c.mixed_steps && m.fg_share < 0.0) { order[0] = 1; order[1] = 2; }  // nothing known: mixed
   }
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t p0 = std::min(P, k * cp);
-    m.next_micro = Impl::Micro{m.n_steps, p0, std::min(cp, P - p0), k == 0};
+    m.next_micro = Impl::Micro{m.n_steps, p0, std::min(cp, P - p0), k == 0, n == 2 ? order[k] : (uint8_t)0};
     m.Iterate(true, timed);
   }
   ++m.n_steps;
@@ -851,7 +872,8 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     constexpr uint32_t kHbmaBits = SVC_HBMA_FORCE_WAVE_PER_BLOCK | SVC_HBMA_FORCE_FUSED | SVC_HBMA_FORCE_TILED | SVC_HBMA_FORCE_LANE;
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
                                    SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR |
-                                   SVC_CLIP_TUNE_WHOLE_SHARD_STEPS | SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM;
+                                   SVC_CLIP_TUNE_WHOLE_SHARD_STEPS | SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM | SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE |
+                                   SVC_CLIP_TUNE_MIXED_STEPS;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -873,6 +895,8 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.keep_foreground_prior = (k->tuning & SVC_CLIP_KEEP_FOREGROUND_PRIOR) != 0;
     c.whole_shard_steps = (k->tuning & SVC_CLIP_TUNE_WHOLE_SHARD_STEPS) != 0;
     c.search_after_transform = (k->tuning & SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM) != 0;
+    c.idle_rule_any_size = (k->tuning & SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE) != 0;
+    c.mixed_steps = (k->tuning & SVC_CLIP_TUNE_MIXED_STEPS) != 0;
     c.chunk_pairs = k->chunk_pairs;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;

@@ -41,14 +41,14 @@ def random_config(rng, i, max_side):
                                mv_block=mv_block, search_range=search, dct_block=dct_block)
 
 
-def check(cfg, oracle, dev, tuning=0, chunk_pairs=0):
+def check(cfg, oracle, dev, tuning=0, chunk_pairs=0, steps=0):
     pw, ph = cfg.padded
     src = synth.SynthClip(cfg.width, cfg.height, cfg.frames, cfg.seed, device=dev)
     frames = torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(cfg.frames)]).contiguous()
     enc = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED, tuning=tuning, chunk_pairs=chunk_pairs)
     try:
         enc.load_frames(frames)
-        for _ in range(3 if not tuning else 6):  # speculating: long enough for every coefficient set to have been a front AND a finish
+        for _ in range(steps or (3 if not tuning else 6)):  # speculating: long enough for every coefficient set to have been a front AND a finish
             enc.step()
         enc.sync()
         out = enc.outputs()
@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--chunks", action="store_true",
                     help="round 6: every configuration with a random number of frame pairs per chunk (1 .. pairs), so that the pipeline runs over "
                          "the chunks of a step (6-frame clips)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="round 6: ONE step into an empty pipeline with nothing known about the clip, the idle-pipeline rule at any size and "
+                         "SVC_CLIP_TUNE_MIXED_STEPS: the mixed form (first half two passes, second half reading its frames once, blind) where the "
+                         "configuration can speculate, two-pass halves elsewhere (6-frame clips)")
     ap.add_argument("--search-after-transform", action="store_true",
                     help="round 6: the main stream with the motion search behind the transform kernel (ClipConfig::search_after_transform)")
     ap.add_argument("--shape", action="append", default=[], help="WxH:levels:mv_block:search_range:dct_block -- run these instead of random ones")
@@ -124,15 +128,15 @@ def main():
     for i in range(args.count):
         cfg = fixed[i] if fixed else random_config(rng, i, args.max_side)
         chunk_pairs = 0
-        if args.chunks:
+        if args.chunks or args.mixed:
             cfg = configs.CodecConfig(cfg.name, cfg.cfg_id, cfg.width, cfg.height, 6, levels=cfg.levels, mv_block=cfg.mv_block, search_range=cfg.search_range,
                                       dct_block=cfg.dct_block)
-            chunk_pairs = int(rng.integers(1, 6))
+            chunk_pairs = 0 if args.mixed else int(rng.integers(1, 6))
         t0 = time.perf_counter()
         try:
             tuning = (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0) | (
-                clipmod.TUNE_SEARCH_AFTER_TRANSFORM if args.search_after_transform else 0)
-            verdict = check(cfg, oracle, dev, tuning, chunk_pairs)
+                clipmod.TUNE_SEARCH_AFTER_TRANSFORM if args.search_after_transform else 0) | ((clipmod.TUNE_IDLE_RULE_ANY_SIZE | clipmod.TUNE_MIXED_STEPS) if args.mixed else 0)
+            verdict = check(cfg, oracle, dev, tuning, chunk_pairs, steps=1 if args.mixed else 0)
         except Exception as e:  # noqa: BLE001
             verdict = f"EXCEPTION {type(e).__name__}: {str(e)[:200]}"
             if os.environ.get("SWEEP_TRACE"):

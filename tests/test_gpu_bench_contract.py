@@ -71,8 +71,11 @@ def test_bench_line_contract():
     for key in ("once_through", "with_prior"):
         row = fe[key]
         assert row["ms_min"] <= row["ms_median"] <= row["ms_max"] and abs(row["value"] - fe["encoded_frames"] / (row["ms_median"] * 1e-3)) <= 1e-6 * row["value"]
-        assert 0 <= row["chunk_launches_speculated"] <= row["chunk_launches"] == fe["reps"] * fe["chunks_per_step"]
-    assert fe["once_through"]["chunk_launches_speculated"] == 0 or d["config"]["chunks_per_step"] > 1  # a load voids the policy
+        # (a step into an empty pipeline may run in two chunks whatever chunks_per_step says: the idle-pipeline rule on big shards)
+        assert 0 <= row["chunk_launches_speculated"] <= row["chunk_launches"] and row["chunk_launches"] in (fe["reps"] * fe["chunks_per_step"], 2 * fe["reps"])
+    # a load voids the policy: a once-through step speculates only blind, on the second half of the mixed form (big shards)
+    ot = fe["once_through"]
+    assert ot["chunk_launches_speculated"] == 0 or d["config"]["chunks_per_step"] > 1 or (ot["chunk_launches"] == 2 * fe["reps"] and ot["chunk_launches_speculated"] == fe["reps"])
     assert fe["policy_voided_steps"]["steps"] == d["steps"] and fe["policy_voided_steps"]["value"] > 0
     assert set(d["hbm_streaming_measured"]) >= {"read_only", "write_only", "copy_1_read_1_write", "3_read_1_write", "unit"}
     assert not any(k.startswith("frac_of_streaming") for k in r)

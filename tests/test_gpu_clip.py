@@ -212,6 +212,61 @@ def test_chunked_steps_equal_whole_steps(native, form, chunk_pairs):
         enc.close()
 
 
+@pytest.mark.parametrize("n", [3, 6, 9])
+def test_a_step_that_knows_nothing_takes_the_mixed_form(native, n):
+    """Round 6, SVC_CLIP_TUNE_MIXED_STEPS (an A/B switch, off by default: it loses where the foreground share is high): a step into an EMPTY
+    pipeline with nothing known about the clip's foreground share (a clip encoded once) runs its first half in the two-pass order and its
+    second half reading its frames once, blind (ClipEncoder::Step; from 400 M pixels x frames, here forced by SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE).  Same bytes as the serial two-pass
+    step, for odd and even pair counts, clips that change between steps, every pipeline depth; the next step (share known by then: the
+    synthetic clip's is far above 2 %) is two passes again, in two halves when it finds the pipeline empty."""
+    dev = torch.device("cuda")
+    cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
+    fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    want = {}
+    for name, f in (("a", fa), ("b", fb)):
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
+        s.load_frames(f)
+        s.step()
+        s.sync()
+        want[name] = (s.outputs(), s.read("coeffs"), s.read("pyramids"))
+        s.close()
+    assert want["a"][0]["block_types"].count_nonzero() > 0
+    for lat_depth in (0, 1, 3):
+        for extra in (clipmod.TUNE_MIXED_STEPS, clipmod.TUNE_MIXED_STEPS | clipmod.TUNE_SEARCH_AFTER_TRANSFORM, 0):
+            enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, lat_depth=lat_depth, tuning=clipmod.TUNE_IDLE_RULE_ANY_SIZE | extra,
+                               ransac=dict(inlier_thresh=1.5))
+            assert enc.info.chunks_per_step == 1
+            mixed = bool(extra & clipmod.TUNE_MIXED_STEPS)
+            for burst, (name, f) in enumerate((("a", fa), ("b", fb), ("a", fa))):
+                enc.load_frames(f)  # voids the policy: the step knows nothing
+                p0 = enc.policy_info()
+                enc.step(timed=True)
+                out = enc.outputs()  # syncs
+                p1 = enc.policy_info()
+                assert p1["chunks_decided"] - p0["chunks_decided"] == 2 and p1["chunks_speculated"] - p0["chunks_speculated"] == (1 if mixed else 0)
+                for key in want[name][0]:
+                    assert torch.equal(out[key], want[name][0][key]), (lat_depth, extra, burst, key)
+                assert torch.equal(enc.read("coeffs"), want[name][1]), (lat_depth, extra, burst)
+                assert torch.equal(enc.read("pyramids")[enc.info.pyramid_stride:], want[name][2][enc.info.pyramid_stride:]), (lat_depth, extra, burst)
+            t = enc.stage_times_ms()
+            assert t["hbma"][1] == 6 and t["dct_quant"][1] == 6 and (("type_patch" in t) == mixed), t
+            assert enc.output_sets() == 1  # the mixed form needs no extra coefficient sets
+            # the share is known now: a further step into the empty pipeline follows the policy (high share: two passes in two halves, then
+            # whole-shard steps behind it; low: whole-shard one-pass steps)
+            p0 = enc.policy_info()
+            assert p0["foreground_share"] >= 0
+            for _ in range(3):
+                enc.step()
+            enc.sync()
+            p1 = enc.policy_info()
+            if p0["foreground_share"] > 0.02:
+                assert p1["chunks_speculated"] == p0["chunks_speculated"] and p1["chunks_decided"] - p0["chunks_decided"] == 4
+            else:
+                assert p1["chunks_speculated"] - p0["chunks_speculated"] == p1["chunks_decided"] - p0["chunks_decided"] == 3
+            assert torch.equal(enc.read("coeffs"), want["a"][1])
+            enc.close()
+
+
 def test_the_foreground_prior_survives_a_load_only_on_request(native):
     """LoadFrames voids what the speculation policy knew (other frames: the first step over them is two passes) unless the caller states
     that the clips are consecutive pieces of one stream (SVC_CLIP_KEEP_FOREGROUND_PRIOR): then the step right after a load speculates

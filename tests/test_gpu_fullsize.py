@@ -113,22 +113,28 @@ def test_a_step_into_an_empty_pipeline_runs_in_two_chunks(native, encoded):
     cfg, ref = encoded
     dev = torch.device("cuda")
     frames = torch.stack(ref.frames_bgr).contiguous()
-    for tuning, first, wire in ((0, 2, False), (clipmod.TUNE_WHOLE_SHARD_STEPS, 1, False), (0, 1, True)):
+    for tuning, first, wire in ((0, 2, False), (clipmod.TUNE_MIXED_STEPS, 2, False), (clipmod.TUNE_WHOLE_SHARD_STEPS, 1, False), (0, 1, True)):
         drv = clipmod.Clip(cfg, cfg.frames, schedule=clipmod.PIPELINED, tuning=tuning, wire=wire)
         assert drv.info.chunks_per_step == 1
         drv.load_frames(frames)
-        drv.step(timed=True)  # into an empty pipeline; nothing is known about the clip: two passes (planes) / one pass (wire)
+        # into an empty pipeline; nothing is known about the clip: planes + quant runs two-pass halves (with SVC_CLIP_TUNE_MIXED_STEPS the second
+        # half reads its frames once, blind), wire is one pass anyway
+        drv.step(timed=True)
         drv.sync()
         t, sp = drv.stage_times_ms(), drv.stage_pairs()
         for k in ("luma_pyramid", "hbma", "ransac", "segment", "dct_quant"):
             assert t[k][1] == first and sp[k] == drv.info.pairs, (tuning, wire, k, t[k], sp[k])
+        blind = 1 if tuning == clipmod.TUNE_MIXED_STEPS and not wire else 0
+        if not wire:
+            assert drv.policy_info()["chunks_speculated"] == blind and ("type_patch" in t) == bool(blind)
+            assert torch.equal(drv.read("coeffs", device=dev).view(ref.coeffs.shape), ref.coeffs)  # the mixed step's planes are the reference's
         drv.step(timed=True)  # again into an empty pipeline (sync above) -- but now the clip's foreground share is known (0.5 %): planes + quant
         drv.step(timed=True)  # reads the clip once, and the one-pass orders keep whole-shard launches; the third step follows the second anyway
         drv.sync()
         t, sp = drv.stage_times_ms(), drv.stage_pairs()
         assert t["hbma"][1] == first + 2 and sp["hbma"] == 3 * drv.info.pairs
         if not wire:
-            assert drv.policy_info()["chunks_speculated"] == 2
+            assert drv.policy_info()["chunks_speculated"] == blind + 2
         out = drv.outputs(device=dev)
         assert torch.equal(out["mv"], ref.mv) and torch.equal(out["block_types"], ref.types) and torch.equal(out["inlier_mask"], ref.mask)
         if not wire:
