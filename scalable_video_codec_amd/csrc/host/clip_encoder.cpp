@@ -202,11 +202,17 @@ struct ClipEncoder::Impl {
       break;
     }
   }
-  bool DecideSpeculation() {
+  bool DecideSpeculation(uint64_t m) {
     if (!spec_quant || c.two_bgr_passes) return false;
     ++n_decided;
     bool yes = c.always_speculate;
-    if (!yes) {
+    if (c.random_policy) {
+      // test switch, whatever was measured: step 0 never, step 1 on every chunk but its first (the first speculation of a shard -- it
+      // allocates the extra coefficient sets and starts their rotation -- then falls INSIDE a step whose set is not set 0), later steps by
+      // a fixed pseudo-random sequence over the chunk launches (a strict alternation would lock onto the number of chunks per step)
+      const uint32_t s = StepOf(m);
+      yes = s == 0 ? false : s == 1 ? !At(m).first : (Hash32(n_decided * 0x9E3779B1ull) & 1u) != 0;
+    } else if (!yes) {
       PollForeground();
       yes = fg_share >= 0.0 && fg_share <= kSpecMaxShare;
     }
@@ -287,8 +293,18 @@ struct ClipEncoder::Impl {
       n_spec += decided;
       return;
     }
-    decided = spec_quant && Pn(m) && DecideSpeculation();
-    if (decided && !GrowCoeffSets()) decided = false;
+    decided = spec_quant && Pn(m) && DecideSpeculation(m);
+    // The rotation over the extra coefficient sets starts with a STEP, never inside one: the chunks of a step that came before this one
+    // have written (or, drained by GrowCoeffSets, will write) set 0, and a step's planes must not end up in two sets.  So the first
+    // speculation of a shard waits for a step's first chunk (found by tests/helpers/driver_fuzz.py: chunked steps, the foreground count of
+    // the previous step landing between the decisions of two chunks of one step).
+#ifndef SVC_CLIP_ALLOW_MIDSTEP_ROTATION  // 1: the behaviour before the fix, to show that test_the_policy_may_flip_at_every_chunk sees it
+#define SVC_CLIP_ALLOW_MIDSTEP_ROTATION 0
+#endif
+    if (decided && coeff_sets != rec_sets && ((!At(m).first && !SVC_CLIP_ALLOW_MIDSTEP_ROTATION) || !GrowCoeffSets())) {
+      decided = false;
+      --n_spec;
+    }
   }
   template <typename Between> void Luma(uint64_t m, hipStream_t st, bool timing, Between&& between) {
     cur_pairs = Pn(m);
@@ -873,7 +889,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
                                    SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR |
                                    SVC_CLIP_TUNE_WHOLE_SHARD_STEPS | SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM | SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE |
-                                   SVC_CLIP_TUNE_MIXED_STEPS;
+                                   SVC_CLIP_TUNE_MIXED_STEPS | SVC_CLIP_TUNE_RANDOM_POLICY;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -897,6 +913,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.search_after_transform = (k->tuning & SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM) != 0;
     c.idle_rule_any_size = (k->tuning & SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE) != 0;
     c.mixed_steps = (k->tuning & SVC_CLIP_TUNE_MIXED_STEPS) != 0;
+    c.random_policy = (k->tuning & SVC_CLIP_TUNE_RANDOM_POLICY) != 0;
     c.chunk_pairs = k->chunk_pairs;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;

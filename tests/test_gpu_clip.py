@@ -620,3 +620,63 @@ def test_speculation_follows_the_foreground_share(native):
         for k in outs[a][0]:
             assert torch.equal(outs[a][0][k], outs[b][0][k]), (a, k)
         assert torch.equal(outs[a][1], outs[b][1]), a
+
+
+@pytest.mark.parametrize("chunk_pairs", [0, 1, 2, 3, 7])
+def test_the_policy_may_flip_at_every_chunk(native, chunk_pairs):
+    """SVC_CLIP_TUNE_RANDOM_POLICY (a test switch): the speculation policy answers yes / no by a fixed pseudo-random sequence over the chunk
+    launches -- flips inside steps, across steps, across loads.  Found by tests/helpers/driver_fuzz.py: with chunked steps the FIRST speculation of a shard
+    (which allocates the extra coefficient sets and starts their rotation) could fall on a later chunk of a step whose first chunk had
+    already written set 0, leaving the step's planes in two sets; the rotation now starts with a step's first chunk.  Bytes of the serial
+    two-pass step in every burst, whatever flipped where; with whole-shard steps the idle-pipeline rule (forced at this size) cuts the
+    steps that find the pipeline empty in two, so flips fall inside those too."""
+    dev = torch.device("cuda")
+    n = 9
+    cfg_b = configs.CodecConfig("t-360p-3L-dct8-b", 77, 640, 360, n, levels=3, dct_block=8)
+    fa, fb = _frames(CFG, n, dev), _frames(cfg_b, n, dev)
+    want = {}
+    for name, f in (("a", fa), ("b", fb)):
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
+        s.load_frames(f)
+        s.step()
+        s.sync()
+        want[name] = (s.outputs(), s.read("coeffs"), s.read("pyramids"))
+        s.close()
+    for lat_depth in (0, 1, 3):
+        for extra in (0, clipmod.TUNE_SEARCH_AFTER_TRANSFORM):
+            enc = clipmod.Clip(CFG, n, schedule=clipmod.PIPELINED, lat_depth=lat_depth, chunk_pairs=chunk_pairs,
+                               tuning=clipmod.TUNE_RANDOM_POLICY | clipmod.TUNE_IDLE_RULE_ANY_SIZE | extra, ransac=dict(inlier_thresh=1.5))
+            # (the switch's sequence: step 0 never, step 1 on every chunk but its first, then pseudo-random -- the second burst is read right
+            # after the step in which the shard speculates for the first time, inside that step where it has more than one chunk)
+            for burst, (name, f, k, flush) in enumerate((("a", fa, 1, False), ("b", fb, 1, False), ("a", fa, 5, False), ("b", fb, 2, True),
+                                                         ("a", fa, 3, True), ("b", fb, 4, False))):
+                enc.load_frames(f)
+                for i in range(k):
+                    enc.step()
+                    if flush and i == 0:
+                        enc.flush()  # every stage enqueued, nothing waited for: the next step finds the pipeline "empty"
+                out = enc.outputs()  # syncs
+                for key in want[name][0]:
+                    assert torch.equal(out[key], want[name][0][key]), (lat_depth, extra, burst, key)
+                assert torch.equal(enc.read("coeffs"), want[name][1]), (lat_depth, extra, burst)
+                assert torch.equal(enc.read("pyramids")[enc.info.pyramid_stride:], want[name][2][enc.info.pyramid_stride:]), (lat_depth, extra, burst)
+            p = enc.policy_info()
+            assert 0 < p["chunks_speculated"] < p["chunks_decided"]
+            enc.close()
+
+
+def test_random_call_sequences_give_the_serial_encoders_bytes(native):
+    """A slice of tests/helpers/driver_fuzz.py: random configurations of the pipelined driver (output form, chunk plan, pipeline depth, the
+    switches of round 6) under random sequences of load / step x k / flush / sync / reset_policy / read over clips whose foreground share
+    makes the policy's answer flip -- after every read the resident clip's outputs are the serial two-pass encoder's, bit for bit."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("driver_fuzz", os.path.join(os.path.dirname(__file__), "helpers", "driver_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    import sys
+    argv, sys.argv = sys.argv, ["driver_fuzz.py", "--encoders", "30", "--ops", "40", "--seed", "3"]
+    try:
+        assert fz.main() == 0
+    finally:
+        sys.argv = argv
