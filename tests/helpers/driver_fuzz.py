@@ -9,6 +9,7 @@ must be the serial two-pass encoder's for the clip that is resident, bit for bit
 early, a coefficient set rewritten before its redo, a policy decision taken on another clip's share would each surface as the wrong clip's
 bytes.  usage: driver_fuzz.py [--encoders N] [--ops M] [--seed S]"""
 import argparse
+import ctypes as C
 import os
 import sys
 import time
@@ -30,34 +31,52 @@ def frames_of(cfg, n, dev):
     return torch.stack([synth.pad_frame(src.frame_bgr(t), pw, ph) for t in range(n)]).contiguous()
 
 
-def reference(cfg, n, frames, wire, ransac):
+def reference(cfg, n, frames, wire, ransac, dev):
     s = clipmod.Clip(cfg, n, schedule=clipmod.SERIAL, wire=wire, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=ransac)
     s.load_frames(frames)
     s.step()
     s.sync()
-    out = (s.outputs(), s.read("records" if wire else "coeffs"), s.read("pyramids"))
+    # (the pyramids also on the device: a shard's halo is handed over from there, as RCCL would deliver it)
+    out = (s.outputs(), s.read("records" if wire else "coeffs"), s.read("pyramids"), s.read("pyramids", device=dev))
     s.close()
     return out
 
 
 def same(enc, want, wire):
+    """None, or the name of the first output of the encoder's shard that is not the unsharded serial encoder's rows."""
+    i = enc.info
+    g0, p = i.first_encoded - 1, i.pairs
     out = enc.outputs()  # syncs
     for k in KEYS:
-        a, b = out[k], want[0][k]
+        a, b = out[k], want[0][k][g0:g0 + p]
         if a.dtype.is_floating_point:
             if a.numpy().tobytes() != b.numpy().tobytes():
                 return k
         elif not torch.equal(a, b):
             return k
-    if not torch.equal(enc.read("records" if wire else "coeffs"), want[1]):
+    big = want[1]
+    per = big.numel() // want[0]["mv"].shape[0]  # elements per encoded frame (planes or records)
+    if not torch.equal(enc.read("records" if wire else "coeffs"), big[g0 * per:(g0 + p) * per]):
         return "records" if wire else "coeffs"
-    st = enc.info.pyramid_stride
-    if not torch.equal(enc.read("pyramids")[st:], want[2][st:]):
+    st = i.pyramid_stride
+    lo = 0 if i.needs_halo else 1  # slot 0 is the halo (the previous rank's last frame) where there is one
+    if not torch.equal(enc.read("pyramids")[lo * st:], want[2][(i.first_frame + lo) * st:(i.first_frame + i.frames + 1) * st]):
         return "pyramids"
     return None
 
 
-def one_encoder(rng, dev, shapes, clips, refs, ops, log):
+_hip = None
+
+
+def hip_copy_async(dst, src, nbytes, stream):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so.7")  # the HIP runtime already in the process
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert _hip.hipMemcpyAsync(dst, src, nbytes, 3, stream) == 0
+
+
+def one_encoder(rng, dev, shapes, clips, refs, ops, log, max_world=4):
     si = int(rng.integers(len(shapes)))
     cfg, n = shapes[si]
     wire = bool(rng.integers(3) == 0)
@@ -76,16 +95,34 @@ def one_encoder(rng, dev, shapes, clips, refs, ops, log):
     chunk_pairs = int(rng.integers(1, n)) if rng.random() < 0.4 else 0
     lat_depth = int(rng.integers(0, 4))
     ransac = dict(inlier_thresh=1.5)
-    desc = f"{cfg.name} n={n} {form} tuning={tuning} chunk_pairs={chunk_pairs} lat_depth={lat_depth}"
-    enc = clipmod.Clip(cfg, n, schedule=clipmod.PIPELINED, wire=wire, lat_depth=lat_depth, tuning=tuning, chunk_pairs=chunk_pairs, ransac=ransac)
+    # one rank of a multi-rank run now and then (its own iteration order: the motion search one micro-step behind its pyramids, the halo on
+    # the communication stream); the halo comes from the unsharded reference's pyramids through the transport hook
+    world = int(rng.integers(2, 5)) if rng.random() < (0.0 if max_world < 2 else 0.3) else 1
+    world = min(world, max_world, n)
+    rank = int(rng.integers(world))
+    desc = f"{cfg.name} n={n} rank {rank}/{world} {form} tuning={tuning} chunk_pairs={chunk_pairs} lat_depth={lat_depth}"
+    enc = clipmod.Clip(cfg, n, rank=rank, world=world, schedule=clipmod.PIPELINED, wire=wire, lat_depth=lat_depth, tuning=tuning,
+                       chunk_pairs=chunk_pairs, ransac=ransac)
+    first, cnt = enc.info.first_frame, enc.info.frames
     resident, stepped, trace = None, False, []
     bad = None
+    halo = {"src": 0}
+
+    def ref_of(r):
+        key = (si, r, wire)
+        if key not in refs:
+            refs[key] = reference(cfg, n, clips[si][r], wire, ransac, dev)
+        return refs[key]
+    if world > 1:
+        enc.set_halo_transport(lambda send, recv, nbytes, stream: hip_copy_async(recv, halo["src"], nbytes, stream) if recv else None)
     try:
         for _ in range(ops):
             r = rng.random()
             if resident is None or r < 0.18:
                 resident = int(rng.integers(len(clips[si])))
-                enc.load_frames(clips[si][resident])
+                enc.load_frames(clips[si][resident][first:first + cnt].contiguous())
+                if world > 1:  # the pyramid of clip frame first - 1 (slot = frame + 1) of the clip that is resident now
+                    halo["src"] = ref_of(resident)[3].data_ptr() + first * enc.info.pyramid_stride
                 stepped = False
                 trace.append(f"load{resident}")
             elif r < 0.62:
@@ -107,18 +144,12 @@ def one_encoder(rng, dev, shapes, clips, refs, ops, log):
                 enc.reset_timers()
                 trace.append("timers")
             elif stepped:
-                key = (si, resident, wire)
-                if key not in refs:
-                    refs[key] = reference(cfg, n, clips[si][resident], wire, ransac)
                 trace.append("read")
-                bad = same(enc, refs[key], wire)
+                bad = same(enc, ref_of(resident), wire)
                 if bad:
                     break
         if not bad and stepped:
-            key = (si, resident, wire)
-            if key not in refs:
-                refs[key] = reference(cfg, n, clips[si][resident], wire, ransac)
-            bad = same(enc, refs[key], wire)
+            bad = same(enc, ref_of(resident), wire)
     finally:
         pol = enc.policy_info()
         enc.close()
@@ -131,6 +162,7 @@ def main():
     ap.add_argument("--encoders", type=int, default=40)
     ap.add_argument("--ops", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-world", type=int, default=4, help="largest world size a shard's encoder is drawn from (1: unsharded only)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     dev = torch.device("cuda")
@@ -153,7 +185,7 @@ def main():
     t0 = time.perf_counter()
     good = 0
     for i in range(args.encoders):
-        good += one_encoder(rng, dev, shapes, clips, refs, args.ops, lambda s: print(s, flush=True))
+        good += one_encoder(rng, dev, shapes, clips, refs, args.ops, lambda s: print(s, flush=True), args.max_world)
     print(f"{good} of {args.encoders} random call sequences gave the serial two-pass encoder's bytes ({time.perf_counter() - t0:.0f} s)", flush=True)
     return 0 if good == args.encoders else 1
 
