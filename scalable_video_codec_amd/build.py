@@ -132,6 +132,13 @@ def build_dropin(force: bool = False) -> List[str]:
         _run([cxx, "-std=c++17", "-O2", f"-I{INCLUDE}", "-o", exe, src, f"-L{PKG}", "-lsvc_motion", "-lsvc_hip",
               f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd", "-Wl,--allow-shlib-undefined"])
     out.append(exe)
+    # ... and one that uses it at random against itself (batch sizes, depths, entry points, reuse): tests/test_gpu_stream.py
+    exe = os.path.join(os.path.dirname(DROPIN_SRC), "stream_fuzz")
+    src = os.path.join(os.path.dirname(DROPIN_SRC), "stream_fuzz.cpp")
+    if force or not _newer(exe, [src, LIB_MOTION, os.path.join(INCLUDE, "svc", "stream_encoder.hpp")]):
+        _run([cxx, "-std=c++17", "-O2", f"-I{INCLUDE}", "-o", exe, src, f"-L{PKG}", "-lsvc_motion", "-lsvc_hip",
+              f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../../scalable_video_codec_amd", "-Wl,--allow-shlib-undefined"])
+    out.append(exe)
     return out
 
 

@@ -79,3 +79,19 @@ def test_cpp_stream_encoder_equals_resident(native, tmp_path, batch, wire):
         assert np.fromfile(prefix + ".hdr", np.uint32).tolist() == [n - 1, cfg.width, cfg.height, pw - cfg.width, ph - cfg.height, 8, 8, 3]
     else:
         assert np.array_equal(np.fromfile(prefix + ".big", np.float32).reshape(p, 3, ph, pw), ref.coeffs.cpu().numpy())
+
+
+@pytest.mark.parametrize("shape", ["200 120 3 8", "416 234 2 16"])
+def test_stream_encoder_used_at_random_agrees_with_itself(shape):
+    """tests/dropin/stream_fuzz.cpp: random batch sizes (1-8), batches in flight (3-5), copy threads, pointer / Source entry points, encoders
+    reused over clips of 2 to 17 frames in random order (short last batches, clips that end on a batch boundary), all three output forms --
+    every clip encodes to the bytes of its first encoding (the results are a function of clip and seed alone, stream_encoder.hpp:12-14),
+    and the three forms agree on motion fields and region ids.  The test above ties one such result to the resident path."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "dropin", "stream_fuzz")
+    if not os.path.exists(exe):
+        pytest.fail("tests/dropin/stream_fuzz is not built (python -m scalable_video_codec_amd.build)")
+    r = subprocess.run([exe, *shape.split(), "40", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+    assert "all equal" in r.stdout.splitlines()[-1]
