@@ -73,3 +73,51 @@ def test_dropin_additions(native, oracle, tmp_path):
     assert (np.abs(planes - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))).all()
     q = np.frombuffer(extra, np.float32, 3 * dw * dh, 4 + 4 * 3 * dw * dh).reshape(3, dh, dw)
     assert q.tobytes() == oracle.quant(planes, 640).tobytes()
+
+
+def test_host_entry_points_from_several_threads(native):
+    """include/svc_hip.h:476: the host-pointer entry points (what libsvc_motion.so's reference signatures call) are thread-safe, each calling
+    thread with its own staging buffers and stream.  Six threads, each its own frame pair of its own size, 25 rounds of
+    hbma_host -> ransac_host -> dct_quant_host at once (ctypes drops the GIL inside a call): every result equals the one the same call
+    gave alone; an error text raised on one thread never shows on another."""
+    import threading
+    from scalable_video_codec_amd import configs, synth
+    import torch
+    shapes = [(320, 192, 3), (256, 128, 2), (416, 240, 3), (192, 192, 1), (640, 352, 3), (208, 112, 2)]
+    work = []
+    for i, (w, h, levels) in enumerate(shapes):
+        rng = np.random.default_rng(100 + i)
+        f0 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        f1 = np.roll(f0, (1 + i % 3, 2), (0, 1))
+        pyr = [[p.numpy() for p in synth.build_pyramid(synth.bgr_to_y(torch.from_numpy(f)), levels)] for f in (f0, f1)]
+        blocks = (w // 16) * (h // 16)
+        smp = (np.arange(native.ransac_iter_count(), dtype=np.uint32) * 977) % blocks
+        types = (np.arange(blocks, dtype=np.uint32) % 5 == 0).astype(np.uint32)
+
+        def run(pyr=pyr, f1=f1, smp=smp, types=types):
+            mv, mad = native.hbma_host(pyr[0], pyr[1], 8, 16, 16)
+            gm, rmse, inl = native.ransac_host(mv, smp)
+            co = native.dct_quant_host(f1, 8, types, 16, 1, 640)
+            return mv.tobytes(), mad.tobytes(), gm.tobytes(), np.float32(rmse).tobytes(), inl.tobytes(), co.tobytes()
+        work.append((run, run()))  # the result of the call made alone
+    errors = []
+
+    def worker(k):
+        run, want = work[k]
+        try:
+            for r in range(25):
+                if r % 7 == 3:  # a refused call in between: its message belongs to this thread only
+                    with pytest.raises(native.SvcError):
+                        native.hbma_host([np.zeros((16, 16), np.uint8)], [np.zeros((16, 16), np.uint8)], 8, 0, 16)
+                got = run()
+                if got != want:
+                    errors.append((k, r, [i for i, (a, b) in enumerate(zip(got, want)) if a != b]))
+                    return
+        except Exception as ex:  # noqa: BLE001
+            errors.append((k, "exception", repr(ex)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(work))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
