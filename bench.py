@@ -586,6 +586,51 @@ def first_encode(args, enc, clip_dev, info, chunks: int) -> dict:
     enc.sync()
     out["with_prior"] = timed_once(False)
     out["once_through"] = timed_once(True)
+    # A STREAM of clips, each encoded ONCE: K different clips in device memory (made from the resident one: mirrored, upside down, played
+    # backwards, negated, channels permuted, and combinations -- up to 24 of them, 1.9 GB each at C3; beyond that they rotate), stepped where
+    # they are (svc_clip_step_frames: no copy into the resident buffer and no drain of the pipeline between clips -- load_frames
+    # synchronises, so load / step / load / step is once_through every time), the policy's last measurement carried from clip to clip as in
+    # any stream.  Five further clips, untimed, in front (the policy meets the stream; the coefficient sets exist).  Wall clock, sync at the end.
+    try:
+        import itertools
+        perms = list(itertools.permutations(range(3)))
+
+        def variant(i):
+            v = clip_dev if i % 6 == 0 else clip_dev[..., list(perms[i % 6])]
+            i //= 6
+            for axis in (2, 1, 0):  # mirrored, upside down, backwards
+                if i & 1:
+                    v = v.flip(axis)
+                i >>= 1
+            if i & 1:
+                v = 255 - v
+            return v.contiguous() if v is not clip_dev else clip_dev
+        distinct = min(args.steps, 24)
+        lead = [variant(96 - 1 - k) for k in range(5)]
+        for v in lead:
+            enc.step_frames(v)
+        enc.sync()
+        del lead
+        variants = [variant(k) for k in range(distinct)]
+        p0 = enc.policy_info()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            enc.step_frames(variants[i % distinct])
+        enc.sync()
+        dt = time.perf_counter() - t0
+        p1 = enc.policy_info()
+        out["stream_of_clips"] = {"distinct_clips": distinct, "steps": args.steps, "ms_per_clip": dt / args.steps * 1e3, "value": info.pairs * args.steps / dt,
+                                  "chunk_launches_speculated": p1["chunks_speculated"] - p0["chunks_speculated"],
+                                  "chunk_launches": (p1["chunks_decided"] - p0["chunks_decided"]) or args.steps * chunks,
+                                  "foreground_share_last": p1["foreground_share"],
+                                  "note": "different clips resident in HBM, each encoded ONCE where it is (svc_clip_step_frames; clips rotate only beyond 24 "
+                                          "steps); the speculation policy acts on the previous clips' measurements; five more clips untimed in front"}
+        del variants
+    except Exception as e:  # noqa: BLE001
+        out["stream_of_clips"] = None
+        out["stream_of_clips_note"] = f"not measured: {e}"
+    enc.load_frames(clip_dev)  # (the resident clip again, policy voided, as after once_through)
     enc.reset_policy()
     torch.cuda.synchronize()
     p0 = enc.policy_info()
@@ -791,9 +836,9 @@ def main() -> None:
                 "frames_per_gpu": info.frames if world == 1 else [clipmod.plan_shard(r["clip_frames"], world, q)[1] for q in range(world)],
                 "encoded_frames_per_step": r["encoded_per_step"],
                 "foreground_mv_blocks": r.get("foreground_share"),
-                "value_is": ("steady state: K back-to-back steps over the resident clip, the speculation policy taught by the warm-up steps (the state a "
-                             "stream of such clips reaches; SVC_CLIP_KEEP_FOREGROUND_PRIOR carries it across load_frames).  What a clip encoded ONCE costs "
-                             "is first_encode.once_through"),
+                "value_is": ("steady state: K back-to-back steps over the resident clip, the speculation policy taught by the warm-up steps.  A STREAM of "
+                             "different clips, each encoded once where it is (svc_clip_step_frames), runs at the same rate: first_encode.stream_of_clips; "
+                             "ONE clip encoded alone (load, step, sync: nothing to overlap with, nothing known) costs first_encode.once_through"),
                 "bgr_passes_per_step": ("two (luma + pyramid, later the transform)" if one_pass_frac == 0 else
                                         "one (records + luma plane from one kernel; type words stored after the segmentation)" if args.wire else
                                         "one, speculative (every tile quantised as background + the luma plane at the front of the step; foreground tiles redone "

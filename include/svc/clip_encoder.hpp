@@ -147,6 +147,16 @@ class ClipEncoder {
   // the pipelined schedule those are stages of up to four different steps; Flush() keeps timing
   // what it drains, so K timed steps from an empty pipeline time every stage exactly K times).
   void Step(bool timed = false);
+  // A stream of clips, each encoded ONCE (libs/encoder.cpp:453-664 never looks at a clip twice): the step encodes the shard's frames where
+  // the caller has them in DEVICE memory (the layout LoadFrames fills: frames x padded_h x padded_w x 3, frame 0 of an unsharded clip
+  // tracked only) -- no copy, and above all no drain: LoadFrames synchronises (the resident buffer is being read), so load / step / load /
+  // step runs every step into an empty pipeline, while StepFrames over a rotation of buffers keeps consecutive clips overlapped like
+  // consecutive steps (RANSAC + segmentation of one clip beside the kernels of the next).  The speculation policy carries over from clip to
+  // clip (a stream: what keep_foreground_prior gives the load / step form).  The frames must stay untouched until WaitStep(the returned step)
+  // returns (or Sync()): their last reader is the step's transform, up to depth + 1 steps later.  Results: as after Step() -- Output() gives the
+  // newest finished step's; a step's small outputs live for depth + 2 steps, its planes / records for output_sets() steps.
+  uint32_t StepFrames(const uint8_t* device_frames, bool timed = false);
+  void WaitStep(uint32_t step);  // returns once nothing reads that step's frames any more
   void Flush();  // pipelined schedule: enqueues what is left of the steps in flight
   void Sync();   // Flush() + waits for every stream
 
@@ -169,6 +179,7 @@ class ClipEncoder {
  private:
   struct Impl;
   std::unique_ptr<Impl> p_;
+  void StepOn(const uint8_t* frames, bool timed);
 };
 
 }  // namespace svc

@@ -117,6 +117,11 @@ int svc_clip_set_comm(svc_clip* clip, void* nccl_comm); /* from svc_hip_comm_cre
 int svc_clip_set_halo_callback(svc_clip* clip, svc_clip_halo_fn fn, void* user);
 
 int svc_clip_step(svc_clip* clip, int timed); /* enqueue one pass over the shard */
+/* A stream of clips, each encoded once (svc::ClipEncoder::StepFrames): one pass over the shard's frames where the caller has them in DEVICE
+   memory (frames x padded_h x padded_w x 3, the layout svc_clip_load_frames fills) -- no copy and no drain of the pipeline between clips.
+   *step (optional) receives the step's number; the frames must stay untouched until svc_clip_wait_step(clip, that number) or svc_clip_sync. */
+int svc_clip_step_frames(svc_clip* clip, const uint8_t* device_frames, int timed, uint32_t* step);
+int svc_clip_wait_step(svc_clip* clip, uint32_t step); /* returns once nothing reads that step's frames any more */
 int svc_clip_flush(svc_clip* clip);           /* enqueue what the pipeline still holds */
 int svc_clip_sync(svc_clip* clip);            /* flush + wait for the GPU */
 

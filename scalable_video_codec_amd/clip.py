@@ -61,6 +61,8 @@ SIGNATURES = {
     "svc_clip_set_comm": (C.c_int, [_vp, _vp]),
     "svc_clip_set_halo_callback": (C.c_int, [_vp, HALO_FN, _vp]),
     "svc_clip_step": (C.c_int, [_vp, C.c_int]),
+    "svc_clip_step_frames": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_u32)]),
+    "svc_clip_wait_step": (C.c_int, [_vp, _u32]),
     "svc_clip_flush": (C.c_int, [_vp]),
     "svc_clip_sync": (C.c_int, [_vp]),
     "svc_clip_stage_time": (C.c_int, [_vp, _u32, C.POINTER(C.c_double), C.POINTER(_u32)]),
@@ -218,6 +220,21 @@ class Clip:
     # -- running ----------------------------------------------------------------------------------
     def step(self, timed: bool = False) -> None:
         _check(load().svc_clip_step(self._h, int(timed)))
+
+    def step_frames(self, frames: torch.Tensor, timed: bool = False) -> int:
+        """One pass over the shard's frames where THEY are (a CUDA tensor laid out as load_frames fills the resident buffer): a stream of
+        clips, each encoded once, without a copy and without draining the pipeline.  Returns the step's number; the tensor must stay alive
+        and untouched until wait_step(number) or sync()."""
+        i = self.info
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous()
+        assert tuple(frames.shape) == (i.frames, i.padded_h, i.padded_w, 3), frames.shape
+        torch.cuda.current_stream().synchronize()  # whoever produced the frames has finished (the encoder's streams do not order behind torch's)
+        step = _u32()
+        _check(load().svc_clip_step_frames(self._h, _vp(frames.data_ptr()), int(timed), C.byref(step)))
+        return step.value
+
+    def wait_step(self, step: int) -> None:
+        _check(load().svc_clip_wait_step(self._h, step))
 
     def flush(self) -> None:
         _check(load().svc_clip_flush(self._h))

@@ -92,10 +92,21 @@ struct ClipEncoder::Impl {
   // micro-step carries its own description from the moment it enters the pipeline until its last stage has been enqueued
   // order: who decides whether the micro-step reads its frames once -- 0 the policy, 1 two passes, 2 once (speculating BLIND: Step()'s
   // mixed form of a step into an empty pipeline)
-  struct Micro { uint32_t step = 0, p0 = 0, pn = 0; bool first = true; uint8_t order = 0; };
+  // frames: the shard's B,G,R frames this micro-step's step encodes -- the resident buffer (LoadFrames) or the caller's own device buffer
+  // (StepFrames: a stream of clips, each encoded once, without a copy and without draining the pipeline between them)
+  struct Micro { uint32_t step = 0, p0 = 0, pn = 0; bool first = true; uint8_t order = 0; const uint8_t* frames = nullptr; };
   static constexpr int kRing = 8;  // > depth + 2 micro-steps in flight
   Micro ring[kRing], next_micro;
   uint32_t n_steps = 0;
+  const uint8_t* step_frames = nullptr;   // frames of the step being submitted (Step: the resident buffer; StepFrames: the caller's)
+  // "the frames of step s are no longer read": an event on the main stream behind the step's last transform (which has joined the step's
+  // RANSAC + segmentation + redo by then); kRing of them, by step -- a slot reused by a later step stands for the earlier one too (stream order)
+  hipEvent_t e_step[kRing] = {};
+  uint64_t step_last_micro[kRing] = {};  // the micro-step whose transform is the step's last reader
+  void MarkStepDone(uint64_t d) {        // called where the transform of micro-step d has just been enqueued
+    const uint32_t s = StepOf(d);
+    if (step_last_micro[s % kRing] == d) Hip(hipEventRecord(e_step[s % kRing], sM), "hipEventRecord");
+  }
   const Micro& At(uint64_t m) const { return ring[(int)(m % (uint64_t)kRing)]; }
   uint32_t StepOf(uint64_t m) const { return At(m).step; }
   uint32_t P0(uint64_t m) const { return At(m).p0; }  // first pair of the micro-step's chunk
@@ -248,6 +259,8 @@ struct ClipEncoder::Impl {
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : e_fg)
       if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : e_step)
+      if (e) (void)hipEventDestroy(e);
     if (fg_host) (void)hipHostFree(fg_host);
     for (hipStream_t s : {sM, sL[0], sL[1], sL[2], sC})
       if (s) (void)hipStreamDestroy(s);
@@ -313,7 +326,7 @@ struct ClipEncoder::Impl {
     const bool first_chunk = At(m).first;
     if (spec_quant) SpecStep(m) = pn ? decided : false;  // decided at the top of the iteration (Iterate / SerialStep)
     if (pn && (one_bgr_pass || (spec_quant && SpecStep(m)))) {
-      const uint8_t* enc = bgr.p + (uint64_t)(skip + p0) * frame_bytes;
+      const uint8_t* enc = At(m).frames + (uint64_t)(skip + p0) * frame_bytes;
       uint8_t* slots = pyr[b].p + (uint64_t)(1 + skip + p0) * pyr_stride;
       Run(Stage::kTransform, st, timing, [&] {
         if (!one_bgr_pass)
@@ -327,7 +340,7 @@ struct ClipEncoder::Impl {
       cur_pairs = pn;
       Run(Stage::kLumaPyramid, st, timing, [&] {
         if (skip && first_chunk)  // the tracked-only first frame of the clip has no records: its pyramid the usual way
-          Abi(svc_hip_luma_pyramid_frames(bgr.p, frame_bytes, 1, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
+          Abi(svc_hip_luma_pyramid_frames(At(m).frames, frame_bytes, 1, pw, ph, c.levels, pyr[b].p + pyr_stride, pyr_stride, st),
               "svc_hip_luma_pyramid_frames");
         Abi(svc_hip_pyramid_levels_frames(slots, pyr_stride, pn, pw, ph, c.levels, st), "svc_hip_pyramid_levels_frames");
       });
@@ -337,7 +350,7 @@ struct ClipEncoder::Impl {
     const uint32_t f0 = first_chunk ? 0u : p0 + skip, f1 = p0 + pn + skip;
     if (f1 <= f0) return;
     Run(Stage::kLumaPyramid, st, timing, [&] {
-      Abi(svc_hip_luma_pyramid_frames(bgr.p + (uint64_t)f0 * frame_bytes, frame_bytes, f1 - f0, pw, ph, c.levels,
+      Abi(svc_hip_luma_pyramid_frames(At(m).frames + (uint64_t)f0 * frame_bytes, frame_bytes, f1 - f0, pw, ph, c.levels,
                                       pyr[b].p + (uint64_t)(1 + f0) * pyr_stride, pyr_stride, st), "svc_hip_luma_pyramid_frames");
     });
   }
@@ -431,7 +444,7 @@ struct ClipEncoder::Impl {
     const uint32_t p0 = P0(m), pn = Pn(m);
     if (!pn || !c.dct_block_w) return;
     const int b = Set(m);
-    const uint8_t* enc = bgr.p + (uint64_t)(Skip() + p0) * frame_bytes;  // encoded frame of pair p: own frame p + skip
+    const uint8_t* enc = At(m).frames + (uint64_t)(Skip() + p0) * frame_bytes;  // encoded frame of pair p: own frame p + skip
     const uint32_t* types_c = types[b].p + (uint64_t)p0 * blocks;
     DevBuf<uint8_t>& rws = redo_ws[c.schedule == Schedule::kPipelined ? (int)(m % (uint64_t)depth) : 0];
     Run(Stage::kTypePatch, st, timing, [&] {
@@ -449,7 +462,7 @@ struct ClipEncoder::Impl {
     const uint32_t p0 = P0(m), pn = Pn(m);
     if (!pn || !c.dct_block_w) return;
     const int b = Set(m);
-    const uint8_t* enc = bgr.p + (uint64_t)(Skip() + p0) * frame_bytes;  // encoded frame of pair p: own frame p + skip
+    const uint8_t* enc = At(m).frames + (uint64_t)(Skip() + p0) * frame_bytes;  // encoded frame of pair p: own frame p + skip
     const uint32_t* types_c = types[b].p + (uint64_t)p0 * blocks;
     if (OnePassStep(m)) {  // the transform ran at the front of the step; its finish follows the segmentation (pipelined: on that stream, Lat)
       if (c.schedule != Schedule::kPipelined) FinishOnePass(m, st, timing);
@@ -538,7 +551,7 @@ struct ClipEncoder::Impl {
       ++n_luma;
     }
     if (reorder) {
-      if (do_dct) { JoinLat(d); Transform(d, sM, timing); }
+      if (do_dct) { JoinLat(d); Transform(d, sM, timing); MarkStepDone(d); }
       if (!hbma_done) pending_searches(n_luma);  // two-pass micro-step (or draining): behind the transform of this iteration
       n_lat += do_lat; n_dct += do_dct;
       ++iter;
@@ -553,6 +566,7 @@ struct ClipEncoder::Impl {
     if (do_dct) {
       JoinLat(d);
       Transform(d, sM, timing);
+      MarkStepDone(d);
     }
     n_hbma += do_hbma; n_lat += do_lat; n_dct += do_dct;
     ++iter;
@@ -560,7 +574,8 @@ struct ClipEncoder::Impl {
 
   void SerialStep(bool timing) {
     const uint64_t s = n_luma;
-    ring[(int)(s % (uint64_t)kRing)] = Micro{n_steps++, 0u, sh.pairs, true};
+    ring[(int)(s % (uint64_t)kRing)] = Micro{n_steps++, 0u, sh.pairs, true, 0, step_frames};
+    step_last_micro[(n_steps - 1) % kRing] = s;
     Decide(s);
     const int b = Par(s);
     if (c.world > 1 && halo_recorded[b]) Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
@@ -572,6 +587,7 @@ struct ClipEncoder::Impl {
     Hbma(s, sM, timing);
     Lat(s, sM, timing);
     Transform(s, sM, timing);
+    MarkStepDone(s);
     ++n_luma; ++n_hbma; ++n_lat; ++n_dct;
   }
 };
@@ -644,6 +660,7 @@ ClipEncoder::ClipEncoder(const ClipEncoderConfig& config) : p_(new Impl) {
   for (hipEvent_t* e : {&m.e_pyr[0], &m.e_pyr[1], &m.e_halo[0], &m.e_halo[1], &m.e_fork})
     Hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
   for (int b = 0; b < m.nsets; ++b) Hip(hipEventCreateWithFlags(&m.e_join[b], hipEventDisableTiming), "hipEventCreate");
+  for (hipEvent_t& e : m.e_step) Hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
   m.bgr.Alloc((size_t)N * m.frame_bytes);
   for (int b = 0; b < (pipelined ? 2 : 1); ++b) {
     m.pyr[b].Alloc((size_t)(N + 1) * m.pyr_stride);  // slot 0 = halo, slots 1..N = own frames
@@ -741,9 +758,29 @@ void ClipEncoder::LoadFrames(const uint8_t* src, uint32_t first_local, uint32_t 
 void ClipEncoder::SetComm(void* nccl_comm) { p_->comm = nccl_comm; }
 void ClipEncoder::SetHaloTransport(HaloFn fn) { p_->halo = std::move(fn); }
 
-void ClipEncoder::Step(bool timed) {
+void ClipEncoder::Step(bool timed) { StepOn(p_->bgr.p, timed); }
+
+uint32_t ClipEncoder::StepFrames(const uint8_t* device_frames, bool timed) {
+  if (!device_frames) throw std::runtime_error("svc::ClipEncoder: StepFrames needs the shard's frames in device memory");
+  StepOn(device_frames, timed);
+  return p_->n_steps - 1;
+}
+
+void ClipEncoder::WaitStep(uint32_t step) {
+  Impl& m = *p_;
+  if (step >= m.n_steps) throw std::runtime_error("svc::ClipEncoder: WaitStep of a step that has not been submitted");
+  // older than the events kept: the oldest step still tracked stands for it (stream order; its last transform is long in the stream,
+  // at most depth + 2 steps are in flight)
+  if (m.n_steps - step > (uint32_t)Impl::kRing) step = m.n_steps - (uint32_t)Impl::kRing;
+  // the step's last transform must be in the stream before its event means anything
+  if (m.step_last_micro[step % Impl::kRing] >= m.n_dct) Flush();
+  Hip(hipEventSynchronize(m.e_step[step % Impl::kRing]), "hipEventSynchronize");
+}
+
+void ClipEncoder::StepOn(const uint8_t* frames, bool timed) {
   Impl& m = *p_;
   m.last_timed = timed;
+  m.step_frames = frames;
   if (m.c.schedule != Schedule::kPipelined) { m.SerialStep(timed); return; }
   // The step's chunk plan.  Configured: chunk_pairs (default: one chunk).  The idle-pipeline rule (round 6): a step that finds the pipeline
   // EMPTY -- the first one after LoadFrames / Sync: a clip encoded once is exactly that -- has no earlier step's kernels to overlap its
@@ -770,7 +807,8 @@ void ClipEncoder::Step(bool timed) {
   }
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t p0 = std::min(P, k * cp);
-    m.next_micro = Impl::Micro{m.n_steps, p0, std::min(cp, P - p0), k == 0, n == 2 ? order[k] : (uint8_t)0};
+    m.next_micro = Impl::Micro{m.n_steps, p0, std::min(cp, P - p0), k == 0, n == 2 ? order[k] : (uint8_t)0, frames};
+    if (k + 1 == n) m.step_last_micro[m.n_steps % Impl::kRing] = m.n_luma;  // the micro-step this Iterate enters
     m.Iterate(true, timed);
   }
   ++m.n_steps;
@@ -960,6 +998,13 @@ int svc_clip_set_halo_callback(svc_clip* clip, svc_clip_halo_fn fn, void* user) 
 }
 
 int svc_clip_step(svc_clip* clip, int timed) { return Guard([&] { clip->enc->Step(timed != 0); }); }
+int svc_clip_step_frames(svc_clip* clip, const uint8_t* device_frames, int timed, uint32_t* step) {
+  return Guard([&] {
+    const uint32_t s = clip->enc->StepFrames(device_frames, timed != 0);
+    if (step) *step = s;
+  });
+}
+int svc_clip_wait_step(svc_clip* clip, uint32_t step) { return Guard([&] { clip->enc->WaitStep(step); }); }
 int svc_clip_flush(svc_clip* clip) { return Guard([&] { clip->enc->Flush(); }); }
 int svc_clip_sync(svc_clip* clip) { return Guard([&] { clip->enc->Sync(); }); }
 

@@ -104,9 +104,20 @@ def one_encoder(rng, dev, shapes, clips, refs, ops, log, max_world=4):
     enc = clipmod.Clip(cfg, n, rank=rank, world=world, schedule=clipmod.PIPELINED, wire=wire, lat_depth=lat_depth, tuning=tuning,
                        chunk_pairs=chunk_pairs, ransac=ransac)
     first, cnt = enc.info.first_frame, enc.info.frames
-    resident, stepped, trace = None, False, []
+    resident, stepped, trace = None, False, []  # resident: the clip the LAST step encoded (or the one loaded, before any step)
+    loaded = None                                # the clip in the encoder's own buffer
     bad = None
     halo = {"src": 0}
+    shard = {}  # clip -> its frames of this shard, contiguous on the device (step_frames reads them where they are)
+
+    def frames_of_shard(r):
+        if r not in shard:
+            shard[r] = clips[si][r][first:first + cnt].contiguous()
+        return shard[r]
+
+    def halo_for(r):
+        if world > 1:  # the pyramid of clip frame first - 1 (slot = frame + 1) of the clip about to be stepped
+            halo["src"] = ref_of(r)[3].data_ptr() + first * enc.info.pyramid_stride
 
     def ref_of(r):
         key = (si, r, wire)
@@ -118,19 +129,29 @@ def one_encoder(rng, dev, shapes, clips, refs, ops, log, max_world=4):
     try:
         for _ in range(ops):
             r = rng.random()
-            if resident is None or r < 0.18:
-                resident = int(rng.integers(len(clips[si])))
-                enc.load_frames(clips[si][resident][first:first + cnt].contiguous())
-                if world > 1:  # the pyramid of clip frame first - 1 (slot = frame + 1) of the clip that is resident now
-                    halo["src"] = ref_of(resident)[3].data_ptr() + first * enc.info.pyramid_stride
+            if loaded is None or r < 0.15:
+                loaded = resident = int(rng.integers(len(clips[si])))
+                enc.load_frames(frames_of_shard(loaded))
                 stepped = False
-                trace.append(f"load{resident}")
-            elif r < 0.62:
+                trace.append(f"load{loaded}")
+            elif r < 0.50:
                 k = int(rng.integers(1, 6))
+                halo_for(loaded)
                 for _ in range(k):
                     enc.step(timed=bool(rng.integers(2)))
-                stepped = True
+                resident, stepped = loaded, True
                 trace.append(f"step{k}")
+            elif r < 0.62:  # a stream of clips: steps over frames where they are, no load, no drain
+                k = int(rng.integers(1, 5))
+                for _ in range(k):
+                    resident = int(rng.integers(len(clips[si])))
+                    halo_for(resident)
+                    last_ext = enc.step_frames(frames_of_shard(resident), timed=bool(rng.integers(2)))
+                    trace.append(f"ext{resident}")
+                    if rng.random() < 0.2:
+                        enc.wait_step(int(rng.integers(0, last_ext + 1)))
+                        trace.append("wait")
+                stepped = True
             elif r < 0.70:
                 enc.flush()
                 trace.append("flush")

@@ -77,6 +77,11 @@ def test_bench_line_contract():
     ot = fe["once_through"]
     assert ot["chunk_launches_speculated"] == 0 or d["config"]["chunks_per_step"] > 1 or (ot["chunk_launches"] == 2 * fe["reps"] and ot["chunk_launches_speculated"] == fe["reps"])
     assert fe["policy_voided_steps"]["steps"] == d["steps"] and fe["policy_voided_steps"]["value"] > 0
+    # a stream of DIFFERENT clips, each encoded once per rotation, stepped where they are (svc_clip_step_frames): schema and identities
+    sc = fe["stream_of_clips"]
+    assert sc is not None, fe.get("stream_of_clips_note")
+    assert sc["distinct_clips"] == min(d["steps"], 24) and sc["steps"] == d["steps"] and abs(sc["value"] - fe["encoded_frames"] / (sc["ms_per_clip"] * 1e-3)) <= 1e-6 * sc["value"]
+    assert 0 <= sc["chunk_launches_speculated"] <= sc["chunk_launches"]
     assert set(d["hbm_streaming_measured"]) >= {"read_only", "write_only", "copy_1_read_1_write", "3_read_1_write", "unit"}
     assert not any(k.startswith("frac_of_streaming") for k in r)
     assert "traffic_source" in r and d["config"]["driver"].startswith("svc::ClipEncoder")

@@ -665,6 +665,64 @@ def test_the_policy_may_flip_at_every_chunk(native, chunk_pairs):
             enc.close()
 
 
+@pytest.mark.parametrize("form", ["two_passes", "wire", "speculative", "policy"])
+def test_a_stream_of_clips_encoded_where_they_are(native, form):
+    """svc_clip_step_frames (round 6): a stream of clips, each encoded ONCE (libs/encoder.cpp:453-664 never looks at a clip twice), stepped
+    where the caller has them in device memory -- no copy into the resident buffer and no drain of the pipeline between clips (load_frames
+    synchronises, so load / step / load / step runs every step into an empty pipeline).  Four clips in rotation without a sync in between,
+    mixed with steps over the resident buffer: after any sync the outputs are those of the LAST clip stepped, bit for bit (the serial
+    two-pass encoder's); wait_step(s) returns once step s's frames are free -- they are then overwritten with noise while later steps are
+    still in flight, and nothing changes."""
+    dev = torch.device("cuda")
+    n = 9
+    wire = form == "wire"
+    buf = "records" if wire else "coeffs"
+    tuning = {"two_passes": clipmod.TUNE_TWO_BGR_PASSES, "wire": 0, "speculative": clipmod.TUNE_ALWAYS_SPECULATE,
+              "policy": clipmod.TUNE_IDLE_RULE_ANY_SIZE | clipmod.TUNE_RANDOM_POLICY}[form]
+    cfgs = [CFG] + [configs.CodecConfig(f"t-360p-3L-dct8-{k}", 70 + k, 640, 360, n, levels=3, dct_block=8) for k in range(3)]
+    clips = [_frames(c, n, dev) for c in cfgs]
+    want = []
+    for f in clips:
+        s = clipmod.Clip(CFG, n, schedule=clipmod.SERIAL, wire=wire, tuning=clipmod.TUNE_TWO_BGR_PASSES, ransac=dict(inlier_thresh=1.5))
+        s.load_frames(f)
+        s.step()
+        s.sync()
+        want.append((s.outputs(), s.read(buf), s.read("pyramids")))
+        s.close()
+
+    def check(enc, k, tag):
+        out = enc.outputs()  # syncs
+        for key in want[k][0]:
+            assert torch.equal(out[key], want[k][0][key]), (tag, key)
+        assert torch.equal(enc.read(buf), want[k][1]), tag
+        assert torch.equal(enc.read("pyramids")[enc.info.pyramid_stride:], want[k][2][enc.info.pyramid_stride:]), tag
+    for schedule, lat_depth, chunk_pairs in ((clipmod.SERIAL, 0, 0), (clipmod.PIPELINED, 0, 0), (clipmod.PIPELINED, 1, 3), (clipmod.PIPELINED, 3, 0)):
+        enc = clipmod.Clip(CFG, n, schedule=schedule, wire=wire, lat_depth=lat_depth, chunk_pairs=chunk_pairs, tuning=tuning,
+                           ransac=dict(inlier_thresh=1.5))
+        work = [c.clone() for c in clips]  # the stream's buffers (clobbered below)
+        enc.load_frames(clips[0])
+        enc.step()
+        steps = [enc.step_frames(work[k]) for k in (1, 2, 3, 1)]
+        check(enc, 1, (schedule, lat_depth, "first burst"))
+        assert steps == [1, 2, 3, 4]
+        # a longer run; the early buffers are given back and destroyed while the late steps are in flight
+        seq = [2, 3, 0, 1, 2, 3, 0, 2]
+        ids = [enc.step_frames(work[k]) for k in seq]
+        enc.wait_step(ids[3])  # steps over work[2], work[3], work[0], work[1] have let go of their frames ...
+        enc.step()             # (the resident clip in between)
+        ids.append(enc.step_frames(work[1]))
+        enc.wait_step(ids[6])  # ... and so have the next three
+        for k in (0, 3):       # not needed again below: work[2] (ids[7]) and work[1] (the last step) may still be read
+            work[k].random_(0, 256)
+        check(enc, 1, (schedule, lat_depth, "second burst"))
+        work[1].random_(0, 256)
+        enc.step()
+        check(enc, 0, (schedule, lat_depth, "the resident clip again"))
+        with pytest.raises(clipmod.ClipError):
+            enc.wait_step(10 ** 6)  # never submitted
+        enc.close()
+
+
 def test_random_call_sequences_give_the_serial_encoders_bytes(native):
     """A slice of tests/helpers/driver_fuzz.py: random configurations of the pipelined driver (output form, chunk plan, pipeline depth, the
     switches of round 6) under random sequences of load / step x k / flush / sync / reset_policy / read over clips whose foreground share
