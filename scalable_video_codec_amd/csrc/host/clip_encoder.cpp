@@ -762,6 +762,8 @@ void ClipEncoder::Step(bool timed) { StepOn(p_->bgr.p, timed); }
 
 uint32_t ClipEncoder::StepFrames(const uint8_t* device_frames, bool timed) {
   if (!device_frames) throw std::runtime_error("svc::ClipEncoder: StepFrames needs the shard's frames in device memory");
+  // refused HERE, before anything of the step is in the pipeline (the kernels' own checks would refuse it stage by stage)
+  if (reinterpret_cast<uintptr_t>(device_frames) % 16 != 0) throw std::runtime_error("svc::ClipEncoder: StepFrames: the frames must be 16-byte aligned");
   StepOn(device_frames, timed);
   return p_->n_steps - 1;
 }

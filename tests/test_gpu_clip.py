@@ -720,6 +720,11 @@ def test_a_stream_of_clips_encoded_where_they_are(native, form):
         check(enc, 0, (schedule, lat_depth, "the resident clip again"))
         with pytest.raises(clipmod.ClipError):
             enc.wait_step(10 ** 6)  # never submitted
+        odd = torch.empty(clips[0].numel() + 16, dtype=torch.uint8, device=dev)[4:4 + clips[0].numel()].view(clips[0].shape)
+        with pytest.raises(clipmod.ClipError):
+            enc.step_frames(odd)  # 4 bytes off a 16-byte boundary: refused before anything is enqueued ...
+        enc.step()
+        check(enc, 0, (schedule, lat_depth, "after a refused step"))  # ... so the pipeline is as it was
         enc.close()
 
 
