@@ -646,7 +646,8 @@ def first_encode(args, enc, clip_dev, info, chunks: int) -> dict:
     out["note"] = ("outside the timed region; wall clock around step() + sync() (the pipeline's fill and drain included).  once_through: "
                    "load_frames before every repetition voids the speculation policy, so the step runs the two-pass order (in two halves on a big "
                    "shard: the idle-pipeline rule; --mixed-steps: the second half reading its frames once, blind); with_prior: the resident clip "
-                   "again with the last measurement kept")
+                   "again with the last measurement kept -- an ISOLATED one-pass step, whose RANSAC + segmentation + redo are exposed at its end (it can "
+                   "be slower than once_through's two-pass halves); stream_of_clips: the same policy state in a stream, where nothing is exposed")
     return out
 
 
