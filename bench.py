@@ -420,7 +420,7 @@ def run_mode(args, cfg, mode: str, rank: int, world: int, dev, backend: str, com
     tuning = (clipmod.TUNE_STANDALONE_SHAPES if args.standalone_shapes else 0) | (clipmod.TUNE_SEGMENT_FORK if args.segment_fork else 0) | \
              (clipmod.TUNE_NARROW_ATTEMPTS if args.narrow_attempts else 0) | (clipmod.TUNE_INLINE_RMSE if args.inline_rmse else 0) | \
              (clipmod.TUNE_TWO_BGR_PASSES if args.two_bgr_passes else 0) | (clipmod.TUNE_ALWAYS_SPECULATE if args.always_speculate else 0) | \
-             (clipmod.TUNE_WHOLE_SHARD_STEPS if args.whole_shard_steps else 0) | (clipmod.TUNE_SEARCH_AFTER_TRANSFORM if args.search_after_transform else 0) | (clipmod.TUNE_MIXED_STEPS if args.mixed_steps else 0)
+             (clipmod.TUNE_WHOLE_SHARD_STEPS if args.whole_shard_steps else 0) | (clipmod.TUNE_SEARCH_AFTER_TRANSFORM if args.search_after_transform else 0) | (clipmod.TUNE_MIXED_STEPS if args.mixed_steps else 0) | (clipmod.TUNE_FORK_BEHIND_FRONT if args.fork_behind_front else 0)
     enc = clipmod.Clip(cfg, clip_frames, rank=rank, world=world, schedule=schedule,
                        segmentation=not args.no_segmentation, wire=args.wire, hbma_flags=hbma_flags,
                        lat_depth=args.lat_depth, tuning=tuning, chunk_pairs=args.chunk_pairs)
@@ -684,6 +684,8 @@ def main() -> None:
     ap.add_argument("--wire", action="store_true", help="emit the serialised records of libs/encoder.cpp:222-269 (fused into the DCT kernel) instead of coefficient planes")
     ap.add_argument("--search-after-transform", action="store_true",
                     help="one rank: the motion search, not a pyramid pass, runs right behind the transform kernel (A/B)")
+    ap.add_argument("--fork-behind-front", action="store_true",
+                    help="A/B: RANSAC + segmentation of the previous step fork behind the front-of-step transform (beside the pyramid pass and the search)")
     ap.add_argument("--mixed-steps", action="store_true",
                     help="A/B: a step into an empty pipeline that knows nothing about the clip takes the mixed form (first half two passes, second half one pass, blind)")
     ap.add_argument("--whole-shard-steps", action="store_true",

@@ -106,6 +106,7 @@ struct ClipEncoderConfig {
                                         // two-pass order (the idle-pipeline rule, Step())
   bool whole_shard_steps = false;       // never the idle-pipeline rule (A/B)
   bool idle_rule_any_size = false;  // the idle-pipeline rule (Step()) whatever the shard's size (tests: it is tuned for >= 400 M pixels x frames)
+  bool fork_behind_front = false;   // one rank, A/B: RANSAC + segmentation fork behind the front-of-step transform, not in front of it
   bool random_policy = false;       // tests: the speculation policy answers yes / no by a fixed pseudo-random sequence over the chunk launches
   bool mixed_steps = false;         // a step into an empty pipeline that knows nothing about the clip: first half two passes, second half one
                                     // pass, blind (A/B: - 2 % at 0.5 % foreground, + 5-8 % at 13 %; profiles/r06_ab_mixed_step.txt)

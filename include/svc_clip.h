@@ -40,6 +40,7 @@ typedef struct svc_clip svc_clip;
  * the first step over new frames runs the plain two-pass order).  Safe at any share: a stale prior costs one slow step, never a byte. */
 #define SVC_CLIP_KEEP_FOREGROUND_PRIOR 64u
 #define SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE 512u /* the idle-pipeline rule whatever the shard's size (tests; default: from 400 M pixels x frames) */
+#define SVC_CLIP_TUNE_FORK_BEHIND_FRONT 4096u /* one rank, A/B: RANSAC + segmentation of the previous micro-step fork behind the front-of-step transform */
 #define SVC_CLIP_TUNE_RANDOM_POLICY 2048u /* tests: the speculation policy answers yes / no by a fixed pseudo-random sequence over the chunk launches */
 #define SVC_CLIP_TUNE_MIXED_STEPS 1024u /* a step into an empty pipeline that knows nothing about the clip takes the mixed form (two-pass half +
                                            blind one-pass half): A/B, off by default (- 2 % at 0.5 % foreground, + 5-8 % at 13 %) */

@@ -21,6 +21,7 @@ _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
 SERIAL, PIPELINED = 0, 1
 TUNE_STANDALONE_SHAPES, TUNE_SEGMENT_FORK, TUNE_NARROW_ATTEMPTS, TUNE_INLINE_RMSE, TUNE_TWO_BGR_PASSES, TUNE_ALWAYS_SPECULATE = 1, 2, 4, 8, 16, 32  # svc_clip_config.tuning bits
 TUNE_IDLE_RULE_ANY_SIZE = 512  # the idle-pipeline rule whatever the shard's size (tests)
+TUNE_FORK_BEHIND_FRONT = 4096  # one rank, A/B: RANSAC + segmentation fork behind the front-of-step transform
 TUNE_RANDOM_POLICY = 2048  # tests: the speculation policy answers yes / no by a fixed pseudo-random sequence over the chunk launches
 TUNE_MIXED_STEPS = 1024  # a step into an empty pipeline that knows nothing about the clip takes the mixed form (A/B, off by default)
 TUNE_SEARCH_AFTER_TRANSFORM = 256  # one rank: the motion search right behind the transform kernel (A/B)

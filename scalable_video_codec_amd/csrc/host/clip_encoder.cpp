@@ -531,7 +531,11 @@ struct ClipEncoder::Impl {
     const uint64_t l = n_lat, d = n_dct;
     // draining (no new step) joins at once; otherwise the transform of micro-step d waits until lat(d) has had its iterations
     const bool do_dct = n_dct < lats && (!new_step || iter - fork_iter[Slot(d)] >= (uint64_t)depth);
-    if (do_lat) ForkLat(l, timing);  // forked where the previous iteration's main-stream work ends
+    // forked where the previous iteration's main-stream work ends -- or (fork_behind_front, A/B) behind the front-of-step transform of a
+    // micro-step that reads its frames once, so that RANSAC + segmentation run beside the pyramid pass and the motion search instead of beside
+    // the store-bound transform's first third
+    const bool fork_late = c.fork_behind_front && c.world == 1 && new_step && next_micro.pn && (one_bgr_pass || (spec_quant && decided));
+    if (do_lat && !fork_late) ForkLat(l, timing);
     // search_after_transform (one rank; A/B): whatever kernel follows the transform shares the memory system with the write-back of what it
     // left dirty (0.03 ms at C3, profiles/r06_ab_pyr_strip.txt).  With this switch that kernel is the motion search instead of a pyramid
     // pass: a one-pass micro-step runs transform(m) | search(m - 1) | pyramid levels(m) (the search one micro-step behind, as on a
@@ -546,7 +550,10 @@ struct ClipEncoder::Impl {
       const int b = Par(m);
       if (c.world > 1 && halo_recorded[b])  // the send out of pyr[b] two steps ago must have left
         Hip(hipStreamWaitEvent(sM, e_halo[b], 0), "hipStreamWaitEvent");
-      Luma(m, sM, timing, [&] { if (reorder) { pending_searches(lumas_before); hbma_done = true; } });
+      Luma(m, sM, timing, [&] {
+        if (do_lat && fork_late) ForkLat(l, timing);
+        if (reorder) { pending_searches(lumas_before); hbma_done = true; }
+      });
       if (c.world > 1) Halo(m, timing);
       ++n_luma;
     }
@@ -929,7 +936,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     constexpr uint32_t kTuneBits = SVC_CLIP_TUNE_STANDALONE_SHAPES | SVC_CLIP_TUNE_SEGMENT_FORK | SVC_CLIP_TUNE_NARROW_ATTEMPTS | SVC_CLIP_TUNE_INLINE_RMSE |
                                    SVC_CLIP_TUNE_TWO_BGR_PASSES | SVC_CLIP_TUNE_ALWAYS_SPECULATE | SVC_CLIP_KEEP_FOREGROUND_PRIOR |
                                    SVC_CLIP_TUNE_WHOLE_SHARD_STEPS | SVC_CLIP_TUNE_SEARCH_AFTER_TRANSFORM | SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE |
-                                   SVC_CLIP_TUNE_MIXED_STEPS | SVC_CLIP_TUNE_RANDOM_POLICY;
+                                   SVC_CLIP_TUNE_MIXED_STEPS | SVC_CLIP_TUNE_RANDOM_POLICY | SVC_CLIP_TUNE_FORK_BEHIND_FRONT;
     if (k->hbma_flags & ~kHbmaBits) throw std::runtime_error("svc_clip_create: unknown hbma_flags bits");
     if (k->tuning & ~kTuneBits) throw std::runtime_error("svc_clip_create: unknown tuning bits");
     if (k->lat_depth > 3) throw std::runtime_error("svc_clip_create: lat_depth must be 0..3");
@@ -954,6 +961,7 @@ int svc_clip_create(const svc_clip_config* k, svc_clip** out) {
     c.idle_rule_any_size = (k->tuning & SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE) != 0;
     c.mixed_steps = (k->tuning & SVC_CLIP_TUNE_MIXED_STEPS) != 0;
     c.random_policy = (k->tuning & SVC_CLIP_TUNE_RANDOM_POLICY) != 0;
+    c.fork_behind_front = (k->tuning & SVC_CLIP_TUNE_FORK_BEHIND_FRONT) != 0;
     c.chunk_pairs = k->chunk_pairs;
     std::unique_ptr<svc_clip> h(new svc_clip);
     h->cfg = c;

@@ -89,7 +89,7 @@ def one_encoder(rng, dev, shapes, clips, refs, ops, log, max_world=4):
     # (small shards can speculate by the POLICY only with the idle rule's size waiver: SVC_CLIP_TUNE_IDLE_RULE_ANY_SIZE)
     for bit, p in ((clipmod.TUNE_IDLE_RULE_ANY_SIZE, 0.85 if form == "policy" else 0.5), (clipmod.TUNE_MIXED_STEPS, 0.4), (clipmod.TUNE_SEARCH_AFTER_TRANSFORM, 0.3),
                    (clipmod.KEEP_FOREGROUND_PRIOR, 0.3), (clipmod.TUNE_WHOLE_SHARD_STEPS, 0.15), (clipmod.TUNE_INLINE_RMSE, 0.2),
-                   (clipmod.TUNE_NARROW_ATTEMPTS, 0.2), (clipmod.TUNE_RANDOM_POLICY, 0.35 if form == "policy" else 0.0)):
+                   (clipmod.TUNE_NARROW_ATTEMPTS, 0.2), (clipmod.TUNE_FORK_BEHIND_FRONT, 0.3), (clipmod.TUNE_RANDOM_POLICY, 0.35 if form == "policy" else 0.0)):
         if rng.random() < p:
             tuning |= bit
     chunk_pairs = int(rng.integers(1, n)) if rng.random() < 0.4 else 0
